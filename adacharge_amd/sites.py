@@ -1,0 +1,191 @@
+"""Synthetic charging sites and MPC-snapshot generators.
+
+These are *inputs*, not part of the reference: the reference ships no site
+definitions (they live in acnportal, absent here).  ``caltech54`` follows the
+shape of acnportal's ``caltech_acn`` as recalled in SURVEY.md section 8d and is
+labelled "Caltech-shaped" everywhere it is reported.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .acn import InfrastructureInfo, SessionInfo
+
+
+def caltech54(voltage: float = 208.0, max_pilot: float = 32.0) -> InfrastructureInfo:
+    """54 EVSEs on a 3-phase delta: 26 on AB (+30 deg), 14 on BC (-90 deg),
+    14 on CA (+150 deg).  8 constraint rows: two 80 A pods of 8 EVSEs with
+    mixed phases, three secondary (per-phase-pair sum) rows at 416.667 A and
+    three primary rows 1/4 (I_x - I_y) at 180.505 A; 178 non-zeros."""
+    n_ab, n_bc, n_ca = 26, 14, 14
+    n = n_ab + n_bc + n_ca
+    phases = np.array([30.0] * n_ab + [-90.0] * n_bc + [150.0] * n_ca)
+    ab = np.arange(0, n_ab)
+    bc = np.arange(n_ab, n_ab + n_bc)
+    ca = np.arange(n_ab + n_bc, n)
+    cm = np.zeros((8, n))
+    av_pod = np.r_[ab[:3], bc[:3], ca[:2]]
+    cc_pod = np.r_[ab[3:6], bc[3:5], ca[2:5]]
+    cm[0, av_pod] = 1.0
+    cm[1, cc_pod] = 1.0
+    cm[2, ab] = 1.0
+    cm[3, bc] = 1.0
+    cm[4, ca] = 1.0
+    cm[5, ab], cm[5, ca] = 0.25, -0.25
+    cm[6, bc], cm[6, ab] = 0.25, -0.25
+    cm[7, ca], cm[7, bc] = 0.25, -0.25
+    sec = 150e3 / 3 / 120
+    pri = 150e3 / 3 / 277
+    limits = np.array([80.0, 80.0, sec, sec, sec, pri, pri, pri])
+    ids = ["AV-Pod", "CC-Pod", "Sec-A", "Sec-B", "Sec-C", "Pri-A", "Pri-B", "Pri-C"]
+    return InfrastructureInfo(
+        cm,
+        limits,
+        phases,
+        np.full(n, voltage),
+        constraint_ids=ids,
+        station_ids=[f"CT-{i:03d}" for i in range(n)],
+        max_pilot=np.full(n, max_pilot),
+        min_pilot=np.full(n, 8.0),
+        allowable_pilots=[np.r_[0.0, np.arange(8.0, max_pilot + 1)] for _ in range(n)],
+        is_continuous=np.zeros(n, dtype=bool),
+    )
+
+
+def balanced_three_phase(
+    n_evse: int,
+    pods: int,
+    load_fraction: float = 1.0 / 3.0,
+    voltage: float = 208.0,
+    max_pilot: float = 32.0,
+    name: str = "SY",
+) -> InfrastructureInfo:
+    """Synthetic three-phase site in the same style (used for "jpl52" and
+    "synth512", both *synthetic*): ``pods`` contiguous pod rows, three
+    per-phase-pair sums and three primary difference rows, every limit set to
+    ``load_fraction`` of that row's full-load magnitude."""
+    per = [n_evse // 3 + (1 if r < n_evse % 3 else 0) for r in range(3)]
+    phases = np.repeat([30.0, -90.0, 150.0], per)
+    idx = np.split(np.arange(n_evse), np.cumsum(per)[:-1])
+    rows = []
+    for members in np.array_split(np.random.default_rng(7).permutation(n_evse), pods):
+        r = np.zeros(n_evse)
+        r[members] = 1.0
+        rows.append(r)
+    for g in idx:
+        r = np.zeros(n_evse)
+        r[g] = 1.0
+        rows.append(r)
+    for a, b in ((0, 2), (1, 0), (2, 1)):
+        r = np.zeros(n_evse)
+        r[idx[a]] = 0.25
+        r[idx[b]] = -0.25
+        rows.append(r)
+    cm = np.array(rows)
+    ph = np.deg2rad(phases)
+    full = np.hypot((cm * np.cos(ph)) @ np.full(n_evse, max_pilot),
+                    (cm * np.sin(ph)) @ np.full(n_evse, max_pilot))
+    limits = load_fraction * full
+    return InfrastructureInfo(
+        cm,
+        limits,
+        phases,
+        np.full(n_evse, voltage),
+        constraint_ids=[f"{name}-c{j}" for j in range(len(rows))],
+        station_ids=[f"{name}-{i:04d}" for i in range(n_evse)],
+        max_pilot=np.full(n_evse, max_pilot),
+        min_pilot=np.full(n_evse, 8.0),
+        allowable_pilots=[np.r_[0.0, np.arange(8.0, max_pilot + 1)] for _ in range(n_evse)],
+        is_continuous=np.zeros(n_evse, dtype=bool),
+    )
+
+
+def jpl52() -> InfrastructureInfo:
+    """Synthetic 52-EVSE site (the real JPL topology is not available)."""
+    return balanced_three_phase(52, pods=4, load_fraction=0.45, name="JP")
+
+
+def synth512() -> InfrastructureInfo:
+    """Synthetic 512-EVSE site, M = 12 pods + 3 + 3 = 18 rows, limits at 1/3."""
+    return balanced_three_phase(512, pods=12, load_fraction=1.0 / 3.0, name="SY")
+
+
+def random_sessions(
+    infra: InfrastructureInfo,
+    horizon: int,
+    rng: np.random.Generator,
+    min_sessions: int = 10,
+    max_rate: float = 32.0,
+    demand_range=(0.5, 20.0),
+    min_rate_fraction: float = 0.0,
+) -> List[SessionInfo]:
+    """One MPC state snapshot ("Instance"): S ~ U{min..N}
+    distinct EVSEs, arrival_offset 0, remaining_time ~ U{1..T} with one forced
+    to T, remaining_demand ~ U(lo, hi) kWh, min_rates 0, max_rates ``max_rate``;
+    ``min_rate_fraction`` of the sessions get ``min_rates[0] = 8``."""
+    n = infra.num_stations
+    s = int(rng.integers(min(min_sessions, n), n + 1))
+    evses = rng.choice(n, size=s, replace=False)
+    rem = rng.integers(1, horizon + 1, size=s)
+    rem[int(rng.integers(0, s))] = horizon
+    demand = rng.uniform(demand_range[0], demand_range[1], size=s)
+    sessions = []
+    for k in range(s):
+        mins = np.zeros(int(rem[k]))
+        if min_rate_fraction > 0 and rng.random() < min_rate_fraction:
+            mins[0] = 8.0
+        sessions.append(
+            SessionInfo(
+                infra.station_ids[int(evses[k])],
+                f"s{k}",
+                float(demand[k]),
+                0.0,
+                0,
+                int(rem[k]),
+                current_time=0,
+                min_rates=mins,
+                max_rates=max_rate,
+            )
+        )
+    return sessions
+
+
+def snapshot_batch(
+    infra: InfrastructureInfo,
+    horizon: int,
+    batch: int,
+    seed: int = 20240,
+    **kw,
+) -> List[List[SessionInfo]]:
+    """``batch`` independent snapshots from one SeedSequence spawned B ways."""
+    children = np.random.SeedSequence(seed).spawn(batch)
+    return [random_sessions(infra, horizon, np.random.default_rng(c), **kw) for c in children]
+
+
+def demand_scenarios(
+    sessions: Sequence[SessionInfo], n_scenarios: int, rng: np.random.Generator, sigma: float = 0.25
+) -> List[List[SessionInfo]]:
+    """Stochastic-MPC scenarios (config 4): same windows, remaining demand
+    scaled by lognormal(0, sigma) per session per scenario."""
+    out = []
+    for _ in range(n_scenarios):
+        scen = []
+        for s in sessions:
+            f = float(rng.lognormal(0.0, sigma))
+            scen.append(
+                SessionInfo(
+                    s.station_id,
+                    s.session_id,
+                    s.energy_delivered + s.remaining_demand * f,
+                    s.energy_delivered,
+                    s.arrival,
+                    s.departure,
+                    current_time=s.current_time,
+                    min_rates=s.min_rates.copy(),
+                    max_rates=s.max_rates.copy(),
+                )
+            )
+        out.append(scen)
+    return out
