@@ -1,0 +1,298 @@
+"""ctypes binding of the C ABI in include/acn_qp.h (libacn_qp_hip.so).
+
+There is exactly one compute path: the HIP library.  If it is missing or no GPU
+is visible, everything here raises -- there is no CPU fallback by design
+(the CPU implementations under oracle/ are test infrastructure and are never
+imported from this package).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from .builder import CONE_SOC, ProblemBatch, SiteData
+
+_LIB_NAME = "libacn_qp_hip.so"
+_LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+
+STATUS_UNSET = 0
+STATUS_SOLVED = 1
+STATUS_MAX_ITER = 2
+STATUS_PRIMAL_INFEASIBLE = 3
+STATUS_EMPTY_SET = 4
+STATUS_NAMES = {
+    STATUS_UNSET: "unset",
+    STATUS_SOLVED: "optimal",
+    STATUS_MAX_ITER: "max_iter_reached",
+    STATUS_PRIMAL_INFEASIBLE: "infeasible",
+    STATUS_EMPTY_SET: "infeasible",
+}
+
+
+class BackendUnavailable(RuntimeError):
+    """The HIP library could not be loaded or no MI355X is visible."""
+
+
+class _Site(C.Structure):
+    _fields_ = [
+        ("n_evse", C.c_int32),
+        ("n_infra", C.c_int32),
+        ("n_rows", C.c_int32),
+        ("cone", C.c_int32),
+        ("has_peak", C.c_int32),
+        ("G", C.c_void_p),
+        ("limits", C.c_void_p),
+    ]
+
+
+class _Problems(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32),
+        ("t_max", C.c_int32),
+        ("k_sessions", C.c_int32),
+        ("horizon", C.c_void_p),
+        ("lb", C.c_void_p),
+        ("ub", C.c_void_p),
+        ("q", C.c_void_p),
+        ("pdiag", C.c_void_p),
+        ("s_off", C.c_void_p),
+        ("s_len", C.c_void_p),
+        ("s_cap", C.c_void_p),
+        ("s_eq", C.c_void_p),
+        ("peak", C.c_void_p),
+    ]
+
+
+class _Results(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("status", C.c_void_p),
+        ("iters", C.c_void_p),
+        ("pri_res", C.c_void_p),
+        ("dua_res", C.c_void_p),
+        ("obj", C.c_void_p),
+    ]
+
+
+class Options(C.Structure):
+    """Mirror of ``acnqp_options``; construct with ``default_options()``."""
+
+    _fields_ = [
+        ("eps_abs", C.c_double),
+        ("eps_rel", C.c_double),
+        ("max_iter", C.c_int32),
+        ("check_every", C.c_int32),
+        ("adapt_every", C.c_int32),
+        ("rho", C.c_double),
+        ("sigma", C.c_double),
+        ("alpha", C.c_double),
+        ("adapt_tol", C.c_double),
+        ("reg_min", C.c_double),
+        ("precision", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+# every symbol include/acn_qp.h declares; tests check the library exports all of them
+EXPORTED_SYMBOLS = (
+    "acnqp_create",
+    "acnqp_solve_batch",
+    "acnqp_solve_batch_device",
+    "acnqp_destroy",
+    "acnqp_default_options",
+    "acnqp_last_error",
+    "acnqp_abi_version",
+    "acnqp_last_kernel_ms",
+)
+
+_lib = None
+
+
+def library_path() -> str:
+    return os.environ.get("ACNQP_LIBRARY", os.path.join(_LIB_DIR, _LIB_NAME))
+
+
+def load_library():
+    """dlopen the HIP library (once) and set the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise BackendUnavailable(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  adacharge_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(path)
+    except OSError as exc:  # missing ROCm runtime etc.
+        raise BackendUnavailable(f"cannot load {path}: {exc}") from exc
+    lib.acnqp_create.argtypes = [C.POINTER(_Site), C.c_int32, C.POINTER(C.c_void_p)]
+    lib.acnqp_create.restype = C.c_int
+    lib.acnqp_solve_batch.argtypes = [C.c_void_p, C.POINTER(_Problems), C.POINTER(Options), C.POINTER(_Results)]
+    lib.acnqp_solve_batch.restype = C.c_int
+    lib.acnqp_solve_batch_device.argtypes = [
+        C.c_void_p, C.POINTER(_Problems), C.POINTER(Options), C.POINTER(_Results), C.c_void_p,
+    ]
+    lib.acnqp_solve_batch_device.restype = C.c_int
+    lib.acnqp_destroy.argtypes = [C.c_void_p]
+    lib.acnqp_destroy.restype = None
+    lib.acnqp_default_options.argtypes = [C.POINTER(Options)]
+    lib.acnqp_default_options.restype = None
+    lib.acnqp_last_error.argtypes = []
+    lib.acnqp_last_error.restype = C.c_char_p
+    lib.acnqp_abi_version.argtypes = []
+    lib.acnqp_abi_version.restype = C.c_int32
+    lib.acnqp_last_kernel_ms.argtypes = [C.c_void_p]
+    lib.acnqp_last_kernel_ms.restype = C.c_float
+    _lib = lib
+    return lib
+
+
+def default_options(**overrides) -> Options:
+    o = Options()
+    load_library().acnqp_default_options(C.byref(o))
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown solver option {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load_library().acnqp_last_error().decode()
+        if rc == -3:
+            raise BackendUnavailable(f"{what}: {msg}")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class BatchResult:
+    x: np.ndarray        # (B, N, Tm)
+    status: np.ndarray   # (B,) int32
+    iters: np.ndarray    # (B,) int32
+    pri_res: np.ndarray
+    dua_res: np.ndarray
+    obj: np.ndarray
+    kernel_ms: float = float("nan")
+
+
+class SiteHandle:
+    """One ``acnqp_handle``: a site uploaded to one GPU."""
+
+    def __init__(self, site: SiteData, device: int = 0):
+        self._lib = load_library()
+        self.site = site
+        self.device = int(device)
+        G = np.ascontiguousarray(site.G, dtype=np.float64)
+        lim = np.ascontiguousarray(site.limits, dtype=np.float64)
+        desc = _Site(
+            site.N, site.M, site.Mg, 1 if site.cone == CONE_SOC else 0, 1 if site.has_peak else 0,
+            _ptr(G) if G.size else None, _ptr(lim) if lim.size else None,
+        )
+        h = C.c_void_p()
+        _check(self._lib.acnqp_create(C.byref(desc), self.device, C.byref(h)), "acnqp_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.acnqp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host buffers -----------------------------------------------------------
+    def solve(self, batch: ProblemBatch, options: Optional[Options] = None) -> BatchResult:
+        if batch.site is not self.site and (
+            batch.site.Mg != self.site.Mg or batch.site.N != self.site.N or batch.site.cone != self.site.cone
+        ):
+            raise ValueError("batch was built for a different site than this handle")
+        o = options if options is not None else default_options()
+        B, N, Tm = batch.B, batch.N, batch.Tm
+        arrs = dict(
+            horizon=np.ascontiguousarray(batch.T, np.int32),
+            lb=np.ascontiguousarray(batch.lb, np.float64),
+            ub=np.ascontiguousarray(batch.ub, np.float64),
+            q=np.ascontiguousarray(batch.q, np.float64),
+            pdiag=np.ascontiguousarray(batch.pdiag, np.float64),
+            s_off=np.ascontiguousarray(batch.s_off, np.int32),
+            s_len=np.ascontiguousarray(batch.s_len, np.int32),
+            s_cap=np.ascontiguousarray(batch.s_cap, np.float64),
+            s_eq=np.ascontiguousarray(batch.s_eq, np.uint8),
+        )
+        peak = None if batch.peak is None else np.ascontiguousarray(batch.peak, np.float64)
+        p = _Problems(B, Tm, batch.K, *[_ptr(arrs[k]) for k in
+                                       ("horizon", "lb", "ub", "q", "pdiag", "s_off", "s_len", "s_cap", "s_eq")],
+                      _ptr(peak))
+        res = BatchResult(
+            np.zeros((B, N, Tm)), np.zeros(B, np.int32), np.zeros(B, np.int32),
+            np.zeros(B), np.zeros(B), np.zeros(B),
+        )
+        r = _Results(_ptr(res.x), _ptr(res.status), _ptr(res.iters), _ptr(res.pri_res), _ptr(res.dua_res), _ptr(res.obj))
+        _check(self._lib.acnqp_solve_batch(self._h, C.byref(p), C.byref(o), C.byref(r)), "acnqp_solve_batch")
+        res.kernel_ms = float(self._lib.acnqp_last_kernel_ms(self._h))
+        if batch.presolve_status is not None:
+            res.status[batch.presolve_status != 0] = STATUS_EMPTY_SET
+        return res
+
+    # -- device buffers (torch tensors or any object with data_ptr()) --------------
+    def solve_device(self, dev: "DeviceBatch", options: Optional[Options] = None, stream: int = 0) -> None:
+        o = options if options is not None else default_options()
+        p = _Problems(
+            dev.B, dev.Tm, dev.K,
+            dev.horizon.data_ptr(), dev.lb.data_ptr(), dev.ub.data_ptr(), dev.q.data_ptr(), dev.pdiag.data_ptr(),
+            dev.s_off.data_ptr(), dev.s_len.data_ptr(), dev.s_cap.data_ptr(), dev.s_eq.data_ptr(),
+            None if dev.peak is None else dev.peak.data_ptr(),
+        )
+        r = _Results(dev.x.data_ptr(), dev.status.data_ptr(), dev.iters.data_ptr(),
+                     dev.pri_res.data_ptr(), dev.dua_res.data_ptr(), dev.obj.data_ptr())
+        _check(
+            self._lib.acnqp_solve_batch_device(self._h, C.byref(p), C.byref(o), C.byref(r), C.c_void_p(stream)),
+            "acnqp_solve_batch_device",
+        )
+
+    def last_kernel_ms(self) -> float:
+        return float(self._lib.acnqp_last_kernel_ms(self._h))
+
+
+class DeviceBatch:
+    """A ProblemBatch resident in HBM (torch tensors on one GPU) plus result
+    tensors; torch is used for device memory only."""
+
+    def __init__(self, batch: ProblemBatch, device):
+        import torch
+
+        dev = torch.device(device)
+        self.B, self.N, self.Tm, self.K = batch.B, batch.N, batch.Tm, batch.K
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+        self.horizon = t(batch.T, np.int32)
+        self.lb = t(batch.lb, np.float64)
+        self.ub = t(batch.ub, np.float64)
+        self.q = t(batch.q, np.float64)
+        self.pdiag = t(batch.pdiag, np.float64)
+        self.s_off = t(batch.s_off, np.int32)
+        self.s_len = t(batch.s_len, np.int32)
+        self.s_cap = t(batch.s_cap, np.float64)
+        self.s_eq = t(batch.s_eq, np.uint8)
+        self.peak = None if batch.peak is None else t(batch.peak, np.float64)
+        self.x = torch.zeros((self.B, self.N, self.Tm), dtype=torch.float64, device=dev)
+        self.status = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        self.iters = torch.zeros(self.B, dtype=torch.int32, device=dev)
+        self.pri_res = torch.zeros(self.B, dtype=torch.float64, device=dev)
+        self.dua_res = torch.zeros(self.B, dtype=torch.float64, device=dev)
+        self.obj = torch.zeros(self.B, dtype=torch.float64, device=dev)

@@ -1,0 +1,246 @@
+"""Direct problem builder: sessions + infrastructure -> structured QP batch.
+
+Replaces the reference's cvxpy expression-tree construction
+(adaptive_charging_optimization.py:45-284) with plain numpy arrays that the
+C-ABI (include/acn_qp.h) consumes.  Nothing here forms the explicit (P, q, A,
+l, u): the constraint structure is kept symbolic --
+
+  * per-variable bounds  lb <= r <= ub                       (aco.py:61-79)
+  * per-session energy   sum_{t in window} r[i,t] <= cap     (aco.py:105-123)
+        cap = remaining_demand / (V_i * period / 1e3 / 60)   [A-periods]
+  * shared site rows     G r[:,t]  in  box / disc / peak     (aco.py:145-198)
+  * objective            1/2 r'Pr + q'r,  P = pdiag I + lf (I_T (x) v v')
+                                                             (aco.py:200-218, 336-408)
+
+so the kernel can use a matrix-free ADMM whose only linear-algebra object is
+the tiny site matrix G (M_g x N), shared by every problem of the batch.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+CONE_LINEAR = 0
+CONE_SOC = 1
+
+
+@dataclass
+class SiteData:
+    """Per-site data shared by every QP of a batch (uploaded once per handle).
+
+    ``G`` rows: LINEAR -> |C| (M rows); SOC -> [C cos(phi); C sin(phi)] (2M
+    rows, row j pairs with row j+M); plus a trailing all-ones row when the
+    batch carries a peak limit (aco.py:196-198).  ``lam, Q`` is the
+    eigen-decomposition of G G' and ``Ghat = Q' G``; with them
+    (a I + rho G'G)^-1 = (I - Ghat' diag(rho / (a + rho lam)) Ghat) / a  for any
+    per-problem (a, rho), so no factorisation ever happens on the device."""
+
+    N: int
+    M: int
+    cone: int
+    has_peak: bool
+    G: np.ndarray
+    limits: np.ndarray
+    lam: np.ndarray
+    Q: np.ndarray
+    Ghat: np.ndarray
+    volt: np.ndarray
+
+    @property
+    def Mg(self) -> int:
+        return self.G.shape[0]
+
+
+def make_site(infrastructure, constraint_type: str = "SOC", with_peak: bool = False) -> SiteData:
+    N = len(infrastructure.station_ids)
+    cm = infrastructure.constraint_matrix
+    if cm is None or cm.shape == (0, 0):  # aco.py:145-149
+        rows = np.zeros((0, N))
+        limits = np.zeros(0)
+        M = 0
+        cone = CONE_LINEAR if constraint_type != "SOC" else CONE_SOC
+        if constraint_type not in ("SOC", "LINEAR"):
+            _bad_constraint_type(constraint_type)
+    elif constraint_type == "SOC":  # aco.py:151-164
+        if infrastructure.phases is None:
+            raise ValueError("phases is required when using SOC infrastructure constraints.")
+        ph = np.deg2rad(np.asarray(infrastructure.phases, float))
+        cm = np.asarray(cm, float)
+        rows = np.vstack([cm * np.cos(ph), cm * np.sin(ph)])
+        limits = np.asarray(infrastructure.constraint_limits, float).copy()
+        M = cm.shape[0]
+        cone = CONE_SOC
+    elif constraint_type == "LINEAR":  # aco.py:165-172
+        rows = np.abs(np.asarray(cm, float))
+        limits = np.asarray(infrastructure.constraint_limits, float).copy()
+        M = rows.shape[0]
+        cone = CONE_LINEAR
+    else:
+        _bad_constraint_type(constraint_type)
+    if with_peak:
+        rows = np.vstack([rows, np.ones((1, N))])
+    G = np.ascontiguousarray(rows, dtype=np.float64)
+    if G.shape[0]:
+        lam, Q = np.linalg.eigh(G @ G.T)
+        lam = np.maximum(lam, 0.0)
+        lam[lam < 1e-12 * max(1.0, lam.max())] = 0.0
+        Ghat = Q.T @ G
+        Ghat[lam == 0.0] = 0.0
+    else:
+        lam, Q, Ghat = np.zeros(0), np.zeros((0, 0)), np.zeros((0, N))
+    return SiteData(
+        N, M, cone, bool(with_peak), G, limits, lam,
+        np.ascontiguousarray(Q), np.ascontiguousarray(Ghat),
+        np.asarray(infrastructure.voltages, float).copy(),
+    )
+
+
+def _bad_constraint_type(constraint_type):
+    # same text as the reference, including its "AFFINE" wording (aco.py:174-178)
+    raise ValueError(
+        "Invalid infrastructure constraint type: {0}. Valid options are SOC or AFFINE.".format(
+            constraint_type
+        )
+    )
+
+
+@dataclass
+class ProblemBatch:
+    """B structured QPs over one site, padded to a common horizon ``Tm``."""
+
+    site: SiteData
+    B: int
+    Tm: int
+    K: int                      # max sessions per EVSE in this batch
+    T: np.ndarray               # (B,)  int32   own horizon (aco.py:243-245)
+    lb: np.ndarray              # (B, N, Tm) f64, 0 outside windows and for t >= T[b]
+    ub: np.ndarray              # (B, N, Tm) f64
+    q: np.ndarray               # (B, N, Tm) f64  linear cost of the *minimisation*
+    pdiag: np.ndarray           # (B,) f64   P = pdiag I          (equal_share)
+    lf: np.ndarray              # (B,) f64   P_t += lf v v'       (load_flattening), v = volt/1e3
+    s_off: np.ndarray           # (B, K, N) int32
+    s_len: np.ndarray           # (B, K, N) int32  (0 = no session in this slot)
+    s_cap: np.ndarray           # (B, K, N) f64    energy cap in A-periods
+    s_eq: np.ndarray            # (B,) uint8       1 = energy rows are equalities
+    peak: Optional[np.ndarray]  # (B, Tm) f64 or None; +inf = no limit in that period
+    const: np.ndarray = None    # (B,) f64 constant dropped from the objective
+    presolve_status: np.ndarray = None  # (B,) int32, nonzero = infeasible before any solve
+
+    @property
+    def N(self) -> int:
+        return self.site.N
+
+
+def objective_terms(objective, infrastructure, interface, N, T, prev_peak=0):
+    """Evaluate the objective list on a symbolic rates handle; see
+    adaptive_charging_optimization.py in this package for the descriptor
+    algebra.  Returns (q (N,T), pdiag, lf, const)."""
+    from .adaptive_charging_optimization import Rates, QuadObjective
+
+    rates = Rates((N, T))
+    total = QuadObjective.zero((N, T))
+    for component in objective:
+        kwargs = dict(prev_peak=prev_peak)
+        kwargs.update(component.kwargs)
+        term = component.function(rates, infrastructure, interface, **kwargs)
+        total = total + component.coefficient * term
+    if total.sq < 0 or total.flat < 0:
+        raise ValueError(
+            "Objective is not concave: the maximised objective has a positive "
+            "quadratic coefficient (cvxpy would reject it as non-DCP)."
+        )
+    # reference maximises `total`; we minimise its negation
+    return -total.lin, 2.0 * total.sq, 2.0 * total.flat, -total.const
+
+
+def build_batch(
+    session_lists: Sequence[Sequence],
+    infrastructure,
+    interface,
+    objective,
+    constraint_type: str = "SOC",
+    enforce_energy_equality: bool = False,
+    peak_limits: Optional[Sequence] = None,
+    prev_peak=0,
+    site: Optional[SiteData] = None,
+) -> ProblemBatch:
+    """One structured QP per entry of ``session_lists`` (all on one site)."""
+    B = len(session_lists)
+    N = len(infrastructure.station_ids)
+    if peak_limits is None:
+        peak_limits = [None] * B
+    any_peak = any(p is not None for p in peak_limits)
+    if site is None:
+        site = make_site(infrastructure, constraint_type, with_peak=any_peak)
+    elif any_peak and not site.has_peak:
+        raise ValueError("site was built without a peak row but a peak_limit was given")
+    station_index = {s: i for i, s in enumerate(infrastructure.station_ids)}
+    Ts = np.array(
+        [max(s.arrival_offset + s.remaining_time for s in sl) for sl in session_lists], dtype=np.int32
+    )  # aco.py:243-245
+    Tm = int(Ts.max())
+    volt = np.asarray(infrastructure.voltages, float)
+    period = interface.period
+
+    # sessions per EVSE
+    K = 1
+    for sl in session_lists:
+        cnt = {}
+        for s in sl:
+            cnt[s.station_id] = cnt.get(s.station_id, 0) + 1
+        K = max(K, max(cnt.values()))
+
+    lb = np.zeros((B, N, Tm))
+    ub = np.zeros((B, N, Tm))
+    q = np.zeros((B, N, Tm))
+    pdiag = np.zeros(B)
+    lf = np.zeros(B)
+    const = np.zeros(B)
+    s_off = np.zeros((B, K, N), dtype=np.int32)
+    s_len = np.zeros((B, K, N), dtype=np.int32)
+    s_cap = np.zeros((B, K, N))
+    s_eq = np.full(B, 1 if enforce_energy_equality else 0, dtype=np.uint8)
+    peak = np.full((B, Tm), np.inf) if site.has_peak else None
+    presolve = np.zeros(B, dtype=np.int32)
+
+    for b, sl in enumerate(session_lists):
+        T = int(Ts[b])
+        slot = np.zeros(N, dtype=np.int64)
+        occupied = np.zeros((N, Tm), dtype=bool)
+        for s in sl:  # aco.py:62-73
+            i = station_index[s.station_id]
+            o, r = int(s.arrival_offset), int(s.remaining_time)
+            lb[b, i, o : o + r] = s.min_rates
+            ub[b, i, o : o + r] = s.max_rates
+        bad = ub[b] < lb[b]  # aco.py:75
+        ub[b][bad] = lb[b][bad]
+        for s in sl:  # aco.py:105-123
+            i = station_index[s.station_id]
+            o, r = int(s.arrival_offset), int(s.remaining_time)
+            if r <= 0:
+                # empty window: 0 <= (==) remaining_demand
+                if s.remaining_demand < 0 or (enforce_energy_equality and s.remaining_demand != 0):
+                    presolve[b] = 1
+                continue
+            if occupied[i, o : o + r].any():
+                raise ValueError(
+                    f"sessions on EVSE {s.station_id} overlap in time; the structured "
+                    "builder needs disjoint session windows per EVSE"
+                )
+            occupied[i, o : o + r] = True
+            k = slot[i]
+            slot[i] += 1
+            s_off[b, k, i] = o
+            s_len[b, k, i] = r
+            kwh_per_amp_period = volt[i] * period / 1e3 / 60  # aco.py:114
+            s_cap[b, k, i] = s.remaining_demand / kwh_per_amp_period
+        qb, pd, lfc, c0 = objective_terms(objective, infrastructure, interface, N, T, prev_peak)
+        q[b, :, :T] = qb
+        pdiag[b], lf[b], const[b] = pd, lfc, c0
+        if peak is not None and peak_limits[b] is not None:  # aco.py:196-198
+            peak[b, :T] = np.broadcast_to(np.asarray(peak_limits[b], float), (T,))
+    return ProblemBatch(
+        site, B, Tm, K, Ts, lb, ub, q, pdiag, lf, s_off, s_len, s_cap, s_eq, peak, const, presolve
+    )

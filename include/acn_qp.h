@@ -1,0 +1,156 @@
+/*
+ * acn_qp.h -- C ABI of the MI355X batched MPC solver for adacharge.
+ *
+ * This is the drop-in boundary.  The reference has no FFI
+ * at this path: its "solver call" is the Python statement
+ *
+ *     prob.solve(solver=self.solver, verbose=verbose)
+ *         /root/reference/adacharge/adaptive_charging_optimization.py:318
+ *
+ * on a cvxpy Problem assembled at aco.py:220-284 and 315-317.  Each entry point
+ * below names the piece of that path it replaces.  Plain C types only; every
+ * buffer is owned by the caller; nothing is retained after a call returns
+ * (for the *_device form: after the stream has drained).
+ *
+ * Problem solved, for every b in [0, batch):
+ *
+ *   minimise    1/2 pdiag_b |r|^2 + <q_b, r>                   r in R^{N x Tm}
+ *   subject to  lb_b <= r <= ub_b                                (aco.py:61-79)
+ *               sum_{t in [off, off+len)} r[i, t] <= cap          (aco.py:105-123;
+ *                   (== cap when s_eq_b)                            cap in A-periods)
+ *               for every period t, rows of the site matrix G:
+ *                 LINEAR  (G r[:, t])_j <= limits_j               (aco.py:165-172)
+ *                 SOC     |((G r)_j, (G r)_{j+M})|_2 <= limits_j  (aco.py:151-164)
+ *                 peak    sum_i r[i, t] <= peak_b[t]              (aco.py:196-198)
+ *
+ * Layouts are C order: r, lb, ub, q are [batch][N][Tm] -- the (N, T) rates
+ * matrix the reference returns at aco.py:321, one per problem.
+ */
+#ifndef ACN_QP_H
+#define ACN_QP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACNQP_ABI_VERSION 1
+
+/* cone of the infrastructure rows (constraint_type at aco.py:35, 151, 165) */
+#define ACNQP_CONE_LINEAR 0
+#define ACNQP_CONE_SOC 1
+
+/* per-problem status; the Python layer maps anything but SOLVED to
+ * InfeasibilityException exactly as aco.py:319-320 does for cvxpy statuses */
+#define ACNQP_STATUS_UNSET 0
+#define ACNQP_STATUS_SOLVED 1             /* cp.OPTIMAL                     */
+#define ACNQP_STATUS_MAX_ITER 2           /* residuals above tolerance      */
+#define ACNQP_STATUS_PRIMAL_INFEASIBLE 3  /* ADMM certificate (cp.INFEASIBLE) */
+#define ACNQP_STATUS_EMPTY_SET 4          /* a session's bounds cannot meet its energy row */
+
+/* return codes (never C++ exceptions across the ABI) */
+#define ACNQP_OK 0
+#define ACNQP_ERR_INVALID (-1)     /* bad argument / unsupported shape */
+#define ACNQP_ERR_HIP (-2)         /* HIP runtime failure              */
+#define ACNQP_ERR_NO_DEVICE (-3)
+
+typedef struct acnqp_handle acnqp_handle; /* opaque; one per (site, GPU) */
+
+/* Site data shared by every problem of a batch: what InfrastructureInfo
+ * contributes to aco.py:126-198.  G is [n_rows][n_evse] row-major:
+ *   LINEAR: |constraint_matrix| (n_infra rows)            aco.py:171
+ *   SOC:    [C*cos(phi); C*sin(phi)] (2*n_infra rows)     aco.py:156-158
+ *   plus one trailing all-ones row iff has_peak           aco.py:197          */
+typedef struct {
+  int32_t n_evse;        /* N                                   */
+  int32_t n_infra;       /* M: rows of constraint_matrix         */
+  int32_t n_rows;        /* rows of G = M or 2M, + has_peak      */
+  int32_t cone;          /* ACNQP_CONE_*                         */
+  int32_t has_peak;      /* 0 / 1                                */
+  const double* G;       /* [n_rows * n_evse]                    */
+  const double* limits;  /* [n_infra]  constraint_limits         */
+} acnqp_site;
+
+/* One batch of structured problems.  Pointers are HOST pointers for
+ * acnqp_solve_batch and DEVICE pointers for acnqp_solve_batch_device. */
+typedef struct {
+  int32_t batch;           /* B                                              */
+  int32_t t_max;           /* Tm: padded horizon of every array below        */
+  int32_t k_sessions;      /* K: session slots per EVSE (>= 1)               */
+  const int32_t* horizon;  /* [B]        own horizon T_b <= Tm (aco.py:243)  */
+  const double* lb;        /* [B*N*Tm]   0 outside session windows           */
+  const double* ub;        /* [B*N*Tm]   finite                              */
+  const double* q;         /* [B*N*Tm]   linear cost (minimisation form)     */
+  const double* pdiag;     /* [B]        P = pdiag * I  (2 * equal_share)    */
+  const int32_t* s_off;    /* [B*K*N]    window start per (slot, EVSE)       */
+  const int32_t* s_len;    /* [B*K*N]    window length, 0 = empty slot       */
+  const double* s_cap;     /* [B*K*N]    energy cap in A-periods             */
+  const uint8_t* s_eq;     /* [B]        1: energy rows are equalities       */
+  const double* peak;      /* [B*Tm] or NULL; +inf = unlimited period        */
+} acnqp_problems;
+
+typedef struct {
+  double* x;         /* [B*N*Tm]  schedule (the feasible ADMM iterate z)      */
+  int32_t* status;   /* [B]       ACNQP_STATUS_*                              */
+  int32_t* iters;    /* [B]                                                   */
+  double* pri_res;   /* [B]       |A r - z|_inf at exit                       */
+  double* dua_res;   /* [B]       |P r + q + A'y|_inf at exit                 */
+  double* obj;       /* [B]       1/2 pdiag |x|^2 + <q, x>                    */
+} acnqp_results;
+
+/* Solver options -- the knobs cvxpy would forward to its solver (the
+ * reference sets none, aco.py:318; defaults: acnqp_default_options). */
+typedef struct {
+  double eps_abs;        /* absolute residual tolerance                       */
+  double eps_rel;        /* relative residual tolerance                       */
+  int32_t max_iter;
+  int32_t check_every;   /* residual check period (iterations)                */
+  int32_t adapt_every;   /* rho adaptation period, 0 = fixed rho              */
+  double rho;            /* initial ADMM penalty                              */
+  double sigma;          /* proximal weight on x                              */
+  double alpha;          /* over-relaxation in (0, 2)                         */
+  double adapt_tol;      /* adapt when the residual ratio leaves [1/tol, tol] */
+  double reg_min;        /* Tikhonov floor: effective pdiag = max(pdiag, reg_min);
+                            0 disables.  On LP instances a small floor returns
+                            the least-norm LP optimum         */
+  int32_t precision;     /* 64 or 32: arithmetic type of the ADMM loop        */
+  int32_t reserved;
+} acnqp_options;
+
+/* acnqp_create -- uploads the site once.  Replaces the per-call rebuilding of
+ * the infrastructure atoms at aco.py:157-172 (the reference re-creates them on
+ * every MPC step, adacharge.py:152-158).  device_id: HIP ordinal. */
+int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out);
+
+/* acnqp_solve_batch -- host buffers in, host buffers out, synchronous.
+ * Replaces cp.Problem(...).solve(...) at aco.py:315-318 for B problems.      */
+int acnqp_solve_batch(acnqp_handle* h, const acnqp_problems* p,
+                      const acnqp_options* o, acnqp_results* r);
+
+/* acnqp_solve_batch_device -- same, but every pointer in *p and *r is a device
+ * pointer on the handle's GPU and the work is enqueued on `hip_stream`
+ * (a hipStream_t, NULL = default stream); returns without synchronising.     */
+int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p,
+                             const acnqp_options* o, acnqp_results* r,
+                             void* hip_stream);
+
+/* acnqp_destroy -- frees device copies of the site and the staging workspace. */
+void acnqp_destroy(acnqp_handle* h);
+
+void acnqp_default_options(acnqp_options* o);
+
+/* Text of the last error on the calling thread ("" if none). */
+const char* acnqp_last_error(void);
+
+int32_t acnqp_abi_version(void);
+
+/* Duration in milliseconds of the most recent kernel launched through this
+ * handle, measured with HIP events on the launch stream (valid after the
+ * stream has been synchronised); < 0 if none.  Used by bench.py's roofline. */
+float acnqp_last_kernel_ms(acnqp_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACN_QP_H */

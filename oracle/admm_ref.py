@@ -1,0 +1,170 @@
+"""ORACLE -- test infrastructure only.  Nothing under adacharge_amd/ may import it.
+
+Readable numpy restatement of the *device algorithm* (the ADMM the HIP kernel
+runs, adacharge_amd/csrc/acn_qp_kernels.hip), one problem at a time, fp64.  It
+is not the reference's algorithm (the reference calls cvxpy/ECOS, aco.py:318);
+it exists so that a kernel bug can be told apart from an algorithmic property:
+the kernel must agree with this file to ~1e-9, and this file must agree with
+the independent IPM oracle (oracle/ipm.py) to the solver tolerance.
+
+Splitting (OSQP form, generalised from a box to closed convex sets/functions):
+
+    minimise  1/2 pdiag |x|^2 + <q, x> + I_B(z1) + g(z2)
+    s.t.      x = z1,   G x_t = z2_t  for every period t
+
+  B  = { lb <= z <= ub,  sum_{t in window_s} z[i_s, t] <= (==) cap_s }   (lane-local)
+  g  = indicator of the site rows' box / disc / peak sets, or the quadratic
+       load-flattening penalty on a row (prox instead of projection)
+
+x-update: (sigma + pdiag + rho) x~ + rho G'G x~ = rhs, solved in closed form
+through the eigen-decomposition of the tiny G G' (see builder.SiteData).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+ST_SOLVED = 1
+ST_MAX_ITER = 2
+ST_PRIMAL_INFEASIBLE = 3
+ST_PRESOLVE_INFEASIBLE = 4
+
+CONE_LINEAR = 0
+CONE_SOC = 1
+
+
+@dataclass
+class AdmmOptions:
+    eps_abs: float = 1e-6
+    eps_rel: float = 1e-6
+    max_iter: int = 20000
+    rho: float = 0.1
+    sigma: float = 1e-6
+    alpha: float = 1.6
+    check_every: int = 10
+    adaptive_rho: bool = True
+    adapt_every: int = 50
+    adapt_tol: float = 5.0
+
+
+def project_window(v, lb, ub, cap, eq):
+    """Euclidean projection of v onto {lb <= z <= ub, sum z <= cap (== cap if eq)}.
+    Exact, by locating the root of the piecewise-linear g(mu) = sum clip(v - mu)."""
+    z = np.clip(v, lb, ub)
+    s = z.sum()
+    if (not eq and s <= cap) or (eq and s == cap):
+        return z
+    lo_sum, hi_sum = lb.sum(), ub.sum()
+    if cap >= hi_sum:
+        return ub.copy() if eq else z
+    if cap <= lo_sum:
+        return lb.copy()
+    bp = np.unique(np.concatenate([v - ub, v - lb]))
+    gv = np.array([np.clip(v - m, lb, ub).sum() for m in bp])  # non-increasing in mu
+    # find segment [bp[k], bp[k+1]] with gv[k] >= cap >= gv[k+1]
+    k = int(np.searchsorted(-gv, -cap, side="left"))
+    k = min(max(k, 1), len(bp) - 1)
+    m0, m1, g0, g1 = bp[k - 1], bp[k], gv[k - 1], gv[k]
+    mu = m0 if g0 == g1 else m0 + (g0 - cap) * (m1 - m0) / (g0 - g1)
+    return np.clip(v - mu, lb, ub)
+
+
+def _project_B(v, lb, ub, s_off, s_len, s_cap, eq):
+    z = np.clip(v, lb, ub)
+    K, N = s_len.shape
+    for k in range(K):
+        for i in range(N):
+            L = s_len[k, i]
+            if L > 0:
+                o = s_off[k, i]
+                z[i, o : o + L] = project_window(
+                    v[i, o : o + L], lb[i, o : o + L], ub[i, o : o + L], s_cap[k, i], eq
+                )
+    return z
+
+
+def _prox_rows(zh, rho, site, peak_b, T, lf, lf_ext):
+    """z-update for the site rows.  zh is (Mg, Tm)."""
+    z = zh.copy()
+    M = site.M
+    if site.cone == CONE_SOC:
+        re, im = zh[:M], zh[M : 2 * M]
+        nrm = np.hypot(re, im)
+        scale = np.where(nrm > site.limits[:, None], site.limits[:, None] / np.maximum(nrm, 1e-300), 1.0)
+        z[:M] = re * scale
+        z[M : 2 * M] = im * scale
+        r = 2 * M
+    else:
+        z[:M] = np.minimum(zh[:M], site.limits[:, None])
+        r = M
+    if site.has_peak:
+        z[r] = np.minimum(zh[r], peak_b)
+        r += 1
+    z[:, T:] = 0.0
+    return z
+
+
+def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
+    """Run the ADMM on problem ``b`` of a builder.ProblemBatch-like object.
+    Returns dict(x (N,Tm), status, iters, pri_res, dua_res, obj, rho)."""
+    site = batch.site
+    N, Tm, T = site.N, batch.Tm, int(batch.T[b])
+    if batch.presolve_status is not None and batch.presolve_status[b]:
+        return dict(x=np.zeros((N, Tm)), status=ST_PRESOLVE_INFEASIBLE, iters=0,
+                    pri_res=np.inf, dua_res=np.inf, obj=np.nan, rho=opts.rho)
+    lb, ub, q = batch.lb[b], batch.ub[b], batch.q[b]
+    pdiag = float(batch.pdiag[b])
+    eq = bool(batch.s_eq[b])
+    G, Gh, lam, Q = site.G, site.Ghat, site.lam, site.Q
+    Mg = G.shape[0]
+    peak_b = batch.peak[b] if batch.peak is not None else None
+    sig, alpha = opts.sigma, opts.alpha
+    rho = opts.rho
+    x = np.zeros((N, Tm))
+    z1 = np.zeros((N, Tm))
+    y1 = np.zeros((N, Tm))
+    z2 = np.zeros((Mg, Tm))
+    y2 = np.zeros((Mg, Tm))
+    Gx = np.zeros((Mg, Tm))
+    status = ST_MAX_ITER
+    pri = dua = np.inf
+    it = 0
+    for it in range(1, opts.max_iter + 1):
+        a = sig + pdiag + rho
+        r0 = sig * x - q + rho * z1 - y1
+        w = rho * z2 - y2
+        wh = Q.T @ w
+        gh0 = Gh @ r0
+        gh = gh0 + lam[:, None] * wh
+        ch = rho * gh / (a + rho * lam[:, None])
+        eh = wh - ch
+        xt = (r0 + Gh.T @ eh) / a
+        zt2 = Q @ ((gh0 + lam[:, None] * eh) / a)
+        x = alpha * xt + (1 - alpha) * x
+        Gx = alpha * zt2 + (1 - alpha) * Gx
+        zh1 = alpha * xt + (1 - alpha) * z1 + y1 / rho
+        z1 = _project_B(zh1, lb, ub, batch.s_off[b], batch.s_len[b], batch.s_cap[b], eq)
+        y1 = rho * (zh1 - z1)
+        zh2 = alpha * zt2 + (1 - alpha) * z2 + y2 / rho
+        z2 = _prox_rows(zh2, rho, site, peak_b, T, 0.0, None)
+        y2 = rho * (zh2 - z2)
+        if it % opts.check_every == 0 or it == opts.max_iter:
+            Gty = G.T @ y2
+            pri = max(np.abs(x - z1).max(), np.abs(Gx - z2).max() if Mg else 0.0)
+            dua = np.abs(pdiag * x + q + y1 + Gty).max()
+            npri = max(np.abs(x).max(), np.abs(z1).max(), np.abs(Gx).max() if Mg else 0.0, np.abs(z2).max() if Mg else 0.0)
+            ndua = max(np.abs(pdiag * x).max(), np.abs(q).max(), np.abs(y1).max(), np.abs(Gty).max())
+            if trace is not None:
+                trace.append((it, pri, dua, rho))
+            if pri <= opts.eps_abs + opts.eps_rel * npri and dua <= opts.eps_abs + opts.eps_rel * ndua:
+                status = ST_SOLVED
+                break
+            if opts.adaptive_rho and it % opts.adapt_every == 0:
+                ratio = np.sqrt((pri / max(npri, 1e-12)) / max(dua / max(ndua, 1e-12), 1e-30))
+                if ratio > opts.adapt_tol or ratio < 1.0 / opts.adapt_tol:
+                    rho = float(np.clip(rho * ratio, 1e-6, 1e6))
+    # the feasible iterate is z1 (it satisfies bounds and energy rows exactly)
+    xs = z1
+    obj = 0.5 * pdiag * (xs * xs).sum() + (q * xs).sum()
+    return dict(x=xs, xraw=x, status=status, iters=it, pri_res=pri, dua_res=dua, obj=obj, rho=rho)
