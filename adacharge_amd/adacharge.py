@@ -1,0 +1,245 @@
+"""Algorithm adapters -- mirror of /root/reference/adacharge/adacharge.py.
+
+``AdaptiveSchedulingAlgorithm`` keeps the acnportal ``BaseAlgorithm`` plugin
+contract (constructor kwargs ada.py:43-58, ``register_interface`` ada.py:116-133,
+``schedule(active_sessions) -> {station_id: ndarray}`` ada.py:135-193); the body
+is re-pointed at the HIP backend through ``AdaptiveChargingOptimization``.
+"""
+from __future__ import annotations
+
+import warnings
+from copy import deepcopy
+
+import numpy as np
+
+from .acn import (
+    BaseAlgorithm,
+    SessionInfo,
+    apply_minimum_charging_rate,
+    apply_upper_bound_estimate,
+    enforce_pilot_limit,
+)
+from .adaptive_charging_optimization import *  # noqa: F401,F403  (ada.py:5 star-import)
+from .adaptive_charging_optimization import AdaptiveChargingOptimization
+from .postprocessing import (
+    diff_based_reallocation,
+    index_based_reallocation,
+    project_into_continuous_feasible_pilots,
+    project_into_discrete_feasible_pilots,
+)
+
+
+def get_active_sessions(active_evs, current_time):
+    """ada.py:18-39: SessionInfo list for acnsim EV objects."""
+    return [
+        SessionInfo(
+            ev.station_id, ev.session_id, ev.requested_energy, ev.energy_delivered,
+            ev.arrival, ev.departure, current_time=current_time,
+        )
+        for ev in active_evs
+    ]
+
+
+class AdaptiveSchedulingAlgorithm(BaseAlgorithm):
+    """Model Predictive Control based scheduling algorithm (ada.py:42-193)."""
+
+    def __init__(
+        self,
+        objective,
+        constraint_type="SOC",
+        enforce_energy_equality=False,
+        solver=None,
+        peak_limit=None,
+        estimate_max_rate=False,
+        max_rate_estimator=None,
+        uninterrupted_charging=False,
+        quantize=False,
+        reallocate=False,
+        max_recompute=None,
+        allow_overcharging=False,
+        verbose=False,
+        solver_options=None,
+        device=0,
+    ):
+        super().__init__()
+        self.objective = objective
+        self.constraint_type = constraint_type
+        self.enforce_energy_equality = enforce_energy_equality
+        self.solver = solver
+        self.peak_limit = peak_limit
+        self.estimate_max_rate = estimate_max_rate
+        self.max_rate_estimator = max_rate_estimator
+        self.uninterrupted_charging = uninterrupted_charging
+        self.quantize = quantize
+        self.reallocate = reallocate
+        self.verbose = verbose
+        self.solver_options = solver_options
+        self.device = device
+        if not self.quantize and self.reallocate:
+            raise ValueError(
+                "reallocate cannot be true without quantize. "
+                "Otherwise there is nothing to reallocate :)."
+            )
+        if self.quantize:
+            # ada.py:106-111 reads the BaseAlgorithm default before assigning (Appendix D.1)
+            if self.max_recompute is not None:
+                warnings.warn("Overriding max_recompute to 1 since quantization is on.")
+            self.max_recompute = 1
+        else:
+            self.max_recompute = max_recompute
+        self.allow_overcharging = allow_overcharging
+
+    def register_interface(self, interface):
+        """ada.py:116-133."""
+        self._interface = interface
+        if self.max_rate_estimator is not None:
+            self.max_rate_estimator.register_interface(interface)
+
+    def _preprocess(self, active_sessions, infrastructure):
+        """ada.py:141-150."""
+        active_sessions = enforce_pilot_limit(active_sessions, infrastructure)
+        if self.estimate_max_rate:
+            active_sessions = apply_upper_bound_estimate(self.max_rate_estimator, active_sessions)
+        if self.uninterrupted_charging:
+            active_sessions = apply_minimum_charging_rate(
+                active_sessions, infrastructure, self.interface.period
+            )
+        return active_sessions
+
+    def _trimmed_peak(self, active_sessions):
+        """ada.py:160-167: scalar passes through, vector is sliced from the
+        current simulation time."""
+        if self.peak_limit is None or np.isscalar(self.peak_limit):
+            return self.peak_limit
+        t = self.interface.current_time
+        horizon = max(s.arrival_offset + s.remaining_time for s in active_sessions)
+        return self.peak_limit[t : t + horizon]
+
+    def _postprocess(self, rates_matrix, active_sessions, infrastructure):
+        """ada.py:176-189."""
+        if self.quantize:
+            if self.reallocate:
+                rates_matrix = diff_based_reallocation(
+                    rates_matrix, active_sessions, infrastructure, self.interface
+                )
+            else:
+                rates_matrix = project_into_discrete_feasible_pilots(rates_matrix, infrastructure)
+        else:
+            rates_matrix = project_into_continuous_feasible_pilots(rates_matrix, infrastructure)
+        return np.maximum(rates_matrix, 0)
+
+    def _optimizer(self):
+        return AdaptiveChargingOptimization(
+            self.objective, self.interface, self.constraint_type, self.enforce_energy_equality,
+            solver=self.solver, solver_options=self.solver_options, device=self.device,
+        )
+
+    def schedule(self, active_sessions):
+        """See BaseAlgorithm (ada.py:135-193)."""
+        if len(active_sessions) == 0:
+            return {}
+        infrastructure = self.interface.infrastructure_info()
+        active_sessions = self._preprocess(active_sessions, infrastructure)
+        rates_matrix = self._optimizer().solve(
+            active_sessions, infrastructure,
+            peak_limit=self._trimmed_peak(active_sessions),
+            prev_peak=self.interface.get_prev_peak(),
+            verbose=self.verbose,
+        )
+        rates_matrix = self._postprocess(rates_matrix, active_sessions, infrastructure)
+        return {
+            station_id: rates_matrix[i, :] for i, station_id in enumerate(infrastructure.station_ids)
+        }
+
+    def schedule_batch(self, session_lists, peak_limits=None):
+        """Batched extension: one schedule dict per state snapshot, all
+        optimisation problems solved by a single kernel launch.  Snapshots whose
+        solve does not end optimal yield ``None``."""
+        infrastructure = self.interface.infrastructure_info()
+        pre = [self._preprocess(sl, infrastructure) if len(sl) else sl for sl in session_lists]
+        if peak_limits is None:
+            peak_limits = [self._trimmed_peak(sl) if len(sl) else None for sl in pre]
+        rates, status = self._optimizer().solve_batch(
+            pre, infrastructure, peak_limits=peak_limits,
+            prev_peak=self.interface.get_prev_peak(), verbose=self.verbose,
+        )
+        out = []
+        for sl, r, st in zip(pre, rates, status):
+            if len(sl) == 0:
+                out.append({})
+            elif st != 1:
+                out.append(None)
+            else:
+                r = self._postprocess(r, sl, infrastructure)
+                out.append({sid: r[i, :] for i, sid in enumerate(infrastructure.station_ids)})
+        return out
+
+
+class AdaptiveChargingAlgorithmOffline(BaseAlgorithm):
+    """Offline optimisation with perfect future information (ada.py:196-294)."""
+
+    def __init__(
+        self,
+        objective,
+        constraint_type="SOC",
+        enforce_energy_equality=False,
+        solver=None,
+        peak_limit=None,
+        verbose=False,
+        solver_options=None,
+        device=0,
+    ):
+        super().__init__()
+        self.max_recompute = 1
+        self.objective = objective
+        self.constraint_type = constraint_type
+        self.enforce_energy_equality = enforce_energy_equality
+        self.solver = solver
+        self.peak_limit = peak_limit
+        self.verbose = verbose
+        self.solver_options = solver_options
+        self.device = device
+        self.sessions = None
+        self.session_ids = None
+        self.internal_schedule = None
+
+    def register_events(self, events):
+        """ada.py:234-247: only Plugin events are considered."""
+        active_evs = [deepcopy(event[1].ev) for event in events.queue if event[1].event_type == "Plugin"]
+        self.sessions = get_active_sessions(active_evs, 0)
+        self.session_ids = set(s.session_id for s in self.sessions)
+
+    def solve(self):
+        """ada.py:249-276."""
+        if self._interface is None:
+            raise ValueError(
+                "Error: self.interface is None. Please register interface before calling solve."
+            )
+        if self.sessions is None:
+            raise ValueError(
+                "No events registered. Please register an event queue before calling solve."
+            )
+        infrastructure = self.interface.infrastructure_info()
+        self.sessions = enforce_pilot_limit(self.sessions, infrastructure)
+        optimizer = AdaptiveChargingOptimization(
+            self.objective, self.interface, self.constraint_type, self.enforce_energy_equality,
+            solver=self.solver, solver_options=self.solver_options, device=self.device,
+        )
+        rates_matrix = optimizer.solve(self.sessions, infrastructure, self.peak_limit, verbose=self.verbose)
+        rates_matrix = project_into_continuous_feasible_pilots(rates_matrix, infrastructure)
+        self.internal_schedule = {
+            station_id: rates_matrix[i, :] for i, station_id in enumerate(infrastructure.station_ids)
+        }
+
+    def schedule(self, active_evs):
+        """ada.py:278-294."""
+        if self.internal_schedule is None:
+            raise ValueError(
+                "No internal schedule found. Make sure to call solve before calling schedule or "
+                "running a simulation."
+            )
+        for ev in active_evs:
+            if ev.session_id not in self.session_ids:
+                raise ValueError(f"Error: Session {ev.session_id} not included in offline solve.")
+        current_time = self.interface.current_time
+        return {ev.station_id: [self.internal_schedule[ev.station_id][current_time]] for ev in active_evs}

@@ -147,3 +147,167 @@ def demand_charge(rates, infrastructure, interface, baseline_peak=0, **kwargs):
     p = peak(rates, infrastructure, interface, baseline_peak, **kwargs)
     dc = interface.get_demand_charge()
     return -dc * p
+
+
+# ---------------------------------------------------------------------------
+#  The optimiser (aco.py:18-321)
+# ---------------------------------------------------------------------------
+_HANDLE_CACHE = {}
+
+
+def _site_handle(infrastructure, constraint_type, with_peak, device):
+    """One uploaded site per (infrastructure content, cone, peak, GPU).  The
+    reference rebuilds every atom on every call (adacharge.py:152-158); here the
+    site matrix is uploaded once and reused by all later MPC steps."""
+    from . import backend
+    from .builder import make_site
+
+    cm = infrastructure.constraint_matrix
+    key = (
+        None if cm is None else (cm.shape, cm.tobytes()),
+        None if infrastructure.constraint_limits is None else np.asarray(infrastructure.constraint_limits).tobytes(),
+        None if infrastructure.phases is None else np.asarray(infrastructure.phases).tobytes(),
+        np.asarray(infrastructure.voltages).tobytes(),
+        constraint_type, bool(with_peak), int(device),
+    )
+    ent = _HANDLE_CACHE.get(key)
+    if ent is None:
+        site = make_site(infrastructure, constraint_type, with_peak=with_peak)
+        ent = (site, backend.SiteHandle(site, device))
+        if len(_HANDLE_CACHE) > 64:
+            _HANDLE_CACHE.clear()
+        _HANDLE_CACHE[key] = ent
+    return ent
+
+
+class AdaptiveChargingOptimization:
+    """Base class for all MPC based charging algorithms (aco.py:18-43).
+
+    Args:
+        objective (List[ObjectiveComponent]): components of the objective.
+        interface: object providing ``period`` (and prices / demand charge /
+            previous peak when the objective needs them).
+        constraint_type (str): 'SOC' or 'LINEAR' (aco.py:35).
+        enforce_energy_equality (bool): energy rows are equalities (aco.py:36).
+        solver (str): accepted for source compatibility with the reference
+            ("ECOS", "OSQP", None, cvxpy constants ...); every value runs the
+            HIP ADMM backend.  Backend options go in ``solver_options``.
+        solver_options (dict): overrides of ``acnqp_options`` fields
+            (eps_abs, eps_rel, max_iter, rho, reg_rel, precision, ...).
+        device (int): HIP device ordinal.
+    """
+
+    def __init__(
+        self,
+        objective: List[ObjectiveComponent],
+        interface,
+        constraint_type="SOC",
+        enforce_energy_equality=False,
+        solver="ECOS",
+        solver_options: Optional[dict] = None,
+        device: int = 0,
+    ):
+        self.interface = interface
+        self.constraint_type = constraint_type
+        self.enforce_energy_equality = enforce_energy_equality
+        self.solver = solver
+        self.objective_configuration = objective
+        self.solver_options = dict(solver_options or {})
+        self.device = device
+        self.last_result = None
+
+    # the single-problem API asks for tighter residuals than the batch default so that the
+    # reference's own test tolerances (1e-7 on the peak row, t_aco.py:257) hold
+    _SINGLE_DEFAULTS = dict(eps_abs=1e-9, eps_rel=1e-9, max_iter=100000)
+
+    def build_problem(
+        self,
+        active_sessions,
+        infrastructure,
+        peak_limit: Optional[Union[float, List[float], np.ndarray]] = None,
+        prev_peak: float = 0,
+    ):
+        """aco.py:220-284.  Returns the structured one-problem ``ProblemBatch``
+        (the reference returns cvxpy objects; see module docstring)."""
+        from .builder import build_batch
+
+        return build_batch(
+            [active_sessions], infrastructure, self.interface, self.objective_configuration,
+            self.constraint_type, self.enforce_energy_equality,
+            peak_limits=[peak_limit], prev_peak=prev_peak,
+        )
+
+    def solve(
+        self,
+        active_sessions,
+        infrastructure,
+        peak_limit: Union[float, List[float], np.ndarray] = None,
+        prev_peak=0,
+        verbose: bool = False,
+    ):
+        """aco.py:286-321: (N, T) array of charging rates; raises
+        ``InfeasibilityException`` unless the solve ends optimal."""
+        if len(active_sessions) == 0:  # aco.py:310-311
+            return np.zeros((infrastructure.num_stations, 1))
+        rates, status = self.solve_batch(
+            [active_sessions], infrastructure, peak_limits=[peak_limit], prev_peak=prev_peak,
+            verbose=verbose, _defaults=self._SINGLE_DEFAULTS,
+        )
+        from . import backend
+
+        if status[0] != backend.STATUS_SOLVED:  # aco.py:319-320
+            raise InfeasibilityException(
+                f"Solve failed with status {backend.STATUS_NAMES.get(int(status[0]), status[0])}"
+            )
+        return rates[0]
+
+    def solve_batch(
+        self,
+        session_lists: Sequence[Sequence],
+        infrastructure,
+        peak_limits: Optional[Sequence] = None,
+        prev_peak=0,
+        verbose: bool = False,
+        _defaults: Optional[dict] = None,
+    ):
+        """Batched extension (not in the reference): one independent MPC
+        problem per entry of ``session_lists`` (state snapshots, sites' days,
+        demand scenarios), all solved in one kernel launch.  Returns
+        ``(list of (N, T_b) arrays, status (B,) int32)``; never raises for
+        solver outcomes -- inspect ``status``."""
+        from . import backend
+        from .builder import build_batch
+
+        if self.constraint_type not in ("SOC", "LINEAR"):
+            from .builder import _bad_constraint_type
+
+            _bad_constraint_type(self.constraint_type)
+        B = len(session_lists)
+        nonempty = [k for k, sl in enumerate(session_lists) if len(sl) > 0]
+        rates = [np.zeros((infrastructure.num_stations, 1)) for _ in range(B)]
+        status = np.full(B, backend.STATUS_SOLVED, dtype=np.int32)
+        if not nonempty:
+            return rates, status
+        pl = [None] * B if peak_limits is None else list(peak_limits)
+        any_peak = any(pl[k] is not None for k in nonempty)
+        site, handle = _site_handle(infrastructure, self.constraint_type, any_peak, self.device)
+        batch = build_batch(
+            [session_lists[k] for k in nonempty], infrastructure, self.interface,
+            self.objective_configuration, self.constraint_type, self.enforce_energy_equality,
+            peak_limits=[pl[k] for k in nonempty], prev_peak=prev_peak, site=site,
+        )
+        opts = dict(_defaults or {})
+        opts.update(self.solver_options)
+        res = handle.solve(batch, backend.default_options(**opts))
+        self.last_result = res
+        if verbose:
+            for j, k in enumerate(nonempty):
+                print(
+                    f"[acnqp] problem {k}: status={backend.STATUS_NAMES.get(int(res.status[j]))} "
+                    f"iters={int(res.iters[j])} pri_res={res.pri_res[j]:.3e} dua_res={res.dua_res[j]:.3e} "
+                    f"obj={-(res.obj[j] + batch.const[j]):.9g} (maximised) kernel_ms={res.kernel_ms:.3f}"
+                )
+        for j, k in enumerate(nonempty):
+            rates[k] = res.x[j, :, : int(batch.T[j])].copy()
+            status[k] = res.status[j]
+        return rates, status

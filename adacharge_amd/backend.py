@@ -91,7 +91,7 @@ class Options(C.Structure):
         ("sigma", C.c_double),
         ("alpha", C.c_double),
         ("adapt_tol", C.c_double),
-        ("reg_min", C.c_double),
+        ("reg_rel", C.c_double),
         ("precision", C.c_int32),
         ("reserved", C.c_int32),
     ]
@@ -121,6 +121,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime; it must be the one already loaded when our
+    # library resolves libamdhip64, or the process ends up with two runtimes and the
+    # second sees no GPU.  torch is plumbing here (device memory, torch.distributed).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise BackendUnavailable(

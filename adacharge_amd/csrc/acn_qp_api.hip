@@ -132,8 +132,8 @@ const char* acnqp_last_error(void) { return g_last_error.c_str(); }
 
 void acnqp_default_options(acnqp_options* o) {
   if (!o) return;
-  o->eps_abs = 1e-6;
-  o->eps_rel = 1e-6;
+  o->eps_abs = 1e-8;
+  o->eps_rel = 1e-8;
   o->max_iter = 20000;
   o->check_every = 10;
   o->adapt_every = 50;
@@ -141,7 +141,7 @@ void acnqp_default_options(acnqp_options* o) {
   o->sigma = 1e-6;
   o->alpha = 1.6;
   o->adapt_tol = 5.0;
-  o->reg_min = 2e-4;
+  o->reg_rel = 5e-3;
   o->precision = 64;
   o->reserved = 0;
 }
@@ -250,7 +250,7 @@ static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, 
   if (!r->x || !r->status || !r->iters || !r->pri_res || !r->dua_res || !r->obj)
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: null result array");
   if (!(o->eps_abs >= 0) || !(o->eps_rel >= 0) || o->max_iter < 1 || o->check_every < 1 || !(o->rho > 0) ||
-      !(o->sigma >= 0) || !(o->alpha > 0 && o->alpha < 2) || !(o->adapt_tol > 1) || !(o->reg_min >= 0) ||
+      !(o->sigma >= 0) || !(o->alpha > 0 && o->alpha < 2) || !(o->adapt_tol > 1) || !(o->reg_rel >= 0) ||
       o->adapt_every < 0)
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: invalid option value");
   if (o->precision != 64 && o->precision != 32)
@@ -273,7 +273,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.s_off = p->s_off; a.s_len = p->s_len; a.s_cap = p->s_cap; a.s_eq = p->s_eq; a.peak = p->peak;
   a.x = r->x; a.status = r->status; a.iters = r->iters; a.pri = r->pri_res; a.dua = r->dua_res; a.obj = r->obj;
   a.eps_abs = o->eps_abs; a.eps_rel = o->eps_rel; a.rho0 = o->rho; a.sigma = o->sigma; a.alpha = o->alpha;
-  a.adapt_tol = o->adapt_tol; a.reg_min = o->reg_min;
+  a.adapt_tol = o->adapt_tol; a.reg_rel = o->reg_rel;
   a.max_iter = o->max_iter; a.check_every = o->check_every; a.adapt_every = o->adapt_every;
   HIP_TRY(hipEventRecord(h->ev_start, st));
   hipError_t e = (o->precision == 32) ? launch_for_k<float>(a, st) : launch_for_k<double>(a, st);

@@ -42,7 +42,7 @@ struct KernelArgs {
   double* x;
   int32_t *status, *iters;
   double *pri, *dua, *obj;
-  double eps_abs, eps_rel, rho0, sigma, alpha, adapt_tol, reg_min;
+  double eps_abs, eps_rel, rho0, sigma, alpha, adapt_tol, reg_rel;
   int max_iter, check_every, adapt_every;
 };
 
@@ -235,20 +235,23 @@ __global__ __launch_bounds__(kThreads) void admm_kernel(const KernelArgs A) {
   const int hsub = tid % H;
   const bool soc = A.cone == 1;
   const real pd_user = (real)A.pdiag[b];
-  const real pd = pd_user < (real)A.reg_min ? (real)A.reg_min : pd_user;
   const real sigma = (real)A.sigma, alpha = (real)A.alpha;
   real rho = (real)A.rho0;
 
   __syncthreads();
-  real qnorm;
+  real qnorm, pd;
   {
-    real f[2];
+    real f[3];
     f[0] = empty_set ? (real)1 : (real)0;
     f[1] = 0;
+    f[2] = 0;
 #pragma unroll
-    for (int tt = 0; tt < TPT; ++tt) f[1] = fmax(f[1], fabs(qv[tt]));
-    block_max<real, 2>(f, Red, lane, wave);
+    for (int tt = 0; tt < TPT; ++tt) { f[1] = fmax(f[1], fabs(qv[tt])); f[2] = fmax(f[2], ubv[tt]); }
+    block_max<real, 3>(f, Red, lane, wave);
     qnorm = f[1];
+    // scale-free Tikhonov floor (exact regularisation of LP instances)
+    pd = pd_user;
+    if (f[2] > 0) pd = fmax(pd_user, (real)A.reg_rel * qnorm / f[2]);
     if (f[0] > 0) {
       // a session cannot meet its energy row inside its own bounds: nothing to iterate on
 #pragma unroll

@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MPC QP solves/sec, 54 EVSE x horizon 12 (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (acnqp_solve_batch_device: one kernel
+launch) over one batch of 256 independent MPC state snapshots per GPU, inputs
+already resident in HBM.  Workload = BASELINE.json configs[1]: Caltech-shaped
+54-EVSE network, horizon 12, quick_charge (+ equal_share*1e-12, the reference's
+own integration-test objective, t_int.py:67-70), the reference's default SOC
+constraints (aco.py:35), fp64 ADMM, batch 256 per GPU (weak scaling: every rank
+gets its own 256 snapshots; for N > 1 each step ends with one RCCL all-gather of
+the schedules so every rank holds the whole job's result).
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement), with
+`roofline` (HBM algorithmic bytes / measured kernel time) and `cpu_baseline`
+(oracle/admm_port.c, the scalar C port of the same ADMM, on all host cores over
+a bounded sample; N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TF = 78.6     # vector fp64 (vendor figure)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="problems per GPU per step")
+    ap.add_argument("--horizon", type=int, default=12)
+    ap.add_argument("--constraint-type", default="SOC", choices=["SOC", "LINEAR"])
+    ap.add_argument("--precision", type=int, default=64, choices=[64, 32])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(B, N, Tm, K, site):
+    """HBM bytes one launch must move: per problem read lb, ub, q
+    and write x (4*N*Tm doubles), the session table (K*N * (4+4+8) B), 1 double + 1 int + 1
+    byte of scalars in, 3 doubles + 2 ints out; the site matrices once per launch."""
+    per_qp = 8 * 4 * N * Tm + 16 * K * N + (8 + 4 + 1) + (3 * 8 + 2 * 4)
+    if site.has_peak:
+        per_qp += 8 * Tm
+    site_bytes = 8 * (2 * site.Mg * N + site.Mg * site.Mg + site.Mg + site.M)
+    return B * per_qp + site_bytes, per_qp, site_bytes
+
+
+def flops_per_iteration(N, Tm, site):
+    """ALGORITHMIC flops of one ADMM iteration."""
+    Mg = site.Mg
+    return 4 * Mg * N * Tm + 4 * Mg * Mg * Tm + 20 * N * Tm + 12 * Mg * Tm
+
+
+def cpu_baseline_leg(batch, gpu_x, gpu_status, target_seconds, snaps, infra, iface):
+    """The ONLY place bench.py touches oracle/: the scalar C port of the device ADMM timed on
+    the host cores over a bounded sample, which also serves as the parity check of the sample."""
+    from oracle import admm_port
+    import copy
+
+    cores = min(admm_port.max_threads(), os.cpu_count() or 1)
+
+    def sub(k):
+        sb = copy.copy(batch)
+        sb.B = k
+        for name in ("T", "lb", "ub", "q", "pdiag", "lf", "s_off", "s_len", "s_cap", "s_eq", "const", "presolve_status"):
+            setattr(sb, name, getattr(batch, name)[:k])
+        sb.peak = None if batch.peak is None else batch.peak[:k]
+        return sb
+
+    admm_port.solve_batch(sub(min(cores, batch.B)), threads=cores)  # warm the thread pool / caches
+    t0 = time.perf_counter()
+    admm_port.solve_batch(sub(min(cores, batch.B)), threads=cores)
+    per_wave = max(time.perf_counter() - t0, 1e-4)
+    n = int(min(batch.B, max(cores, cores * round(target_seconds / per_wave))))
+    t0 = time.perf_counter()
+    out = admm_port.solve_batch(sub(n), threads=cores)
+    dt = time.perf_counter() - t0
+    ok = (out["status"] == 1) & (gpu_status[:n] == 1)
+    dx = float(np.abs(out["x"][ok] - gpu_x[:n][ok]).max()) if ok.any() else float("nan")
+    res = {
+        "value": n / dt, "unit": "QP solves/s", "cores": int(cores), "kind": "port",
+        "sample": f"{n} of the {batch.B} rank-0 problems, oracle/admm_port.c (scalar C port of the device ADMM, "
+                  f"gcc -O3 -fopenmp), {dt:.1f} s wall",
+    }
+    parity = {"port_sample": n, "max_abs_rate_diff_gpu_vs_port_A": dx,
+              "status_mismatches_vs_port": int((out["status"] != gpu_status[:n]).sum())}
+    # independent solver on the LP the reference states (pure quick_charge): objective / aggregate gap
+    try:
+        from oracle.ipm import solve_lp_highs
+        from oracle.ref_problem import build_reference_problem
+
+        gaps, aggs, th = [], [], []
+        for b in range(min(4, batch.B)):
+            prob = build_reference_problem(snaps[b], infra, iface, [("quick_charge", 1, {})], "LINEAR")
+            t0 = time.perf_counter()
+            h = solve_lp_highs(prob)
+            th.append(time.perf_counter() - t0)
+            if h.status == 0 and gpu_status[b] == 1:
+                T = int(batch.T[b])
+                x = gpu_x[b][:, :T]
+                gaps.append((prob.objective(x) - h.fun) / abs(h.fun))
+                aggs.append(float(np.abs(x.sum(0) - h.x.reshape(prob.N, T).sum(0)).max()))
+        parity["highs_lp_rel_objective_gap_max"] = float(np.max(gaps)) if gaps else None
+        parity["highs_lp_aggregate_gap_max_A"] = float(np.max(aggs)) if aggs else None
+        res["highs_lp_ms_per_solve_1thread"] = 1e3 * float(np.median(th))
+    except Exception as exc:  # the LINEAR-only cross-check is informative, never fatal
+        parity["highs_error"] = repr(exc)
+    return res, parity
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists by design)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from adacharge_amd import ObjectiveComponent, equal_share, quick_charge, sites
+    from adacharge_amd.acn import Interface
+    from adacharge_amd.backend import DeviceBatch, SiteHandle, default_options
+    from adacharge_amd.builder import build_batch
+
+    infra = sites.caltech54()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    T, B = args.horizon, args.batch
+    objective = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
+    snaps = sites.snapshot_batch(infra, T, B, seed=20240 + rank)
+    batch = build_batch(snaps, infra, iface, objective, args.constraint_type)
+    handle = SiteHandle(batch.site, local_rank)
+    dbatch = DeviceBatch(batch, dev)
+    opts = default_options(precision=args.precision)
+    if args.precision == 32:
+        opts.eps_abs = opts.eps_rel = 5e-5
+    stream = torch.cuda.current_stream().cuda_stream
+    gathered = (
+        torch.empty((world * B, batch.N, batch.Tm), dtype=torch.float64, device=dev) if world > 1 else None
+    )
+
+    def step():
+        handle.solve_device(dbatch, opts, stream=stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, dbatch.x)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(handle.last_kernel_ms())   # HIP events on the launch stream
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    x = dbatch.x.cpu().numpy()
+    status = dbatch.status.cpu().numpy()
+    iters = dbatch.iters.cpu().numpy()
+    solved = int((status == 1).sum())
+    if world > 1:
+        cnt = torch.tensor([solved, B], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt)
+        solved_all, total_all = int(cnt[0]), int(cnt[1])
+        if rank == 0:   # the gather really carries every rank's schedules
+            assert torch.equal(gathered[:B], dbatch.x)
+    else:
+        solved_all, total_all = solved, B
+
+    if rank == 0:
+        k_avg_ms = float(np.mean(kernel_ms))
+        abytes, per_qp, site_bytes = algorithmic_bytes(B, batch.N, batch.Tm, batch.K, batch.site)
+        achieved = abytes / (k_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):   # committed result of the separate rocprofv3 --pmc passes
+            try:
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        fl = flops_per_iteration(batch.N, batch.Tm, batch.site)
+        # SIMT cost: every problem of a launch occupies its CU until its own last iteration
+        valu_tf = float(iters.sum()) * fl / (k_avg_ms * 1e-3) / 1e12
+        out = {
+            "metric": "MPC QP solves/sec whole-node, 54 EVSE x horizon 12; max rate residual vs cvxpy",
+            "value": world * B * args.steps / elapsed,
+            "unit": "QP solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if args.precision == 64 else "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"caltech54 (Caltech-shaped, 54 EVSE) x horizon {T}, quick_charge + equal_share*1e-12, "
+                            f"{args.constraint_type} constraints, batch {B} independent MPC snapshots per GPU "
+                            f"(BASELINE.json configs[1])",
+                "batch_per_gpu": B, "n_evse": batch.N, "horizon": T, "constraint_type": args.constraint_type,
+                "parallelism": f"dp{world} (one batch shard per GPU" + (", RCCL all-gather of schedules per step)" if world > 1 else ")"),
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "acnqp::admm_kernel", "kernel_avg_ms": k_avg_ms,
+                "algorithmic_bytes_per_launch": abytes, "bytes_per_qp": per_qp,
+                "note": "LDS-resident iterative solver: HBM is touched once per problem, so the HBM fraction is "
+                        "small by construction (SURVEY.md H8); the VALU view is in `valu`",
+            },
+            "valu": {
+                "achieved": valu_tf, "peak": FP64_VALU_PEAK_TF if args.precision == 64 else 157.3, "unit": "TFLOP/s",
+                "frac": valu_tf / (FP64_VALU_PEAK_TF if args.precision == 64 else 157.3),
+                "flops_per_iteration": fl, "iterations_mean": float(iters.mean()), "iterations_max": int(iters.max()),
+            },
+            "solver": {
+                "solved": solved_all, "problems": total_all,
+                "eps_abs": opts.eps_abs, "eps_rel": opts.eps_rel, "reg_rel": opts.reg_rel,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, parity = cpu_baseline_leg(batch, x, status, args.cpu_seconds, snaps, infra, iface)
+            out["cpu_baseline"] = cb
+            out["parity"] = parity
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

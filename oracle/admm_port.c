@@ -1,0 +1,237 @@
+/* ORACLE -- test infrastructure only.  Nothing under adacharge_amd/ links this.
+ *
+ * Scalar C port of the device ADMM (adacharge_amd/csrc/acn_qp_kernel.hpp), same
+ * algorithm and same parameters, double precision, one problem per call;
+ * oracle/admm_ref.py is its readable numpy twin.  Used (a) as a near-bitwise
+ * checker for the HIP kernel and (b) as bench.py's `cpu_baseline` ("port"),
+ * run over a bounded sample with one OpenMP thread per problem.
+ *
+ * It is NOT the reference's algorithm: the reference calls cvxpy -> ECOS
+ * (/root/reference/adacharge/adaptive_charging_optimization.py:318), whose
+ * interior-point method is restated in oracle/ipm.py.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+  int N, Tm, K, Mg, M, cone, has_peak;
+  const double *G, *Ghat, *Q, *lam, *limits;  /* G,Ghat [Mg][N]; Q [Mg][Mg] (Q[r][k]) */
+} port_site;
+
+typedef struct {
+  double eps_abs, eps_rel, rho, sigma, alpha, adapt_tol, reg_rel;
+  int max_iter, check_every, adapt_every;
+} port_opts;
+
+static double clip(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* projection of v[0..L) onto {lb<=z<=ub, sum z <= cap (== if eq)}; safeguarded Newton on
+ * g(mu) = sum clip(v - mu), warm-started at *mu (kernel: the `while (__any(need))` loop) */
+static void project_window(int L, const double* v, const double* lb, const double* ub, double cap, int eq,
+                           double sum_lb, double sum_ub, double* mu, double* z) {
+  double s0 = 0, lo = 1e300, hi = -1e300;
+  for (int t = 0; t < L; ++t) {
+    z[t] = clip(v[t], lb[t], ub[t]);
+    s0 += z[t];
+    if (v[t] - ub[t] < lo) lo = v[t] - ub[t];
+    if (v[t] - lb[t] > hi) hi = v[t] - lb[t];
+  }
+  const double tol = 1e-13 * fmax(1.0, fabs(cap));
+  int need = eq ? fabs(s0 - cap) > tol : s0 > cap + tol;
+  if (!need) { *mu = 0; return; }
+  if (cap >= sum_ub) { for (int t = 0; t < L; ++t) z[t] = ub[t]; *mu = 0; return; }
+  if (cap <= sum_lb) { for (int t = 0; t < L; ++t) z[t] = lb[t]; *mu = 0; return; }
+  if (!eq && lo < 0) lo = 0;
+  double m = fmin(fmax(*mu, lo), hi);
+  for (int guard = 0; guard <= 80; ++guard) {
+    double g = 0, nf = 0;
+    for (int t = 0; t < L; ++t) {
+      const double w = v[t] - m;
+      g += clip(w, lb[t], ub[t]);
+      nf += (w > lb[t] && w < ub[t]) ? 1.0 : 0.0;
+    }
+    const double d = g - cap;
+    if (fabs(d) <= tol) break;
+    if (d > 0) lo = m; else hi = m;
+    double mn = nf > 0 ? m + d / nf : 0.5 * (lo + hi);
+    if (!(mn > lo && mn < hi)) mn = 0.5 * (lo + hi);
+    m = mn;
+  }
+  *mu = m;
+  for (int t = 0; t < L; ++t) z[t] = clip(v[t] - m, lb[t], ub[t]);
+}
+
+/* returns status: 1 solved, 2 max_iter, 4 empty set */
+static int solve_one(const port_site* S, const port_opts* O, const double* lb, const double* ub_in, const double* q,
+                     double pdiag_user, const int32_t* s_off, const int32_t* s_len, const double* s_cap, int eq,
+                     const double* peak, double* xout, int* iters_out, double* pri_out, double* dua_out,
+                     double* obj_out) {
+  const int N = S->N, T = S->Tm, Mg = S->Mg, M = S->M, K = S->K;
+  const int n = N * T, mt = Mg * T;
+  double* buf = (double*)calloc((size_t)(8 * n + 8 * mt + K * N * 3 + 4 * T + 16), sizeof(double));
+  double *x = buf, *z1 = x + n, *y1 = z1 + n, *r0 = y1 + n, *zh = r0 + n, *ub = zh + n, *xt = ub + n, *gty = xt + n;
+  double *z2 = gty + n, *y2 = z2 + mt, *gx = y2 + mt, *w = gx + mt, *wh = w + mt, *gh0 = wh + mt, *eh = gh0 + mt,
+         *hh = eh + mt;
+  double *mu = hh + mt, *slo = mu + K * N, *shi = slo + K * N, *tmpv = shi + K * N;
+  double qnorm = 0, ubmax = 0;
+  for (int k = 0; k < n; ++k) {
+    ub[k] = ub_in[k] < lb[k] ? lb[k] : ub_in[k];
+    qnorm = fmax(qnorm, fabs(q[k]));
+    ubmax = fmax(ubmax, ub[k]);
+  }
+  int status = 2, it = 0;
+  for (int k = 0; k < K; ++k)
+    for (int i = 0; i < N; ++i) {
+      const int L = s_len[k * N + i], o = s_off[k * N + i];
+      double a = 0, b = 0;
+      for (int t = o; t < o + L && t < T; ++t) { a += lb[i * T + t]; b += ub[i * T + t]; }
+      slo[k * N + i] = a; shi[k * N + i] = b;
+      if (L > 0) {
+        const double cap = s_cap[k * N + i], slack = 64 * 1e-13 * fmax(1.0, fabs(cap));
+        if (a > cap + slack || (eq && b < cap - slack)) status = 4;
+      }
+    }
+  double pri = 1e300, dua = 1e300;
+  if (status == 4) {
+    memset(xout, 0, sizeof(double) * n);
+    *iters_out = 0; *pri_out = pri; *dua_out = dua; *obj_out = 0;
+    free(buf);
+    return 4;
+  }
+  double pd = pdiag_user;
+  if (ubmax > 0) pd = fmax(pd, O->reg_rel * qnorm / ubmax);
+  double rho = O->rho;
+  const double sigma = O->sigma, alpha = O->alpha;
+  for (int k = 0; k < n; ++k) r0[k] = -q[k];
+  for (it = 1; it <= O->max_iter; ++it) {
+    const double a = sigma + pd + rho, inv_a = 1.0 / a, inv_rho = 1.0 / rho;
+    /* eigen roles */
+    for (int t = 0; t < T; ++t)
+      for (int j = 0; j < Mg; ++j) {
+        double acc = 0, whj = 0;
+        for (int i = 0; i < N; ++i) acc += S->Ghat[j * N + i] * r0[i * T + t];
+        for (int r = 0; r < Mg; ++r) whj += S->Q[r * Mg + j] * w[r * T + t];
+        const double lj = S->lam[j];
+        const double gh = acc + lj * whj;
+        const double ch = rho * gh / (a + rho * lj);
+        eh[j * T + t] = whj - ch;
+        hh[j * T + t] = (acc + lj * eh[j * T + t]) * inv_a;
+      }
+    /* variable role */
+    for (int i = 0; i < N; ++i)
+      for (int t = 0; t < T; ++t) {
+        double v = r0[i * T + t];
+        for (int j = 0; j < Mg; ++j) v += S->Ghat[j * N + i] * eh[j * T + t];
+        const double xn = v * inv_a;
+        const int k = i * T + t;
+        zh[k] = alpha * xn + (1 - alpha) * z1[k] + y1[k] * inv_rho;
+        x[k] = alpha * xn + (1 - alpha) * x[k];
+        z1[k] = clip(zh[k], lb[k], ub[k]);
+      }
+    for (int k = 0; k < K; ++k)
+      for (int i = 0; i < N; ++i) {
+        const int L = s_len[k * N + i], o = s_off[k * N + i];
+        if (L > 0)
+          project_window(L, zh + i * T + o, lb + i * T + o, ub + i * T + o, s_cap[k * N + i], eq, slo[k * N + i],
+                         shi[k * N + i], &mu[k * N + i], z1 + i * T + o);
+      }
+    for (int k = 0; k < n; ++k) y1[k] = rho * (zh[k] - z1[k]);
+    /* constraint role */
+    for (int t = 0; t < T; ++t) {
+      for (int r = 0; r < Mg; ++r) {
+        double zt = 0;
+        for (int k = 0; k < Mg; ++k) zt += S->Q[r * Mg + k] * hh[k * T + t];
+        gx[r * T + t] = alpha * zt + (1 - alpha) * gx[r * T + t];
+        tmpv[r] = alpha * zt + (1 - alpha) * z2[r * T + t] + y2[r * T + t] * inv_rho;
+      }
+      for (int c = 0; c < M; ++c) {
+        if (S->cone == 1) {
+          const double za = tmpv[c], zb = tmpv[c + M], nrm = sqrt(za * za + zb * zb), lim = S->limits[c];
+          const double sc = nrm > lim ? lim / nrm : 1.0;
+          z2[c * T + t] = za * sc; z2[(c + M) * T + t] = zb * sc;
+          y2[c * T + t] = rho * (za - za * sc); y2[(c + M) * T + t] = rho * (zb - zb * sc);
+        } else {
+          const double za = fmin(tmpv[c], S->limits[c]);
+          y2[c * T + t] = rho * (tmpv[c] - za); z2[c * T + t] = za;
+        }
+      }
+      if (S->has_peak) {
+        const int r = Mg - 1;
+        const double lim = peak ? fmin(peak[t], 1e300) : 1e300;
+        const double za = fmin(tmpv[r], lim);
+        y2[r * T + t] = rho * (tmpv[r] - za); z2[r * T + t] = za;
+      }
+    }
+    const int check = (it % O->check_every == 0) || it >= O->max_iter;
+    int done = 0;
+    if (check) {
+      double v0 = 0, v1 = 0, v2 = 0, v4 = 0, v5 = 0;
+      for (int i = 0; i < N; ++i)
+        for (int t = 0; t < T; ++t) {
+          double g = 0;
+          for (int j = 0; j < Mg; ++j) g += S->G[j * N + i] * y2[j * T + t];
+          const int k = i * T + t;
+          v0 = fmax(v0, fabs(x[k] - z1[k]));
+          v1 = fmax(v1, fabs(pd * x[k] + q[k] + y1[k] + g));
+          v2 = fmax(v2, fmax(fabs(x[k]), fabs(z1[k])));
+          v4 = fmax(v4, fabs(pd * x[k]));
+          v5 = fmax(v5, fabs(y1[k] + g));
+        }
+      for (int k = 0; k < mt; ++k) {
+        v0 = fmax(v0, fabs(gx[k] - z2[k]));
+        v2 = fmax(v2, fmax(fabs(gx[k]), fabs(z2[k])));
+      }
+      pri = v0; dua = v1;
+      const double npri = v2, ndua = fmax(fmax(v4, v5), qnorm);
+      if (pri <= O->eps_abs + O->eps_rel * npri && dua <= O->eps_abs + O->eps_rel * ndua) { status = 1; done = 1; }
+      else if (it >= O->max_iter) done = 1;
+      else if (O->adapt_every > 0 && it % O->adapt_every == 0) {
+        const double sp = pri / fmax(npri, 1e-12), sd = dua / fmax(ndua, 1e-12);
+        const double ratio = sqrt(sp / fmax(sd, 1e-30));
+        if (ratio > O->adapt_tol || ratio < 1.0 / O->adapt_tol) rho = fmin(fmax(rho * ratio, 1e-6), 1e6);
+      }
+    }
+    if (done) break;
+    for (int k = 0; k < n; ++k) r0[k] = sigma * x[k] - q[k] + rho * z1[k] - y1[k];
+    for (int k = 0; k < mt; ++k) w[k] = rho * z2[k] - y2[k];
+  }
+  if (it > O->max_iter) it = O->max_iter;
+  double obj = 0;
+  for (int k = 0; k < n; ++k) { xout[k] = z1[k]; obj += (0.5 * pdiag_user * z1[k] + q[k]) * z1[k]; }
+  *iters_out = it; *pri_out = pri; *dua_out = dua; *obj_out = obj;
+  free(buf);
+  return status;
+}
+
+/* Batch driver: same array layout as include/acn_qp.h (host pointers); `threads` OpenMP threads. */
+int admm_port_solve_batch(const port_site* S, const port_opts* O, int B, const double* lb, const double* ub,
+                          const double* q, const double* pdiag, const int32_t* s_off, const int32_t* s_len,
+                          const double* s_cap, const uint8_t* s_eq, const double* peak, double* x, int32_t* status,
+                          int32_t* iters, double* pri, double* dua, double* obj, int threads) {
+  const size_t nv = (size_t)S->N * S->Tm, ns = (size_t)S->K * S->N;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (int b = 0; b < B; ++b) {
+    int it = 0;
+    status[b] = solve_one(S, O, lb + b * nv, ub + b * nv, q + b * nv, pdiag[b], s_off + b * ns, s_len + b * ns,
+                          s_cap + b * ns, s_eq[b] != 0, peak ? peak + (size_t)b * S->Tm : 0, x + b * nv, &it,
+                          pri + b, dua + b, obj + b);
+    iters[b] = it;
+  }
+  return 0;
+}
+
+int admm_port_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

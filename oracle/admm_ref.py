@@ -46,6 +46,7 @@ class AdmmOptions:
     adaptive_rho: bool = True
     adapt_every: int = 50
     adapt_tol: float = 5.0
+    reg_rel: float = 0.0
 
 
 def project_window(v, lb, ub, cap, eq):
@@ -115,6 +116,8 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
                     pri_res=np.inf, dua_res=np.inf, obj=np.nan, rho=opts.rho)
     lb, ub, q = batch.lb[b], batch.ub[b], batch.q[b]
     pdiag = float(batch.pdiag[b])
+    if ub.max() > 0:
+        pdiag = max(pdiag, opts.reg_rel * np.abs(q).max() / ub.max())
     eq = bool(batch.s_eq[b])
     G, Gh, lam, Q = site.G, site.Ghat, site.lam, site.Q
     Mg = G.shape[0]

@@ -271,8 +271,12 @@ def solve_conic_qp(P, q, G, h, l, nq, A=None, b=None, tol=1e-9, max_iter=100, ve
         if hz < 0 and np.linalg.norm(G.T @ z + A.T @ y + P @ x * 0) / (-hz) < 1e-9 and pres > 1e-6 and it > 5:
             status = "primal_infeasible"
             break
-        Winv, apply_W, apply_Winv, lam = cone.nt_scaling(s, z)
-        kkt = _KKT(P, G, A, Winv)
+        try:
+            Winv, apply_W, apply_Winv, lam = cone.nt_scaling(s, z)
+            kkt = _KKT(P, G, A, Winv)
+        except (np.linalg.LinAlgError, ValueError):
+            status = "numerical_failure"  # diverging iterates (typically an infeasible problem)
+            break
         W2inv = Winv @ Winv
 
         def newton(ds_rhs):
@@ -300,6 +304,8 @@ def solve_conic_qp(P, q, G, h, l, nq, A=None, b=None, tol=1e-9, max_iter=100, ve
         if not np.all(np.isfinite(x)) or not (cone.min_eig(s) > 0 and cone.min_eig(z) > 0) or stall >= 3:
             status = "stalled"
             break
+    if status == "numerical_failure" and best[0] > 1e-6:
+        return IPMResult(x, status, it + 1, pcost, gap, pres, dres), (y, z, s)
     if status != "optimal" and status != "primal_infeasible":
         # ECOS-like reduced-accuracy exit: keep the best iterate seen
         merit, x, (y, z, s), pcost, gap, pres, dres = best

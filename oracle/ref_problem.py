@@ -173,8 +173,8 @@ def objective_terms(objective_spec, infrastructure, interface, N, T):
         # x is (i, t) row-major: block for period t picks indices i*T + t
         sel = sp.csr_matrix(
             (np.ones(n), (np.arange(n), (np.arange(n) % T) * N + np.arange(n) // T)), shape=(n, n)
-        )  # permutation (i,t) -> (t,i)
-        P = P + sel.T @ sp.kron(sp.identity(T), vv, format="csr") @ sel
+        )  # sel[i*T + t, t*N + i] = 1: maps the (t, i)-ordered vector to the (i, t)-ordered one
+        P = P + sel @ sp.kron(sp.identity(T), vv, format="csr") @ sel.T
     return sp.csr_matrix(P), q.reshape(-1)
 
 

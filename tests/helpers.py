@@ -1,0 +1,81 @@
+"""Shared test helpers: golden-fixture loading and the four invariants the
+reference's own test base class asserts (t_aco.py:50-83)."""
+import os
+
+import numpy as np
+
+from adacharge_amd import sites
+from adacharge_amd.acn import Interface, SessionInfo
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "caltech54_T12.npz")
+
+
+def load_golden():
+    return np.load(GOLDEN, allow_pickle=False)
+
+
+def golden_case(g, key):
+    """Rebuild the SessionInfo list of fixture ``key``; returns
+    (sessions, meta dict, expected dict)."""
+    st = g[f"{key}_station"]
+    sessions = []
+    for k in range(len(st)):
+        rem = int(g[f"{key}_departure"][k] - g[f"{key}_arrival"][k])
+        mins = np.zeros(rem)
+        mins[0] = g[f"{key}_min0"][k]
+        sessions.append(
+            SessionInfo(
+                str(st[k]), f"s{k}", float(g[f"{key}_demand"][k]), 0.0,
+                int(g[f"{key}_arrival"][k]), int(g[f"{key}_departure"][k]),
+                current_time=0, min_rates=mins, max_rates=float(g[f"{key}_maxr"][k]),
+            )
+        )
+    m = g[f"{key}_meta"]
+    meta = dict(seed=int(m[0]), ct="SOC" if m[1] else "LINEAR", es=float(m[2]), eq=bool(m[3]), T=int(m[4]))
+    exp = {k: g[f"{key}_{k}"] for k in ("rates", "obj", "agg") if f"{key}_{k}" in g}
+    return sessions, meta, exp
+
+
+def caltech_interface():
+    infra = sites.caltech54()
+    return infra, Interface({"infrastructure_info": infra, "period": 5})
+
+
+# ---- the reference's invariants (t_aco.py:50-83) ------------------------------------
+def assert_rates_below_max(rates, max_rate, tol=1e-3):
+    assert (rates <= max_rate + tol).all()
+
+
+def energy_delivered(rates, sessions, infrastructure, period):
+    out = []
+    for s in sessions:
+        i = infrastructure.station_ids.index(s.station_id)
+        e = rates[i, s.arrival_offset : s.arrival_offset + s.remaining_time].sum()
+        out.append(e * infrastructure.voltages[i] * period / 1e3 / 60)
+    return np.array(out)
+
+
+def assert_energy_demands_met(rates, sessions, infrastructure, period):
+    delivered = energy_delivered(rates, sessions, infrastructure, period)
+    expected = np.array([s.remaining_demand for s in sessions])
+    assert np.allclose(delivered, expected, atol=1e-4, rtol=1e-4)
+
+
+def assert_no_charging_when_unplugged(rates, sessions, infrastructure):
+    mask = np.ones(rates.shape, dtype=bool)
+    for s in sessions:
+        i = infrastructure.station_ids.index(s.station_id)
+        mask[i, s.arrival_offset : s.arrival_offset + s.remaining_time] = False
+    assert np.allclose(rates[mask], 0)
+
+
+def infrastructure_violation(rates, infrastructure):
+    """max over rows/periods of |[v cos; v sin] @ rates| - limit (utils.py:5-12 formula)."""
+    ph = np.deg2rad(infrastructure.phases)
+    cm = infrastructure.constraint_matrix
+    mag = np.hypot((cm * np.cos(ph)) @ rates, (cm * np.sin(ph)) @ rates)
+    return float((mag - np.asarray(infrastructure.constraint_limits)[:, None]).max())
+
+
+def assert_infrastructure_satisfied(rates, infrastructure, tol=1e-3):
+    assert infrastructure_violation(rates, infrastructure) <= tol

@@ -1,0 +1,43 @@
+"""The numpy restatement of the device algorithm (oracle/admm_ref.py) against
+the independent IPM oracle's golden vectors, and its projection against brute
+force -- so a kernel/oracle disagreement can be attributed."""
+import numpy as np
+import pytest
+
+from adacharge_amd import ObjectiveComponent, equal_share, quick_charge
+from adacharge_amd.builder import build_batch
+from oracle.admm_ref import AdmmOptions, project_window, solve_one
+from tests.helpers import caltech_interface, golden_case, load_golden
+
+
+@pytest.mark.parametrize("key", ["c01", "c03"])
+def test_admm_restatement_matches_golden(key):
+    g = load_golden()
+    infra, iface = caltech_interface()
+    sl, meta, exp = golden_case(g, key)
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, meta["es"])]
+    batch = build_batch([sl], infra, iface, obj, meta["ct"], meta["eq"])
+    out = solve_one(batch, 0, AdmmOptions(eps_abs=1e-8, eps_rel=1e-8, rho=0.01, max_iter=5000))
+    assert out["status"] == 1
+    assert np.abs(out["x"][:, : meta["T"]] - exp["rates"]).max() <= 1e-4 * 32
+
+
+def test_project_window_is_the_euclidean_projection():
+    rng = np.random.default_rng(0)
+    from scipy.optimize import minimize
+
+    for eq in (False, True):
+        for _ in range(10):
+            L = int(rng.integers(1, 7))
+            v = rng.normal(10, 15, size=L)
+            lb = rng.uniform(0, 4, size=L) * (rng.random(L) < 0.3)
+            ub = lb + rng.uniform(1, 30, size=L)
+            cap = rng.uniform(lb.sum(), ub.sum())
+            z = project_window(v, lb, ub, cap, eq)
+            assert (z >= lb - 1e-12).all() and (z <= ub + 1e-12).all()
+            assert z.sum() <= cap + 1e-9 and (not eq or abs(z.sum() - cap) < 1e-9)
+            cons = [{"type": "eq" if eq else "ineq", "fun": lambda x: cap - x.sum()}]
+            ref = minimize(lambda x: 0.5 * ((x - v) ** 2).sum(), np.clip(v, lb, ub), jac=lambda x: x - v,
+                           bounds=list(zip(lb, ub)), constraints=cons, method="SLSQP",
+                           options=dict(ftol=1e-14, maxiter=200))
+            assert np.abs(z - ref.x).max() < 1e-5

@@ -1,0 +1,257 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against
+(i) the reference's own scenario table and invariants (t_aco.py), (ii) the
+oracle-certified golden vectors, (iii) size-independent properties at the
+BASELINE.json batch sizes.  Tolerance on rates: 1e-4 relative to the 32 A
+pilot scale (north_star), i.e. 3.2e-3 A absolute."""
+import numpy as np
+import pytest
+
+from adacharge_amd import (
+    AdaptiveChargingOptimization, InfeasibilityException, ObjectiveComponent, equal_share, quick_charge,
+    tou_energy_cost, sites,
+)
+from adacharge_amd.backend import SiteHandle, default_options
+from adacharge_amd.builder import build_batch
+from tests.acn_testing import (
+    TestingInterface, session_generator, single_phase_single_constraint, three_phase_balanced_network,
+)
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+RATE_TOL = 1e-4 * 32.0
+DEFAULT_OBJECTIVE = [ObjectiveComponent(quick_charge)]
+KAT1_ROW = np.array([32.0] * 5 + [3.3 / (208 * 5 / 60 / 1e3) - 160] + [0.0] * 6)
+
+
+def tiny_interface(arrivals=(0, 0), departures=(12, 12), limit=64, min_rates=None, station_ids=None,
+                   current_time=0, prices=None):
+    sd = session_generator(2, list(arrivals), list(departures), [3.3] * 2, [3.3] * 2, [32] * 2,
+                           min_rates=min_rates, station_ids=station_ids)
+    d = {"active_sessions": sd, "infrastructure_info": single_phase_single_constraint(2, limit),
+         "current_time": current_time, "period": 5}
+    if prices is not None:
+        d["prices"] = prices
+    return TestingInterface(d)
+
+
+def run(iface, objective=DEFAULT_OBJECTIVE, **kw):
+    solve_kw = {k: kw.pop(k) for k in ("peak_limit",) if k in kw}
+    infra = iface.infrastructure_info()
+    sessions = iface.active_sessions()
+    opt = AdaptiveChargingOptimization(objective, iface, **kw)
+    return opt.solve(sessions, infra, **solve_kw), sessions, infra
+
+
+def check_invariants(rates, sessions, infra, period=5, max_rate=32):
+    """t_aco.py:50-83"""
+    H.assert_rates_below_max(rates, max_rate)
+    H.assert_energy_demands_met(rates, sessions, infra, period)
+    H.assert_no_charging_when_unplugged(rates, sessions, infra)
+    H.assert_infrastructure_satisfied(rates, infra)
+
+
+# ---- the reference's tiny scenarios (t_aco.py:87-282) ------------------------------------
+@pytest.mark.parametrize("eq", [False, True])
+@pytest.mark.parametrize("ct", ["SOC", "LINEAR"])
+def test_tiny_feasible_network_closed_form(eq, ct):
+    rates, sessions, infra = run(tiny_interface(), enforce_energy_equality=eq, constraint_type=ct)
+    assert rates.shape == (2, 12)
+    check_invariants(rates, sessions, infra)
+    assert np.abs(rates - np.stack([KAT1_ROW] * 2)).max() <= RATE_TOL   # KAT-1
+
+
+@pytest.mark.parametrize("kw", [dict(departures=(12, 4)), dict(limit=30)])
+def test_tiny_infeasible_raises(kw):   # t_aco.py:119-175
+    iface = tiny_interface(**kw)
+    opt = AdaptiveChargingOptimization(DEFAULT_OBJECTIVE, iface, enforce_energy_equality=True,
+                                       solver_options=dict(max_iter=20000))
+    with pytest.raises(InfeasibilityException, match="Solve failed with status"):
+        opt.solve(iface.active_sessions(), iface.infrastructure_info())
+
+
+def test_tiny_delayed_start():   # t_aco.py:178-191
+    rates, sessions, infra = run(tiny_interface(arrivals=(0, 4), departures=(12, 16)))
+    assert rates.shape == (2, 16)
+    check_invariants(rates, sessions, infra)
+
+
+def test_tiny_multiple_sessions_same_evse():   # t_aco.py:194-208
+    rates, sessions, infra = run(tiny_interface(arrivals=(0, 12), departures=(12, 24), station_ids=["0", "0"]))
+    assert rates.shape == (2, 24)
+    H.assert_rates_below_max(rates, 32)
+    H.assert_no_charging_when_unplugged(rates, sessions, infra)
+    H.assert_infrastructure_satisfied(rates, infra)
+    delivered = H.energy_delivered(rates, sessions, infra, 5)
+    assert np.allclose(delivered, 3.3, atol=1e-4, rtol=1e-4)
+
+
+def test_tiny_minimum_charge():   # t_aco.py:211-229
+    rates, sessions, infra = run(tiny_interface(min_rates=[6, 6]))
+    check_invariants(rates, sessions, infra)
+    assert (rates >= 6 - 1e-7).all()
+
+
+@pytest.mark.parametrize("peak", [32, np.array([40] * 6 + [24] * 6)])
+def test_tiny_peak_limit(peak):   # t_aco.py:232-282
+    rates, sessions, infra = run(tiny_interface(), peak_limit=peak)
+    check_invariants(rates, sessions, infra)
+    assert (rates.sum(axis=0) <= peak + 1e-7).all()
+
+
+def test_tou_cost_minimisation():   # t_aco.py:469-507
+    iface = tiny_interface(prices=np.array([0.3] * 6 + [0.1] * 6))
+    rates, sessions, infra = run(iface, [ObjectiveComponent(tou_energy_cost)], enforce_energy_equality=True)
+    check_invariants(rates, sessions, infra)
+    assert np.allclose(rates[:, :6], 0, atol=1e-3)
+
+
+def test_tou_cost_minimisation_nonzero_current_time():   # t_aco.py:510-545
+    sd = session_generator(2, [0] * 2, [12] * 2, [3.3] * 2, [3.3] * 2, [32] * 2)
+    iface = TestingInterface({"active_sessions": sd, "infrastructure_info": single_phase_single_constraint(2, 64),
+                              "current_time": 4, "period": 5,
+                              "prices": np.array([0.0] * 4 + [0.3] * 2 + [0.1] * 6)})
+    rates, sessions, infra = run(iface, [ObjectiveComponent(tou_energy_cost)], enforce_energy_equality=True)
+    assert rates.shape == (2, 8)
+    check_invariants(rates, sessions, infra)
+    assert np.allclose(rates[:, :2], 0, atol=1e-3)
+    assert np.all(rates[:, 2:] > 1e-4)
+
+
+def test_no_sessions_returns_zero_column():   # aco.py:310-311
+    iface = tiny_interface()
+    out = AdaptiveChargingOptimization(DEFAULT_OBJECTIVE, iface).solve([], iface.infrastructure_info())
+    assert out.shape == (2, 1) and not out.any()
+
+
+def test_bad_constraint_type_raises_value_error():   # aco.py:173-178
+    iface = tiny_interface()
+    with pytest.raises(ValueError, match="SOC or AFFINE"):
+        AdaptiveChargingOptimization(DEFAULT_OBJECTIVE, iface, constraint_type="AFFINE").solve(
+            iface.active_sessions(), iface.infrastructure_info())
+
+
+# ---- three-phase mixed rows: SOC differs from LINEAR -----------------------------------------
+@pytest.mark.parametrize("ct", ["SOC", "LINEAR"])
+def test_three_phase_small(ct):
+    N, T = 12, 12
+    sd = session_generator(N, [0] * N, [T] * N, [10] * N, [10] * N, [32] * N)
+    infra = three_phase_balanced_network(N // 3, 60)
+    iface = TestingInterface({"active_sessions": sd, "infrastructure_info": infra, "current_time": 0, "period": 5})
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    opt = AdaptiveChargingOptimization(obj, iface, constraint_type=ct)
+    rates = opt.solve(iface.active_sessions(), iface.infrastructure_info())
+    info = iface.infrastructure_info()
+    H.assert_infrastructure_satisfied(rates, info)   # SOC norm holds for both (LINEAR is tighter)
+    if ct == "LINEAR":
+        assert (np.abs(info.constraint_matrix) @ rates <= 60 + 1e-6).all()
+
+
+# ---- golden vectors (oracle-certified optimum of the reference's problem statement) -----------
+def test_golden_strictly_convex_rates():
+    g = H.load_golden()
+    infra, iface = H.caltech_interface()
+    keys = sorted(k[:-6] for k in g.files if k.endswith("_rates"))
+    worst = {}
+    for key in keys:
+        sl, meta, exp = H.golden_case(g, key)
+        obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, meta["es"])]
+        opt = AdaptiveChargingOptimization(obj, iface, constraint_type=meta["ct"],
+                                           enforce_energy_equality=meta["eq"],
+                                           solver_options=dict(reg_rel=0.0))
+        rates = opt.solve(sl, infra)
+        d = float(np.abs(rates - exp["rates"]).max())
+        worst[key] = d
+        assert d <= RATE_TOL, (key, meta, d)
+        assert abs(opt.last_result.obj[0] - float(exp["obj"])) <= 1e-6 * abs(float(exp["obj"]))
+        H.assert_infrastructure_satisfied(rates, infra, tol=1e-5)
+    print("max |rate - oracle| over golden cases: %.3e A" % max(worst.values()))
+
+
+def test_golden_lp_objective_and_aggregate():
+    """Pure quick_charge is a degenerate LP: parity is on the
+    objective, the per-period aggregate and feasibility, against scipy-HiGHS."""
+    g = H.load_golden()
+    infra, iface = H.caltech_interface()
+    for key in sorted(k[:-4] for k in g.files if k.endswith("_agg")):
+        sl, meta, exp = H.golden_case(g, key)
+        opt = AdaptiveChargingOptimization(DEFAULT_OBJECTIVE, iface, constraint_type="LINEAR")
+        rates = opt.solve(sl, infra)
+        lp_obj = -(rates * np.array([(12 - t) / 12 for t in range(12)])[None, :]).sum()
+        assert abs(lp_obj - float(exp["obj"])) <= 2e-6 * abs(float(exp["obj"])), key
+        assert np.abs(rates.sum(0) - exp["agg"]).max() <= 5e-3 * max(1.0, exp["agg"].max()) , key
+        assert (np.abs(infra.constraint_matrix) @ rates <= infra.constraint_limits[:, None] + 1e-5).all()
+
+
+# ---- BASELINE.json batch sizes: properties that need no oracle --------------------------------
+@pytest.mark.parametrize("B,ct", [(256, "LINEAR"), (256, "SOC"), (4096, "SOC")])
+def test_full_batch_invariants_and_determinism(B, ct):
+    infra, iface = H.caltech_interface()
+    T = 12
+    snaps = sites.snapshot_batch(infra, T, B, seed=11)
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    batch = build_batch(snaps, infra, iface, obj, ct)
+    h = SiteHandle(batch.site, 0)
+    o = default_options()
+    res = h.solve(batch, o)
+    assert (res.status == 1).all()
+    # invariants on every instance (t_aco.py:50-83), vectorised
+    assert (res.x <= batch.ub + 1e-9).all() and (res.x >= batch.lb - 1e-9).all()
+    ph = np.deg2rad(infra.phases)
+    cm = infra.constraint_matrix
+    re = np.einsum("mn,bnt->bmt", cm * np.cos(ph), res.x)
+    im = np.einsum("mn,bnt->bmt", cm * np.sin(ph), res.x)
+    assert (np.hypot(re, im) <= infra.constraint_limits[None, :, None] + 1e-3).all()
+    for b in range(0, B, max(1, B // 16)):
+        e = H.energy_delivered(res.x[b], snaps[b], infra, 5)
+        assert (e <= np.array([s.remaining_demand for s in snaps[b]]) + 1e-6).all()
+    # determinism: same launch twice is bitwise identical
+    res2 = h.solve(batch, o)
+    assert np.array_equal(res.x, res2.x) and np.array_equal(res.iters, res2.iters)
+    # batch-order independence: each problem's result does not depend on its neighbours
+    perm = np.random.default_rng(0).permutation(B)
+    batch_p = build_batch([snaps[k] for k in perm], infra, iface, obj, ct, site=batch.site)
+    res_p = h.solve(batch_p, o)
+    assert np.array_equal(res_p.x, res.x[perm])
+    # objective never worse than a feasible heuristic (scaled-down max rates)
+    heur = np.minimum(batch.ub, 4.0)
+    heur_obj = 0.5 * batch.pdiag[:, None, None] * heur ** 2 + batch.q * heur
+    cap_ok = np.ones(B, bool)
+    assert (res.obj[cap_ok] <= heur_obj.sum(axis=(1, 2))[cap_ok] + 1e-6).all()
+    h.close()
+
+
+def test_device_pointer_entry_matches_host_entry():
+    import torch
+    from adacharge_amd.backend import DeviceBatch
+
+    infra, iface = H.caltech_interface()
+    snaps = sites.snapshot_batch(infra, 12, 64, seed=5)
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    batch = build_batch(snaps, infra, iface, obj, "SOC")
+    h = SiteHandle(batch.site, 0)
+    o = default_options()
+    host = h.solve(batch, o)
+    dev = DeviceBatch(batch, "cuda:0")
+    h.solve_device(dev, o, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.x.cpu().numpy(), host.x)
+    assert np.array_equal(dev.status.cpu().numpy(), host.status)
+    assert h.last_kernel_ms() > 0
+    h.close()
+
+
+def test_fp32_path_reaches_its_tolerance():
+    infra, iface = H.caltech_interface()
+    snaps = sites.snapshot_batch(infra, 12, 32, seed=9)
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-2)]
+    batch = build_batch(snaps, infra, iface, obj, "SOC")
+    h = SiteHandle(batch.site, 0)
+    # same stopping tolerance in both precisions: the fp32 loop must land where the fp64 loop
+    # lands (the remaining distance to the optimum is set by eps, not by the arithmetic type)
+    r64 = h.solve(batch, default_options(eps_abs=5e-5, eps_rel=5e-5, reg_rel=0.0))
+    r32 = h.solve(batch, default_options(eps_abs=5e-5, eps_rel=5e-5, reg_rel=0.0, precision=32))
+    assert (r64.status == 1).all() and (r32.status == 1).all()
+    assert np.abs(r32.x - r64.x).max() <= 2e-2   # 6e-4 relative to the 32 A pilot scale
+    assert np.abs(r32.obj - r64.obj).max() <= 1e-4 * np.abs(r64.obj).max()
+    h.close()

@@ -18,7 +18,7 @@ for ct in ("LINEAR","SOC"):
     sl = sites.snapshot_batch(infra, T, 8, seed=1)
     batch = build_batch(sl, infra, iface, obj, ct)
     h = SiteHandle(batch.site)
-    o = default_options(eps_abs=1e-8, eps_rel=1e-8, reg_min=0.0, rho=0.1)
+    o = default_options(eps_abs=1e-8, eps_rel=1e-8, reg_rel=0.0, rho=0.1)
     t=time.time(); res = h.solve(batch, o); dt=time.time()-t
     print(ct, "status", res.status, "iters", res.iters, "kernel_ms %.3f wall %.3f"%(res.kernel_ms, dt))
     for b in range(4):
