@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "adacharge_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "adacharge_amd", "lib")
 LIB = os.path.join(LIBDIR, "libacn_qp_hip.so")
 SOURCES = [os.path.join(CSRC, "acn_qp_api.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "acn_qp_kernel.hpp"), os.path.join(ROOT, "include", "acn_qp.h")]
+DEPS = SOURCES + [os.path.join(CSRC, "acn_qp_tiled.hpp"), os.path.join(ROOT, "include", "acn_qp.h")]
 
 
 def hipcc_path() -> str:
@@ -38,7 +38,7 @@ def build_hip_library(force: bool = False, verbose: bool = True) -> str:
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [
-        hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+        hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans", "-mno-amdgpu-ieee", "-fPIC", "-shared",
         "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
         *SOURCES, "-o", LIB,
     ]

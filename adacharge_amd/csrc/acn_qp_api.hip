@@ -8,7 +8,7 @@
 #include <vector>
 
 #include "acn_qp.h"
-#include "acn_qp_kernel.hpp"
+#include "acn_qp_tiled.hpp"
 
 namespace {
 
@@ -26,7 +26,7 @@ int fail(int rc, const std::string& msg) {
       return fail(ACNQP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
   } while (0)
 
-// Cyclic Jacobi eigen-decomposition of a small symmetric matrix (n <= kMaxRows).
+// Cyclic Jacobi eigen-decomposition of a small symmetric matrix (n <= 48).
 // a is overwritten; on return lam[k] are eigenvalues and V[r*n + k] the k-th eigenvector.
 void jacobi_eigh(int n, std::vector<double>& a, std::vector<double>& lam, std::vector<double>& V) {
   V.assign((size_t)n * n, 0.0);
@@ -87,42 +87,144 @@ struct DevBuf {
 
 }  // namespace
 
+// Site data in the kernel's internal row order, one copy per arithmetic type (the MFMA C-operand
+// row map differs between f64 and f32, and SOC pairs must sit in adjacent registers of one lane).
+struct SiteDev {
+  bool ready = false;
+  int MR = 0;                    // padded rows (multiple of 16)
+  void *G = nullptr, *Ghat = nullptr, *Q = nullptr, *lam = nullptr, *rowlim = nullptr;
+  int32_t* rowtype = nullptr;
+  void release() {
+    for (void** p : {&G, &Ghat, &Q, &lam, &rowlim}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    if (rowtype) (void)hipFree(rowtype);
+    rowtype = nullptr;
+    ready = false;
+  }
+};
+
 struct acnqp_handle {
   int device = 0;
-  int N = 0, M = 0, Mg = 0, Mc = 0, cone = 0, has_peak = 0;
-  double *dG = nullptr, *dGhat = nullptr, *dQ = nullptr, *dLam = nullptr, *dLim = nullptr;
+  int N = 0, M = 0, Mg = 0, cone = 0, has_peak = 0;
+  int NW = 4, NP = 64;
+  std::vector<double> G, limits;   // host copy in ABI order
+  SiteDev dev64, dev32;
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   bool timed = false;
   hipStream_t stream = nullptr;   // used by the host-buffer entry point
   DevBuf in, out;                 // staging for the host-buffer entry point
 };
 
-template <typename real, int TPT, int KS>
-static hipError_t launch_one(const acnqp::KernelArgs& a, hipStream_t st) {
-  const acnqp::LdsLayout L(a.N, 4 * TPT, a.Mg, a.M);
-  const size_t lds = (size_t)L.total * sizeof(real);
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&acnqp::admm_kernel<real, TPT, KS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL((acnqp::admm_kernel<real, TPT, KS>), dim3(a.B), dim3(acnqp::kThreads), lds, st, a);
-  return hipGetLastError();
-}
+namespace {
 
-template <typename real, int KS>
-static hipError_t launch_for_tmax(const acnqp::KernelArgs& a, hipStream_t st) {
-  if (a.Tm <= 12) return launch_one<real, 3, KS>(a, st);
-  if (a.Tm <= 16) return launch_one<real, 4, KS>(a, st);
-  if (a.Tm <= 24) return launch_one<real, 6, KS>(a, st);
-  return launch_one<real, 8, KS>(a, st);
+// internal row slot of site row (constraint c, component) -- see acn_qp_tiled.hpp
+inline int soc_slot(bool f64, int c, int im) {
+  return f64 ? 8 * (c / 4) + (c % 4) + 4 * im : 2 * c + im;
 }
 
 template <typename real>
-static hipError_t launch_for_k(const acnqp::KernelArgs& a, hipStream_t st) {
-  if (a.K == 1) return launch_for_tmax<real, 1>(a, st);
-  return launch_for_tmax<real, acnqp::kMaxK>(a, st);
+int build_site_dev(acnqp_handle* h, SiteDev* d) {
+  const bool f64 = sizeof(real) == 8;
+  const int N = h->N, M = h->M, NP = h->NP;
+  int raw;
+  if (h->cone == ACNQP_CONE_SOC) raw = (f64 ? 8 * ((M + 3) / 4) : 2 * M) + h->has_peak;
+  else raw = M + h->has_peak;
+  const int MR = 16 * ((raw + 15) / 16 > 0 ? (raw + 15) / 16 : 1);
+  if (MR > 48) return fail(ACNQP_ERR_INVALID, "site has too many rows for the tiled kernel (> 48 after padding)");
+  std::vector<double> Gi((size_t)MR * NP, 0.0), lim(MR, 0.0);
+  std::vector<int32_t> ty(MR, acnqp::kRowFree);
+  auto put = [&](int slot, int src_row, int type, double limit) {
+    for (int i = 0; i < N; ++i) Gi[(size_t)slot * NP + i] = h->G[(size_t)src_row * N + i];
+    ty[slot] = type;
+    lim[slot] = limit;
+  };
+  int peak_slot;
+  if (h->cone == ACNQP_CONE_SOC) {
+    for (int c = 0; c < M; ++c) {
+      put(soc_slot(f64, c, 0), c, acnqp::kRowSocRe, h->limits[c]);
+      put(soc_slot(f64, c, 1), c + M, acnqp::kRowSocIm, h->limits[c]);
+    }
+    peak_slot = f64 ? 8 * ((M + 3) / 4) : 2 * M;
+  } else {
+    for (int c = 0; c < M; ++c) put(c, c, acnqp::kRowBox, h->limits[c]);
+    peak_slot = M;
+  }
+  if (h->has_peak) put(peak_slot, h->Mg - 1, acnqp::kRowPeak, 0.0);
+
+  std::vector<double> GGt((size_t)MR * MR, 0.0), lam, Q;
+  for (int r = 0; r < MR; ++r)
+    for (int c = 0; c < MR; ++c) {
+      double s = 0;
+      for (int i = 0; i < N; ++i) s += Gi[(size_t)r * NP + i] * Gi[(size_t)c * NP + i];
+      GGt[(size_t)r * MR + c] = s;
+    }
+  jacobi_eigh(MR, GGt, lam, Q);
+  double lmax = 0;
+  for (int k = 0; k < MR; ++k) lmax = std::fmax(lmax, lam[k]);
+  std::vector<double> Gh((size_t)MR * NP, 0.0);
+  for (int k = 0; k < MR; ++k) {
+    if (lam[k] < 1e-12 * std::fmax(1.0, lmax)) { lam[k] = 0.0; continue; }
+    for (int i = 0; i < N; ++i) {
+      double s = 0;
+      for (int r = 0; r < MR; ++r) s += Q[(size_t)r * MR + k] * Gi[(size_t)r * NP + i];
+      Gh[(size_t)k * NP + i] = s;
+    }
+  }
+  auto up = [&](void** dst, const std::vector<double>& src) -> hipError_t {
+    std::vector<real> tmp(src.begin(), src.end());
+    hipError_t e = hipMalloc(dst, tmp.size() * sizeof(real));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(real), hipMemcpyHostToDevice);
+  };
+  hipError_t e = up(&d->G, Gi);
+  if (e == hipSuccess) e = up(&d->Ghat, Gh);
+  if (e == hipSuccess) e = up(&d->Q, Q);
+  if (e == hipSuccess) e = up(&d->lam, lam);
+  if (e == hipSuccess) e = up(&d->rowlim, lim);
+  if (e == hipSuccess) e = hipMalloc((void**)&d->rowtype, MR * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpy(d->rowtype, ty.data(), MR * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { d->release(); return fail(ACNQP_ERR_HIP, std::string("site upload: ") + hipGetErrorString(e)); }
+  d->MR = MR;
+  d->ready = true;
+  return ACNQP_OK;
 }
+
+template <typename real, int NW, int CT, int MT, int KS>
+hipError_t launch_tiled(const acnqp::TiledArgs& a, hipStream_t st) {
+  const acnqp::TiledLds L(NW, MT, CT, a.NP, a.K);
+  const size_t lds = (size_t)L.total * sizeof(real);
+  auto kern = &acnqp::admm_tiled_kernel<real, NW, CT, MT, KS>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.B), dim3(NW * 64), lds, st, a);
+  return hipGetLastError();
+}
+
+template <typename real, int NW, int CT, int MT>
+hipError_t launch_k(const acnqp::TiledArgs& a, hipStream_t st) {
+  if (a.K == 1) return launch_tiled<real, NW, CT, MT, 1>(a, st);
+  return launch_tiled<real, NW, CT, MT, acnqp::kMaxK>(a, st);
+}
+
+template <typename real, int NW, int CT>
+hipError_t launch_mt(const acnqp::TiledArgs& a, hipStream_t st) {
+  switch (a.MR / 16) {
+    case 1: return launch_k<real, NW, CT, 1>(a, st);
+    case 2: return launch_k<real, NW, CT, 2>(a, st);
+    default: return launch_k<real, NW, CT, 3>(a, st);
+  }
+}
+
+template <typename real>
+hipError_t launch_any(const acnqp::TiledArgs& a, int NW, hipStream_t st) {
+  const int CT = (a.Tm + 15) / 16;
+  if (NW == 4) return CT == 1 ? launch_mt<real, 4, 1>(a, st) : launch_mt<real, 4, 2>(a, st);
+  return launch_mt<real, 16, 1>(a, st);
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -135,8 +237,8 @@ void acnqp_default_options(acnqp_options* o) {
   o->eps_abs = 1e-8;
   o->eps_rel = 1e-8;
   o->max_iter = 20000;
-  o->check_every = 10;
-  o->adapt_every = 50;
+  o->check_every = 20;
+  o->adapt_every = 40;
   o->rho = 0.003;
   o->sigma = 1e-6;
   o->alpha = 1.6;
@@ -150,13 +252,13 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
   if (!site || !out) return fail(ACNQP_ERR_INVALID, "acnqp_create: null argument");
   *out = nullptr;
   const int N = site->n_evse, M = site->n_infra, Mg = site->n_rows;
-  if (N < 1 || N > acnqp::kMaxEvse)
-    return fail(ACNQP_ERR_INVALID, "acnqp_create: n_evse must be in [1, 64] for the resident kernel");
+  if (N < 1 || N > 256)
+    return fail(ACNQP_ERR_INVALID, "acnqp_create: n_evse must be in [1, 256] for the tiled kernel");
   if (site->cone != ACNQP_CONE_LINEAR && site->cone != ACNQP_CONE_SOC)
     return fail(ACNQP_ERR_INVALID, "acnqp_create: cone must be ACNQP_CONE_LINEAR or ACNQP_CONE_SOC");
   const int expect = (site->cone == ACNQP_CONE_SOC ? 2 * M : M) + (site->has_peak ? 1 : 0);
-  if (M < 0 || Mg != expect || Mg > acnqp::kMaxRows)
-    return fail(ACNQP_ERR_INVALID, "acnqp_create: n_rows inconsistent with n_infra/cone/has_peak or > 40");
+  if (M < 0 || Mg != expect || Mg > 48)
+    return fail(ACNQP_ERR_INVALID, "acnqp_create: n_rows inconsistent with n_infra/cone/has_peak or > 48");
   if (Mg > 0 && !site->G) return fail(ACNQP_ERR_INVALID, "acnqp_create: G is null");
   if (M > 0 && !site->limits) return fail(ACNQP_ERR_INVALID, "acnqp_create: limits is null");
   for (int j = 0; j < M; ++j)
@@ -168,44 +270,14 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
   if (device_id < 0 || device_id >= ndev) return fail(ACNQP_ERR_INVALID, "acnqp_create: bad device_id");
   HIP_TRY(hipSetDevice(device_id));
 
-  // eigen-decomposition of G G' and the rotated rows Ghat = Q' G
-  std::vector<double> GGt((size_t)Mg * Mg, 0.0), lam, Q;
-  for (int r = 0; r < Mg; ++r)
-    for (int c = 0; c < Mg; ++c) {
-      double s = 0;
-      for (int i = 0; i < N; ++i) s += site->G[(size_t)r * N + i] * site->G[(size_t)c * N + i];
-      GGt[(size_t)r * Mg + c] = s;
-    }
-  jacobi_eigh(Mg, GGt, lam, Q);
-  double lmax = 0;
-  for (int k = 0; k < Mg; ++k) lmax = std::fmax(lmax, lam[k]);
-  std::vector<double> Ghat((size_t)Mg * N, 0.0);
-  for (int k = 0; k < Mg; ++k) {
-    if (lam[k] < 1e-12 * std::fmax(1.0, lmax)) { lam[k] = 0.0; continue; }
-    for (int i = 0; i < N; ++i) {
-      double s = 0;
-      for (int r = 0; r < Mg; ++r) s += Q[(size_t)r * Mg + k] * site->G[(size_t)r * N + i];
-      Ghat[(size_t)k * N + i] = s;
-    }
-  }
-
   acnqp_handle* h = new acnqp_handle();
   h->device = device_id;
   h->N = N; h->M = M; h->Mg = Mg; h->cone = site->cone; h->has_peak = site->has_peak ? 1 : 0;
-  h->Mc = M + h->has_peak;
-  auto up = [&](double** d, const double* src, size_t n) -> hipError_t {
-    hipError_t e = hipMalloc((void**)d, (n ? n : 1) * sizeof(double));
-    if (e != hipSuccess) return e;
-    if (n) e = hipMemcpy(*d, src, n * sizeof(double), hipMemcpyHostToDevice);
-    return e;
-  };
-  hipError_t e = hipSuccess;
-  if (e == hipSuccess) e = up(&h->dG, site->G, (size_t)Mg * N);
-  if (e == hipSuccess) e = up(&h->dGhat, Ghat.data(), (size_t)Mg * N);
-  if (e == hipSuccess) e = up(&h->dQ, Q.data(), (size_t)Mg * Mg);
-  if (e == hipSuccess) e = up(&h->dLam, lam.data(), (size_t)Mg);
-  if (e == hipSuccess) e = up(&h->dLim, site->limits, (size_t)M);
-  if (e == hipSuccess) e = hipEventCreate(&h->ev_start);
+  h->NW = N <= 64 ? 4 : 16;
+  h->NP = 16 * h->NW;
+  h->G.assign(site->G, site->G + (size_t)Mg * N);
+  h->limits.assign(site->limits, site->limits + M);
+  hipError_t e = hipEventCreate(&h->ev_start);
   if (e == hipSuccess) e = hipEventCreate(&h->ev_stop);
   if (e == hipSuccess) e = hipStreamCreate(&h->stream);
   if (e != hipSuccess) {
@@ -213,6 +285,8 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
     acnqp_destroy(h);
     return fail(ACNQP_ERR_HIP, msg);
   }
+  int rc = build_site_dev<double>(h, &h->dev64);   // the fp32 copy is built on first use
+  if (rc != ACNQP_OK) { acnqp_destroy(h); return rc; }
   *out = h;
   return ACNQP_OK;
 }
@@ -220,11 +294,8 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
 void acnqp_destroy(acnqp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  if (h->dG) (void)hipFree(h->dG);
-  if (h->dGhat) (void)hipFree(h->dGhat);
-  if (h->dQ) (void)hipFree(h->dQ);
-  if (h->dLam) (void)hipFree(h->dLam);
-  if (h->dLim) (void)hipFree(h->dLim);
+  h->dev64.release();
+  h->dev32.release();
   if (h->ev_start) (void)hipEventDestroy(h->ev_start);
   if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -238,12 +309,11 @@ static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, 
   if (!h || !p || !o || !r) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: null argument");
   if (p->batch < 0) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: negative batch");
   if (p->batch == 0) return ACNQP_OK;
-  if (p->t_max < 1 || p->t_max > 32)
-    return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: t_max must be in [1, 32] for the resident kernel");
+  const int tmax_ok = h->NW == 4 ? 32 : 16;
+  if (p->t_max < 1 || p->t_max > tmax_ok)
+    return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: t_max must be in [1, 32] (N <= 64) or [1, 16] (N <= 256)");
   if (p->k_sessions < 1 || p->k_sessions > acnqp::kMaxK)
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: k_sessions must be in [1, 4]");
-  if ((long)h->Mc * p->t_max > (long)40 * 32)
-    return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: too many (row, period) pairs");
   if (!p->horizon || !p->lb || !p->ub || !p->q || !p->pdiag || !p->s_off || !p->s_len || !p->s_cap || !p->s_eq)
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: null problem array");
   if (h->has_peak && !p->peak) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: site has a peak row but peak is null");
@@ -265,18 +335,25 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   if (p->batch == 0) return ACNQP_OK;
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
-  acnqp::KernelArgs a;
-  a.B = p->batch; a.N = h->N; a.Tm = p->t_max; a.K = p->k_sessions;
-  a.Mg = h->Mg; a.M = h->M; a.Mc = h->Mc; a.cone = h->cone; a.has_peak = h->has_peak;
-  a.G = h->dG; a.Ghat = h->dGhat; a.Q = h->dQ; a.lam = h->dLam; a.limits = h->dLim;
+  SiteDev* d = &h->dev64;
+  if (o->precision == 32) {
+    d = &h->dev32;
+    if (!d->ready) {
+      rc = build_site_dev<float>(h, d);
+      if (rc != ACNQP_OK) return rc;
+    }
+  }
+  acnqp::TiledArgs a;
+  a.B = p->batch; a.N = h->N; a.Tm = p->t_max; a.K = p->k_sessions; a.NP = h->NP; a.MR = d->MR;
+  a.G = d->G; a.Ghat = d->Ghat; a.Q = d->Q; a.lam = d->lam; a.rowlim = d->rowlim; a.rowtype = d->rowtype;
   a.horizon = p->horizon; a.lb = p->lb; a.ub = p->ub; a.q = p->q; a.pdiag = p->pdiag;
-  a.s_off = p->s_off; a.s_len = p->s_len; a.s_cap = p->s_cap; a.s_eq = p->s_eq; a.peak = p->peak;
+  a.s_off = p->s_off; a.s_len = p->s_len; a.s_cap = p->s_cap; a.s_eq = p->s_eq; a.peak = h->has_peak ? p->peak : nullptr;
   a.x = r->x; a.status = r->status; a.iters = r->iters; a.pri = r->pri_res; a.dua = r->dua_res; a.obj = r->obj;
   a.eps_abs = o->eps_abs; a.eps_rel = o->eps_rel; a.rho0 = o->rho; a.sigma = o->sigma; a.alpha = o->alpha;
   a.adapt_tol = o->adapt_tol; a.reg_rel = o->reg_rel;
   a.max_iter = o->max_iter; a.check_every = o->check_every; a.adapt_every = o->adapt_every;
   HIP_TRY(hipEventRecord(h->ev_start, st));
-  hipError_t e = (o->precision == 32) ? launch_for_k<float>(a, st) : launch_for_k<double>(a, st);
+  hipError_t e = (o->precision == 32) ? launch_any<float>(a, h->NW, st) : launch_any<double>(a, h->NW, st);
   if (e != hipSuccess) return fail(ACNQP_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   HIP_TRY(hipEventRecord(h->ev_stop, st));
   h->timed = true;
@@ -362,5 +439,12 @@ int acnqp_solve_batch(acnqp_handle* h, const acnqp_problems* p, const acnqp_opti
   HIP_TRY(hipStreamSynchronize(st));
   return ACNQP_OK;
 }
+
+#ifdef ACNQP_STAMPS
+/* diagnostic build only: copy the per-phase cycle counters to the host */
+int acnqp_debug_read_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(acnqp::g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 }  // extern "C"

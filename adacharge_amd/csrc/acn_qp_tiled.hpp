@@ -1,0 +1,687 @@
+// MFMA-tiled batched MPC QP solver for gfx950: one workgroup per problem, one wavefront per
+// 16-EVSE tile, every cross-EVSE product as a chain of v_mfma_f64_16x16x4_f64 / _f32_16x16x4_f32.
+//
+// Device algorithm (restated on the CPU in oracle/admm_ref.py and oracle/admm_port.c):
+//   x~   = (a I + rho G'G)^-1 (sigma x - q + rho z1 - y1 + G'(rho z2 - y2))   per period
+//   z1   = Proj_B (alpha x~ + (1-alpha) z1 + y1/rho),   B = box /\ session energy rows
+//   z2   = Proj_C (alpha G x~ + (1-alpha) z2 + y2/rho), C = site rows (box / disc / peak)
+//   y    = rho (pre-projection point - projected point)
+// with (a I + rho G'G)^-1 = (I - Ghat' D Ghat)/a,  G G' = Q Lam Q',  Ghat = Q'G,  D = rho/(a + rho Lam).
+//
+// Layout.  Wave w, lane l = 16 g + t (g = l >> 4, t = l & 15) holds, for each column tile c and
+// register r, the entry (EVSE 16 w + rowof(g, r), period 16 c + t) of every N x T iterate: exactly
+// the C/D operand map of the 16x16x4 MFMA (rowof = g + 4 r for f64, 4 g + r for f32), so that
+//   * the wave's own r0 registers are the B operand of  P_w = Ghat[:, tile w] r0_w          (phase 1)
+//   * x~ tile = r0 + Ghat[:, tile w]' e^ comes out of the MFMA in the layout it is consumed in
+//   * an accumulator tile feeds the next chain as B operand (register s <-> k-step s), so
+//     w^ = Q'w, e^, h^ and G x~ = Q h^ never leave registers.
+// The site-row space (<= 48 rows) is tiny, so every wave keeps its own copy of (z2, y2, G x) and
+// updates it redundantly: the only exchange per iteration is the sum of the NW partial tiles P_w
+// through a double-buffered LDS slab, i.e. ONE workgroup barrier per iteration.  A session's
+// energy sum runs over the 16 lanes of a row: four DPP steps (quad_perm, quad_perm,
+// row_half_mirror, row_mirror), no LDS.  HBM is touched once per problem.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace acnqp {
+
+#ifdef ACNQP_STAMPS
+// diagnostic build only: cycles per phase, [block][wave][8]; never read by the kernel
+__device__ unsigned long long g_stamps[1024 * 16 * 8];
+#define STAMP(slot)                                                                    \
+  do {                                                                                 \
+    unsigned long long _t;                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)::"memory");         \
+    __builtin_amdgcn_sched_barrier(0);                                                 \
+    st_acc[slot] += _t - st_prev;                                                      \
+    st_prev = _t;                                                                      \
+  } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
+
+constexpr int kMaxK = 4;       // session slots per EVSE
+constexpr int kNumRed = 8;
+
+// row types of the (internally ordered) site rows
+constexpr int kRowFree = 0;    // padding row: no constraint
+constexpr int kRowBox = 1;     // z <= limit
+constexpr int kRowSocRe = 2;   // pairs with the next register (kRowSocIm): |(re, im)| <= limit
+constexpr int kRowSocIm = 3;
+constexpr int kRowPeak = 4;    // z <= peak[b][t]
+
+struct TiledArgs {
+  int B, N, Tm, K, NP, MR;     // NP = 16 * waves (padded EVSEs), MR = 16 * MT (padded site rows)
+  const void *G, *Ghat, *Q, *lam, *rowlim;   // [MR][NP], [MR][NP], [MR][MR], [MR], [MR]  (real)
+  const int32_t* rowtype;                     // [MR]
+  const int32_t* horizon;
+  const double *lb, *ub, *q, *pdiag;
+  const int32_t *s_off, *s_len;
+  const double* s_cap;
+  const uint8_t* s_eq;
+  const double* peak;
+  double* x;
+  int32_t *status, *iters;
+  double *pri, *dua, *obj;
+  double eps_abs, eps_rel, rho0, sigma, alpha, adapt_tol, reg_rel;
+  int max_iter, check_every, adapt_every;
+};
+
+template <typename real> struct Mfma;
+template <> struct Mfma<double> {
+  typedef double vec4 __attribute__((ext_vector_type(4)));
+  __host__ __device__ static constexpr int rowof(int g, int r) { return g + 4 * r; }
+  __device__ static inline vec4 mma(double a, double b, vec4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static constexpr double proj_tol = 1e-13;
+  static constexpr double big = 1e300;
+};
+template <> struct Mfma<float> {
+  typedef float vec4 __attribute__((ext_vector_type(4)));
+  __host__ __device__ static constexpr int rowof(int g, int r) { return 4 * g + r; }
+  __device__ static inline vec4 mma(float a, float b, vec4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static constexpr float proj_tol = 2e-6f;
+  static constexpr float big = 1e30f;
+};
+
+// ---- cross-lane helpers (DPP: plain VALU moves, no LDS crossbar) -------------------------------
+template <int CTRL> __device__ inline float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ inline double dpp_mov(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kRowHalfMirror = 0x141, kRowMirror = 0x140;
+
+// reductions over the 16 lanes of a DPP row (= the 16 periods of one EVSE); every lane gets the result
+template <typename T> __device__ inline T row_sum(T v) {
+  v += dpp_mov<kQuadXor1>(v);
+  v += dpp_mov<kQuadXor2>(v);
+  v += dpp_mov<kRowHalfMirror>(v);
+  v += dpp_mov<kRowMirror>(v);
+  return v;
+}
+template <typename T> __device__ inline T row_min(T v) {
+  v = fmin(v, dpp_mov<kQuadXor1>(v));
+  v = fmin(v, dpp_mov<kQuadXor2>(v));
+  v = fmin(v, dpp_mov<kRowHalfMirror>(v));
+  v = fmin(v, dpp_mov<kRowMirror>(v));
+  return v;
+}
+template <typename T> __device__ inline T row_max(T v) {
+  v = fmax(v, dpp_mov<kQuadXor1>(v));
+  v = fmax(v, dpp_mov<kQuadXor2>(v));
+  v = fmax(v, dpp_mov<kRowHalfMirror>(v));
+  v = fmax(v, dpp_mov<kRowMirror>(v));
+  return v;
+}
+template <typename T> __device__ inline T wave_max(T v) {
+  v = row_max<T>(v);
+  v = fmax(v, __shfl_xor(v, 16));
+  v = fmax(v, __shfl_xor(v, 32));
+  return v;
+}
+template <typename T> __device__ inline T wave_sum(T v) {
+  v = row_sum<T>(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+// 1 / sqrt(x): hardware estimate + two Newton steps (full precision for f64, cheaper than sqrt + div)
+__device__ inline double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - 0.5 * x * y * y);
+  y = y * (1.5 - 0.5 * x * y * y);
+  return y;
+}
+__device__ inline float rsqrt_nr(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  y = y * (1.5f - 0.5f * x * y * y);
+  return y;
+}
+
+// 1 / n for a small positive integer n (interior-period count of a session window)
+__device__ inline double rcp_small(int n) {
+  const double x = (double)n;
+  double y = __builtin_amdgcn_rcp(x);
+  y = y + y * (1.0 - x * y);   // one Newton step: full double precision for n <= 2^24
+  return y;
+}
+__device__ inline float rcp_smallf(int n) { return 1.0f / (float)n; }
+
+// LDS carve-up in units of `real`; shared by host (size) and device (offsets)
+struct TiledLds {
+  int pbuf, scap, slo, shi, red, total;
+  __host__ __device__ TiledLds(int NW, int MT, int CT, int NP, int K) {
+    int o = 0;
+    pbuf = o; o += 2 * NW * MT * CT * 4 * 64;   // double-buffered partial tiles
+    scap = o; o += K * NP;
+    slo = o;  o += K * NP;
+    shi = o;  o += K * NP;
+    red = o;  o += 16 * kNumRed + 8;
+    total = (o + 1) & ~1;
+  }
+};
+
+// Block-wide max of NV per-thread values (2 barriers); every thread gets the result.
+template <typename real, int NV>
+__device__ inline void block_max(real (&v)[NV], real* Red, int lane, int wave, int nw) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const real m = wave_max<real>(v[k]);
+    if (lane == 0) Red[wave * kNumRed + k] = m;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    real m = Red[k];
+    for (int wv = 1; wv < nw; ++wv) m = fmax(m, Red[wv * kNumRed + k]);
+    v[k] = m;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------
+template <typename real, int NW, int CT, int MT, int KS>
+__global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) {
+  using M = Mfma<real>;
+  using vec4 = typename M::vec4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  real* sm = reinterpret_cast<real*>(smem_raw);
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, t = lane & 15;
+  const int N = A.N, Tm = A.Tm, NP = A.NP, MR = A.MR;
+  const TiledLds L(NW, MT, CT, NP, A.K);
+  real* Pbuf = sm + L.pbuf;
+  real* Scap = sm + L.scap;
+  real* Slo = sm + L.slo;
+  real* Shi = sm + L.shi;
+  real* Red = sm + L.red;
+  const real* Gm = static_cast<const real*>(A.G);
+  const real* Gh = static_cast<const real*>(A.Ghat);
+  const real* Qm = static_cast<const real*>(A.Q);
+  const real* Lm = static_cast<const real*>(A.lam);
+  const real* RL = static_cast<const real*>(A.rowlim);
+
+  // ---- static MFMA A-operand fragments of this wave ------------------------------------
+  real aP[MT][4];        // Ghat[16m + t'][16w + rowof(g,s)]      (t' = lane & 15 is the A row)
+  real aX[MT][4];        // Ghat[16m + rowof(g,s)][16w + t']
+  real aQt[MT][MT][4];   // Q[16mi + rowof(g,s)][16mo + t']       (w^ = Q' w)
+  real aQ[MT][MT][4];    // Q[16mo + t'][16mi + rowof(g,s)]       (G x~ = Q h^)
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      aP[m][s] = Gh[(size_t)(16 * m + t) * NP + 16 * wave + M::rowof(g, s)];
+      aX[m][s] = Gh[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * wave + t];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        aQt[m][mi][s] = Qm[(size_t)(16 * mi + M::rowof(g, s)) * MR + 16 * m + t];
+        aQ[m][mi][s] = Qm[(size_t)(16 * m + t) * MR + 16 * mi + M::rowof(g, s)];
+      }
+    }
+  // site-row constants in C layout: row j = 16 m + rowof(g, r)
+  real lamv[MT][4], djv[MT][4], limv[MT][4];
+  int rtype[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * m + M::rowof(g, r);
+      lamv[m][r] = Lm[j];
+      limv[m][r] = RL[j];
+      rtype[m][r] = A.rowtype[j];
+    }
+
+  // ---- problem data -> registers (C layout) --------------------------------------------
+  real x[CT][4], z1[CT][4], y1[CT][4], qv[CT][4], lbv[CT][4], ubv[CT][4];
+  real pk[CT];
+  bool evact[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) evact[r] = 16 * wave + M::rowof(g, r) < N;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const int tt = 16 * c + t;
+    double pv = 1e300;
+    if (A.peak && tt < Tm) pv = A.peak[(size_t)b * Tm + tt];
+    pk[c] = pv < (double)M::big ? (real)pv : M::big;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ev = 16 * wave + M::rowof(g, r);
+      const bool ok = evact[r] && tt < Tm;
+      const size_t idx = ((size_t)b * N + (ok ? ev : 0)) * Tm + (ok ? tt : 0);
+      lbv[c][r] = ok ? (real)A.lb[idx] : (real)0;
+      ubv[c][r] = ok ? (real)A.ub[idx] : (real)0;
+      qv[c][r] = ok ? (real)A.q[idx] : (real)0;
+      if (ubv[c][r] < lbv[c][r]) ubv[c][r] = lbv[c][r];
+      x[c][r] = 0; z1[c][r] = 0; y1[c][r] = 0;
+    }
+  }
+  const bool eq = A.s_eq[b] != 0;
+  unsigned wmask[KS];          // bit (4 c + r): period 16c+t lies in slot k's window on EVSE(r)
+  unsigned hasm[KS];           // bit r: EVSE(r) has a session in slot k
+  real mu[KS][4];
+  int smode[KS][4];            // 0: root-find each iteration, 2: pinned at ub, 3: pinned at lb
+  bool empty_set = false;
+#pragma unroll
+  for (int k = 0; k < KS; ++k) {
+    wmask[k] = 0; hasm[k] = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mu[k][r] = 0; smode[k][r] = 0; }
+    if (k < A.K) {   // block-uniform
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ev = 16 * wave + M::rowof(g, r);
+        const size_t sidx = ((size_t)b * A.K + k) * N + (evact[r] ? ev : 0);
+        const int off = evact[r] ? A.s_off[sidx] : 0;
+        const int len = evact[r] ? A.s_len[sidx] : 0;
+        real sl = 0, su = 0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const int tt = 16 * c + t;
+          if (tt >= off && tt < off + len && tt < Tm) { wmask[k] |= 1u << (4 * c + r); sl += lbv[c][r]; su += ubv[c][r]; }
+        }
+        sl = row_sum<real>(sl);
+        su = row_sum<real>(su);
+        const real cap = evact[r] ? (real)A.s_cap[sidx] : (real)0;
+        if (len > 0) {
+          hasm[k] |= 1u << r;
+          const real slack = (real)64 * M::proj_tol * fmax((real)1, fabs(cap));
+          if (sl > cap + slack) empty_set = true;
+          if (eq && su < cap - slack) empty_set = true;
+          if (eq && cap >= su) smode[k][r] = 2;
+          else if (cap <= sl) smode[k][r] = 3;
+        }
+        if (t == 0 && evact[r]) { Scap[k * NP + ev] = cap; Slo[k * NP + ev] = sl; Shi[k * NP + ev] = su; }
+      }
+    }
+  }
+
+  const real pd_user = (real)A.pdiag[b];
+  const real sigma = (real)A.sigma, alpha = (real)A.alpha;
+  real rho = (real)A.rho0;
+  real qnorm, pd;
+  {
+    real f[3];
+    f[0] = empty_set ? (real)1 : (real)0;
+    f[1] = 0; f[2] = 0;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { f[1] = fmax(f[1], fabs(qv[c][r])); f[2] = fmax(f[2], ubv[c][r]); }
+    block_max<real, 3>(f, Red, lane, wave, NW);
+    qnorm = f[1];
+    pd = pd_user;
+    if (f[2] > 0) pd = fmax(pd_user, (real)A.reg_rel * qnorm / f[2]);   // scale-free Tikhonov floor
+    if (f[0] > 0) {   // a session cannot meet its energy row inside its own bounds
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int tt = 16 * c + t, ev = 16 * wave + M::rowof(g, r);
+          if (evact[r] && tt < Tm) A.x[((size_t)b * N + ev) * Tm + tt] = 0;
+        }
+      if (tid == 0) {
+        A.status[b] = 4; A.iters[b] = 0;
+        A.pri[b] = (double)M::big; A.dua[b] = (double)M::big; A.obj[b] = 0;
+      }
+      return;
+    }
+  }
+
+  // site-row state, replicated in every wave (identical instruction stream => identical bits)
+  real z2[MT][CT][4], y2[MT][CT][4], gx[MT][CT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { z2[m][c][r] = 0; y2[m][c][r] = 0; gx[m][c][r] = 0; }
+
+  real a = sigma + pd + rho, inv_a = (real)1 / a, inv_rho = (real)1 / rho;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) djv[m][r] = rho / (a + rho * lamv[m][r]);
+
+  int status = 2, it = 0;
+  real pri = M::big, dua = M::big;
+  bool done = false;
+  const real ptol_scale = M::proj_tol;
+
+#ifdef ACNQP_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
+  while (!done) {
+    ++it;
+    real* Pw = Pbuf + (size_t)(it & 1) * NW * MT * CT * 256;
+
+    // ---- w^ = Q'(rho z2 - y2) and r0 = sigma x - q + rho z1 - y1;  P_w = Ghat_w r0 --------
+    vec4 wh[MT][CT], r0[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) r0[c][r] = sigma * x[c][r] - qv[c][r] + rho * z1[c][r] - y1[c][r];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        vec4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = M::mma(aP[m][s], r0[c][s], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pw[(((wave * MT + m) * CT + c) * 4 + r) * 64 + lane] = acc[r];
+      }
+#pragma unroll
+      for (int mo = 0; mo < MT; ++mo) {
+        vec4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) acc = M::mma(aQt[mo][mi][s], rho * z2[mi][c][s] - y2[mi][c][s], acc);
+        wh[mo][c] = acc;
+      }
+    }
+    STAMP(0);   // r0, P_w, w^ (8 MFMA)
+    __syncthreads();   // the one barrier of the iteration: all partial tiles are in LDS
+    STAMP(1);   // barrier
+
+    // ---- g0 = sum_w P_w;  e^ = w^ - D (g0 + Lam w^);  h^ = (g0 + Lam e^)/a --------------------
+    vec4 eh[MT][CT], hh[MT][CT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          real g0 = 0;
+#pragma unroll
+          for (int wv = 0; wv < NW; ++wv) g0 += Pw[(((wv * MT + m) * CT + c) * 4 + r) * 64 + lane];
+          const real w_ = wh[m][c][r];
+          const real e_ = w_ - djv[m][r] * (g0 + lamv[m][r] * w_);
+          eh[m][c][r] = e_;
+          hh[m][c][r] = (g0 + lamv[m][r] * e_) * inv_a;
+        }
+
+    STAMP(2);   // partial-tile sum, e^, h^
+    // ---- x~ tile = (r0 + Ghat_w' e^)/a, relaxation, clip ------------------------------------
+    real zh[CT][4];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      vec4 acc = r0[c];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = M::mma(aX[m][s], eh[m][c][s], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const real xn = acc[r] * inv_a;
+        zh[c][r] = alpha * xn + ((real)1 - alpha) * z1[c][r] + y1[c][r] * inv_rho;
+        x[c][r] = alpha * xn + ((real)1 - alpha) * x[c][r];
+        z1[c][r] = fmin(fmax(zh[c][r], lbv[c][r]), ubv[c][r]);
+      }
+    }
+
+    STAMP(3);   // x~ MFMA + clip
+    // ---- energy rows: exact water-filling per (EVSE register, session slot) ----------------------
+    // z = clip(zh - m) with g(m) = sum_t clip(zh_t - m) = cap.  Newton on the piecewise-linear g from
+    // the previous iteration's m.  Which periods sit at a bound is a pair of wave-wide compare masks
+    // (SGPRs): the interior count is a popcount of the row's 16 mask bits and a step is exact as soon
+    // as it leaves both masks unchanged on the row -- in steady state ONE 16-lane f64 reduction per
+    // register and iteration, everything else branch-free VALU/SALU.  Bisection only as a fallback.
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      if (k < A.K) {   // block-uniform
+        real cap[4], m_[4], lo[4], hi[4], tolv[4];
+        bool need[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ev = 16 * wave + M::rowof(g, r);
+          const bool has = (hasm[k] >> r) & 1u;
+          cap[r] = has ? Scap[k * NP + ev] : (real)0;
+          tolv[r] = ptol_scale * fmax((real)1, fabs(cap[r]));
+          need[r] = has && smode[k][r] == 0;
+          m_[r] = mu[k][r];
+          lo[r] = eq ? -M::big : (real)-1;   // inequality: m >= 0, so (-1, .) brackets m = 0
+          hi[r] = M::big;
+        }
+        int guard = 0;
+        while (__any(need[0] | need[1] | need[2] | need[3])) {
+          ++guard;
+          real gs[4];
+          int nfi[4];
+          unsigned long long mub[4][CT], mlb[4][CT];   // (v < ub), (v > lb) lane masks at m
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            real gl = 0;
+            int nl = 0;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+              const bool inw = (wmask[k] >> (4 * c + r)) & 1u;
+              const real v = zh[c][r] - m_[r];
+              const bool bu = v < ubv[c][r], bl = v > lbv[c][r];
+              gl += inw ? fmin(fmax(v, lbv[c][r]), ubv[c][r]) : (real)0;
+              mub[r][c] = __ballot(bu && inw);
+              mlb[r][c] = __ballot(bl && inw);
+              const unsigned inner = (unsigned)(((mub[r][c] & mlb[r][c]) >> (16 * g)) & 0xFFFFull);
+              nl += __popc(inner);
+            }
+            gs[r] = row_sum<real>(gl);
+            nfi[r] = nl;
+          }
+          real mn[4];
+          bool step[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const real d = gs[r] - cap[r];
+            const bool fin = fabs(d) <= tolv[r] || (!eq && m_[r] <= (real)0 && d <= (real)0) || guard > 120;
+            need[r] = need[r] && !fin;
+            lo[r] = (need[r] && d > 0) ? m_[r] : lo[r];
+            hi[r] = (need[r] && !(d > 0)) ? m_[r] : hi[r];
+          }
+          // flat piece with an open bracket (rare): fetch the true bracket ends so the fallback bisects
+          bool open_any = false;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) open_any |= need[r] && nfi[r] == 0 && !(lo[r] > -M::big && hi[r] < M::big);
+          if (__any(open_any)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              real lo_l = M::big, hi_l = -M::big;
+#pragma unroll
+              for (int c = 0; c < CT; ++c)
+                if ((wmask[k] >> (4 * c + r)) & 1u) {
+                  lo_l = fmin(lo_l, zh[c][r] - ubv[c][r]);
+                  hi_l = fmax(hi_l, zh[c][r] - lbv[c][r]);
+                }
+              const real lo0 = row_min<real>(lo_l), hi0 = row_max<real>(hi_l);
+              const bool open = need[r] && nfi[r] == 0 && !(lo[r] > -M::big && hi[r] < M::big);
+              lo[r] = open ? fmax(lo[r], lo0) : lo[r];
+              hi[r] = open ? fmin(hi[r], hi0) : hi[r];
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const real d = gs[r] - cap[r];
+            const bool bracketed = lo[r] > -M::big && hi[r] < M::big;
+            const real mid = (real)0.5 * (lo[r] + hi[r]);
+            bool newton = nfi[r] > 0;
+            real cand = newton ? m_[r] + d * rcp_small(nfi[r]) : (bracketed ? mid : fmin(fmax(m_[r] + d, lo[r]), hi[r]));
+            if (!eq && cand < (real)0) { cand = 0; newton = false; }     // inequality: multiplier >= 0
+            const bool inside = cand > lo[r] && cand < hi[r];
+            real alt = bracketed ? mid : fmin(fmax(cand, lo[r]), hi[r]);
+            if (!eq && alt < (real)0) alt = 0;
+            cand = inside ? cand : alt;
+            newton = newton && inside;
+            mn[r] = need[r] ? cand : m_[r];
+            step[r] = need[r] && newton;
+          }
+          // a Newton step that leaves both compare masks unchanged on the row is exact (g is linear
+          // between m and mn)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            unsigned long long changed = 0;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+              const bool inw = (wmask[k] >> (4 * c + r)) & 1u;
+              const real v = zh[c][r] - mn[r];
+              changed |= (__ballot(v < ubv[c][r] && inw) ^ mub[r][c]) | (__ballot(v > lbv[c][r] && inw) ^ mlb[r][c]);
+            }
+            const bool row_same = ((changed >> (16 * g)) & 0xFFFFull) == 0ull;
+            m_[r] = mn[r];
+            need[r] = need[r] && !(step[r] && row_same);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool has = (hasm[k] >> r) & 1u;
+          if (has && smode[k][r] == 0) mu[k][r] = m_[r];
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+            if ((wmask[k] >> (4 * c + r)) & 1u) {
+              if (smode[k][r] == 0) z1[c][r] = fmin(fmax(zh[c][r] - m_[r], lbv[c][r]), ubv[c][r]);
+              else if (smode[k][r] == 2) z1[c][r] = ubv[c][r];
+              else z1[c][r] = lbv[c][r];
+            }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y1[c][r] = rho * (zh[c][r] - z1[c][r]);
+
+    STAMP(4);   // water-filling + y1
+    // ---- site rows: G x~ = Q h^, relaxation, projection onto C, y2 (every wave, redundantly) ---
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+#pragma unroll
+      for (int mo = 0; mo < MT; ++mo) {
+        vec4 zt = {0, 0, 0, 0};
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) zt = M::mma(aQ[mo][mi][s], hh[mi][c][s], zt);
+        real zhr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gx[mo][c][r] = alpha * zt[r] + ((real)1 - alpha) * gx[mo][c][r];
+          zhr[r] = alpha * zt[r] + ((real)1 - alpha) * z2[mo][c][r] + y2[mo][c][r] * inv_rho;
+        }
+        real scl[2] = {(real)1, (real)1};   // radial clip factor of the register pairs (0,1), (2,3)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          if (rtype[mo][2 * pr] == kRowSocRe) {
+            const real re = zhr[2 * pr], im = zhr[2 * pr + 1], lim = limv[mo][2 * pr];
+            const real n2 = re * re + im * im;
+            if (n2 > lim * lim) scl[pr] = lim * rsqrt_nr(n2);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          real zn = zhr[r];
+          const int ty = rtype[mo][r];
+          if (ty == kRowBox) zn = fmin(zhr[r], limv[mo][r]);
+          else if (ty == kRowPeak) zn = fmin(zhr[r], pk[c]);
+          else if (ty == kRowSocRe || ty == kRowSocIm) zn = zhr[r] * scl[r >> 1];
+          y2[mo][c][r] = rho * (zhr[r] - zn);
+          z2[mo][c][r] = zn;
+        }
+      }
+    }
+    STAMP(5);   // site rows
+    // ---- residuals, termination, rho adaptation (block-uniform decisions) -----------------
+    const bool check = (it % A.check_every == 0) || it >= A.max_iter;
+    if (check) {
+      real v[6];   // pri, dua, |Ax| |z|, -, |Px|, |A'y|
+      v[0] = v[1] = v[2] = v[3] = v[4] = v[5] = 0;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        vec4 gty = {0, 0, 0, 0};   // (G' y2) tile of this wave
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            gty = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * wave + t], y2[m][c][s], gty);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[0] = fmax(v[0], fabs(x[c][r] - z1[c][r]));
+          v[1] = fmax(v[1], fabs(pd * x[c][r] + qv[c][r] + y1[c][r] + gty[r]));
+          v[2] = fmax(v[2], fmax(fabs(x[c][r]), fabs(z1[c][r])));
+          v[4] = fmax(v[4], fabs(pd * x[c][r]));
+          v[5] = fmax(v[5], fabs(y1[c][r] + gty[r]));
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[0] = fmax(v[0], fabs(gx[m][c][r] - z2[m][c][r]));
+            v[2] = fmax(v[2], fmax(fabs(gx[m][c][r]), fabs(z2[m][c][r])));
+          }
+      }
+      block_max<real, 6>(v, Red, lane, wave, NW);
+      pri = v[0];
+      dua = v[1];
+      const real npri = v[2];
+      const real ndua = fmax(fmax(v[4], v[5]), qnorm);
+      const real eps_p = (real)A.eps_abs + (real)A.eps_rel * npri;
+      const real eps_d = (real)A.eps_abs + (real)A.eps_rel * ndua;
+      if (pri <= eps_p && dua <= eps_d) { status = 1; done = true; }
+      else if (it >= A.max_iter) { done = true; }
+      else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
+        const real sp = pri / fmax(npri, (real)1e-12);
+        const real sd = dua / fmax(ndua, (real)1e-12);
+        const real ratio = sqrt(sp / fmax(sd, (real)1e-30));
+        if (ratio > (real)A.adapt_tol || ratio < (real)1 / (real)A.adapt_tol) {
+          rho = fmin(fmax(rho * ratio, (real)1e-6), (real)1e6);
+          a = sigma + pd + rho;
+          inv_a = (real)1 / a;
+          inv_rho = (real)1 / rho;
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) djv[m][r] = rho / (a + rho * lamv[m][r]);
+        }
+      }
+    }
+    STAMP(6);   // residual check (amortised)
+  }
+#ifdef ACNQP_STAMPS
+  if (lane == 0 && b < 1024)
+    for (int k = 0; k < 8; ++k) g_stamps[(b * 16 + wave) * 8 + k] = st_acc[k];
+#endif
+
+  // ---- results: the feasible iterate z1 is the schedule ------------------------------------
+  real ol = 0;
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tt = 16 * c + t, ev = 16 * wave + M::rowof(g, r);
+      if (evact[r] && tt < Tm) {
+        A.x[((size_t)b * N + ev) * Tm + tt] = (double)z1[c][r];
+        ol += ((real)0.5 * pd_user * z1[c][r] + qv[c][r]) * z1[c][r];
+      }
+    }
+  ol = wave_sum<real>(ol);
+  __syncthreads();
+  if (lane == 0) Red[wave * kNumRed] = ol;
+  __syncthreads();
+  if (tid == 0) {
+    real o = 0;
+    for (int wv = 0; wv < NW; ++wv) o += Red[wv * kNumRed];
+    A.status[b] = status;
+    A.iters[b] = it;
+    A.pri[b] = (double)pri;
+    A.dua[b] = (double)dua;
+    A.obj[b] = (double)o;
+  }
+}
+
+}  // namespace acnqp
