@@ -9,6 +9,7 @@
 
 #include "acn_qp.h"
 #include "acn_qp_tiled.hpp"
+#include "acn_qp_general.hpp"
 
 namespace {
 
@@ -112,6 +113,7 @@ struct acnqp_handle {
   bool timed = false;
   hipStream_t stream = nullptr;   // used by the host-buffer entry point
   DevBuf in, out;                 // staging for the host-buffer entry point
+  DevBuf work;                    // workspace of the general-shape kernel
 };
 
 namespace {
@@ -243,7 +245,7 @@ void acnqp_default_options(acnqp_options* o) {
   o->sigma = 1e-6;
   o->alpha = 1.6;
   o->adapt_tol = 5.0;
-  o->reg_rel = 5e-3;
+  o->reg_rel = 0.06;
   o->precision = 64;
   o->reserved = 0;
 }
@@ -301,6 +303,7 @@ void acnqp_destroy(acnqp_handle* h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   h->in.release();
   h->out.release();
+  h->work.release();
   delete h;
 }
 
@@ -309,9 +312,8 @@ static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, 
   if (!h || !p || !o || !r) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: null argument");
   if (p->batch < 0) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: negative batch");
   if (p->batch == 0) return ACNQP_OK;
-  const int tmax_ok = h->NW == 4 ? 32 : 16;
-  if (p->t_max < 1 || p->t_max > tmax_ok)
-    return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: t_max must be in [1, 32] (N <= 64) or [1, 16] (N <= 256)");
+  if (p->t_max < 1 || p->t_max > 4096)
+    return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: t_max must be in [1, 4096]");
   if (p->k_sessions < 1 || p->k_sessions > acnqp::kMaxK)
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: k_sessions must be in [1, 4]");
   if (!p->horizon || !p->lb || !p->ub || !p->q || !p->pdiag || !p->s_off || !p->s_len || !p->s_cap || !p->s_eq)
@@ -352,8 +354,29 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.eps_abs = o->eps_abs; a.eps_rel = o->eps_rel; a.rho0 = o->rho; a.sigma = o->sigma; a.alpha = o->alpha;
   a.adapt_tol = o->adapt_tol; a.reg_rel = o->reg_rel;
   a.max_iter = o->max_iter; a.check_every = o->check_every; a.adapt_every = o->adapt_every;
+  const bool tiled = p->t_max <= (h->NW == 4 ? 32 : 16);
+  acnqp::GeneralArgs ga;
+  if (!tiled) {
+    // general-shape fallback: state streamed through a global workspace (not graph-capturable: it may allocate)
+    const size_t rsz = o->precision == 32 ? 4 : 8;
+    const long long n = (long long)h->N * p->t_max, mt = (long long)d->MR * p->t_max;
+    ga.ws_per_problem = 6 * n + 7 * mt + 3LL * p->k_sessions * h->N + 8;
+    HIP_TRY(h->work.reserve((size_t)ga.ws_per_problem * p->batch * rsz));
+    ga.work = h->work.p;
+    ga.pair_stride = o->precision == 32 ? 1 : 4;
+    ga.t = a;
+  }
   HIP_TRY(hipEventRecord(h->ev_start, st));
-  hipError_t e = (o->precision == 32) ? launch_any<float>(a, h->NW, st) : launch_any<double>(a, h->NW, st);
+  hipError_t e = hipSuccess;
+  if (tiled) {
+    e = (o->precision == 32) ? launch_any<float>(a, h->NW, st) : launch_any<double>(a, h->NW, st);
+  } else {
+    if (o->precision == 32)
+      hipLaunchKernelGGL(acnqp::admm_general_kernel<float>, dim3(a.B), dim3(acnqp::kGenThreads), 0, st, ga);
+    else
+      hipLaunchKernelGGL(acnqp::admm_general_kernel<double>, dim3(a.B), dim3(acnqp::kGenThreads), 0, st, ga);
+    e = hipGetLastError();
+  }
   if (e != hipSuccess) return fail(ACNQP_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   HIP_TRY(hipEventRecord(h->ev_stop, st));
   h->timed = true;

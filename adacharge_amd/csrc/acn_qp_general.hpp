@@ -1,0 +1,259 @@
+// General-shape fallback of the batched MPC QP solver: any horizon, N <= 256, state streamed
+// through a per-problem global-memory workspace (L2 resident) instead of registers.
+//
+// Same ADMM as acn_qp_tiled.hpp (see there for the algorithm); this kernel trades speed for
+// generality so that the reference's large scenarios (N = 54, T = 144 stress tests, t_aco.py:286-466,
+// and the offline algorithm, adacharge.py:196-294) run through the same C ABI.  One 256-thread
+// workgroup per problem; plain loops; one thread per session for the water-filling.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "acn_qp_tiled.hpp"
+
+namespace acnqp {
+
+constexpr int kGenThreads = 256;
+
+struct GeneralArgs {
+  TiledArgs t;          // same site / problem / result / option fields as the tiled kernel
+  void* work;           // [B][ws_per_problem] reals
+  long long ws_per_problem;
+  int pair_stride;      // register distance of a SOC pair in the internal row order (4: f64, 1: f32)
+};
+
+template <typename real>
+__device__ inline real block_reduce_max(real v, real* red, int tid) {
+  v = wave_max<real>(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  real m = red[0];
+  for (int w = 1; w < kGenThreads / 64; ++w) m = fmax(m, red[w]);
+  return m;
+}
+
+template <typename real>
+__global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const GeneralArgs GA) {
+  using M = Mfma<real>;
+  const TiledArgs& A = GA.t;
+  __shared__ real red[8];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int N = A.N, T = A.Tm, NP = A.NP, MR = A.MR, K = A.K;
+  const int n = N * T, mt = MR * T;
+  real* W0 = static_cast<real*>(GA.work) + (size_t)b * GA.ws_per_problem;
+  real *x = W0, *z1 = x + n, *y1 = z1 + n, *r0 = y1 + n, *zh = r0 + n, *ub = zh + n;
+  real *z2 = ub + n, *y2 = z2 + mt, *gx = y2 + mt, *w = gx + mt, *eh = w + mt, *hh = eh + mt, *zh2 = hh + mt;
+  real* mu = zh2 + mt;             // [K*N]
+  real* slo = mu + K * N;
+  real* shi = slo + K * N;
+  const real* Gm = static_cast<const real*>(A.G);
+  const real* Gh = static_cast<const real*>(A.Ghat);
+  const real* Qm = static_cast<const real*>(A.Q);
+  const real* Lm = static_cast<const real*>(A.lam);
+  const real* RL = static_cast<const real*>(A.rowlim);
+  const double* lbg = A.lb + (size_t)b * n;
+  const double* ubg = A.ub + (size_t)b * n;
+  const double* qg = A.q + (size_t)b * n;
+  const bool eq = A.s_eq[b] != 0;
+
+  real qn = 0, um = 0;
+  for (int k = tid; k < n; k += kGenThreads) {
+    const real l = (real)lbg[k];
+    real u = (real)ubg[k];
+    if (u < l) u = l;
+    ub[k] = u;
+    x[k] = 0; z1[k] = 0; y1[k] = 0;
+    r0[k] = -(real)qg[k];
+    qn = fmax(qn, fabs((real)qg[k]));
+    um = fmax(um, u);
+  }
+  for (int k = tid; k < mt; k += kGenThreads) { z2[k] = 0; y2[k] = 0; gx[k] = 0; w[k] = 0; }
+  real bad = 0;
+  for (int s = tid; s < K * N; s += kGenThreads) {
+    const int i = s % N;
+    const size_t sidx = (size_t)b * K * N + s;
+    const int off = A.s_off[sidx], len = A.s_len[sidx];
+    real a = 0, c = 0;
+    for (int t = off; t < off + len && t < T; ++t) {
+      const real l = (real)lbg[i * T + t];
+      real u = (real)ubg[i * T + t];
+      if (u < l) u = l;
+      a += l; c += u;
+    }
+    mu[s] = 0; slo[s] = a; shi[s] = c;
+    if (len > 0) {
+      const real cap = (real)A.s_cap[sidx];
+      const real slack = (real)64 * M::proj_tol * fmax((real)1, fabs(cap));
+      if (a > cap + slack || (eq && c < cap - slack)) bad = 1;
+    }
+  }
+  __syncthreads();
+  const real qnorm = block_reduce_max<real>(qn, red, tid);
+  const real ubmax = block_reduce_max<real>(um, red, tid);
+  const real anybad = block_reduce_max<real>(bad, red, tid);
+  const real pd_user = (real)A.pdiag[b];
+  real pd = pd_user;
+  if (ubmax > 0) pd = fmax(pd_user, (real)A.reg_rel * qnorm / (ubmax * (real)max(1, A.horizon[b])));
+  if (anybad > 0) {
+    for (int k = tid; k < n; k += kGenThreads) A.x[(size_t)b * n + k] = 0;
+    if (tid == 0) { A.status[b] = 4; A.iters[b] = 0; A.pri[b] = (double)M::big; A.dua[b] = (double)M::big; A.obj[b] = 0; }
+    return;
+  }
+  const real sigma = (real)A.sigma, alpha = (real)A.alpha;
+  real rho = (real)A.rho0;
+  int status = 2, it = 0;
+  real pri = M::big, dua = M::big;
+  bool done = false;
+  while (!done) {
+    ++it;
+    const real a = sigma + pd + rho, inv_a = (real)1 / a, inv_rho = (real)1 / rho;
+    // ---- eigen space: e^ and h^ -------------------------------------------------------------
+    for (int k = tid; k < mt; k += kGenThreads) {
+      const int j = k / T, t = k - j * T;
+      real acc = 0, whj = 0;
+      for (int i = 0; i < N; ++i) acc += Gh[(size_t)j * NP + i] * r0[i * T + t];
+      for (int r = 0; r < MR; ++r) whj += Qm[(size_t)r * MR + j] * w[r * T + t];
+      const real lj = Lm[j];
+      const real e_ = whj - (rho / (a + rho * lj)) * (acc + lj * whj);
+      eh[k] = e_;
+      hh[k] = (acc + lj * e_) * inv_a;
+    }
+    __syncthreads();
+    // ---- x~, relaxation, box clip;  G x~, relaxation of the site rows ---------------------------
+    for (int k = tid; k < n; k += kGenThreads) {
+      const int i = k / T, t = k - i * T;
+      real v = r0[k];
+      for (int j = 0; j < MR; ++j) v += Gh[(size_t)j * NP + i] * eh[j * T + t];
+      const real xn = v * inv_a;
+      const real zz = alpha * xn + ((real)1 - alpha) * z1[k] + y1[k] * inv_rho;
+      zh[k] = zz;
+      x[k] = alpha * xn + ((real)1 - alpha) * x[k];
+      z1[k] = fmin(fmax(zz, (real)lbg[k]), ub[k]);
+    }
+    for (int k = tid; k < mt; k += kGenThreads) {
+      const int r = k / T, t = k - r * T;
+      real zt = 0;
+      for (int j = 0; j < MR; ++j) zt += Qm[(size_t)r * MR + j] * hh[j * T + t];
+      gx[k] = alpha * zt + ((real)1 - alpha) * gx[k];
+      zh2[k] = alpha * zt + ((real)1 - alpha) * z2[k] + y2[k] * inv_rho;
+    }
+    __syncthreads();
+    // ---- energy rows: one thread per session, safeguarded Newton on g(m) = sum clip(zh - m) -------
+    for (int s = tid; s < K * N; s += kGenThreads) {
+      const int i = s % N;
+      const size_t sidx = (size_t)b * K * N + s;
+      const int off = A.s_off[sidx];
+      int len = A.s_len[sidx];
+      if (off + len > T) len = T - off;
+      if (len <= 0) continue;
+      const real cap = (real)A.s_cap[sidx];
+      const real* v = zh + i * T + off;
+      const double* lb_ = lbg + i * T + off;
+      const real* ub_ = ub + i * T + off;
+      real* z = z1 + i * T + off;
+      real s0 = 0, lo = M::big, hi = -M::big;
+      for (int t = 0; t < len; ++t) {
+        s0 += z[t];
+        lo = fmin(lo, v[t] - ub_[t]);
+        hi = fmax(hi, v[t] - (real)lb_[t]);
+      }
+      const real tol = M::proj_tol * fmax((real)1, fabs(cap));
+      const bool need = eq ? fabs(s0 - cap) > tol : s0 > cap + tol;
+      if (!need) { mu[s] = 0; continue; }
+      if (eq && cap >= shi[s]) { for (int t = 0; t < len; ++t) z[t] = ub_[t]; mu[s] = 0; continue; }
+      if (cap <= slo[s]) { for (int t = 0; t < len; ++t) z[t] = (real)lb_[t]; mu[s] = 0; continue; }
+      if (!eq && lo < 0) lo = 0;
+      real m = fmin(fmax(mu[s], lo), hi);
+      for (int guard = 0; guard <= 100; ++guard) {
+        real g = 0, nf = 0;
+        for (int t = 0; t < len; ++t) {
+          const real u = v[t] - m;
+          g += fmin(fmax(u, (real)lb_[t]), ub_[t]);
+          nf += (u > (real)lb_[t] && u < ub_[t]) ? (real)1 : (real)0;
+        }
+        const real d = g - cap;
+        if (fabs(d) <= tol) break;
+        if (d > 0) lo = m; else hi = m;
+        real mn = nf > 0 ? m + d / nf : (real)0.5 * (lo + hi);
+        if (!(mn > lo && mn < hi)) mn = (real)0.5 * (lo + hi);
+        m = mn;
+      }
+      mu[s] = m;
+      for (int t = 0; t < len; ++t) z[t] = fmin(fmax(v[t] - m, (real)lb_[t]), ub_[t]);
+    }
+    // ---- site rows: projection (internal row order: a SOC pair is `pair_stride` rows apart) -------
+    for (int k = tid; k < mt; k += kGenThreads) {
+      const int r = k / T, t = k - r * T;
+      const int ty = A.rowtype[r];
+      real zn = zh2[k];
+      if (ty == kRowBox) zn = fmin(zn, RL[r]);
+      else if (ty == kRowPeak) {
+        const double pv = A.peak ? A.peak[(size_t)b * T + t] : 1e300;
+        zn = fmin(zn, pv < (double)M::big ? (real)pv : M::big);
+      } else if (ty == kRowSocRe || ty == kRowSocIm) {
+        const int rr = ty == kRowSocRe ? r : r - GA.pair_stride;
+        const real re = zh2[rr * T + t], im = zh2[(rr + GA.pair_stride) * T + t];
+        const real n2 = re * re + im * im, lim = RL[rr];
+        if (n2 > lim * lim) zn = zn * (lim / sqrt(n2));
+      }
+      y2[k] = rho * (zh2[k] - zn);
+      z2[k] = zn;
+    }
+    __syncthreads();
+    for (int k = tid; k < n; k += kGenThreads) y1[k] = rho * (zh[k] - z1[k]);
+    // ---- residuals, termination, rho adaptation ------------------------------------------------
+    const bool check = (it % A.check_every == 0) || it >= A.max_iter;
+    if (check) {
+      real v0 = 0, v1 = 0, v2 = 0, v4 = 0, v5 = 0;
+      for (int k = tid; k < n; k += kGenThreads) {
+        const int i = k / T, t = k - i * T;
+        real gty = 0;
+        for (int j = 0; j < MR; ++j) gty += Gm[(size_t)j * NP + i] * y2[j * T + t];
+        const real yk = rho * (zh[k] - z1[k]);
+        v0 = fmax(v0, fabs(x[k] - z1[k]));
+        v1 = fmax(v1, fabs(pd * x[k] + (real)qg[k] + yk + gty));
+        v2 = fmax(v2, fmax(fabs(x[k]), fabs(z1[k])));
+        v4 = fmax(v4, fabs(pd * x[k]));
+        v5 = fmax(v5, fabs(yk + gty));
+      }
+      for (int k = tid; k < mt; k += kGenThreads) {
+        v0 = fmax(v0, fabs(gx[k] - z2[k]));
+        v2 = fmax(v2, fmax(fabs(gx[k]), fabs(z2[k])));
+      }
+      pri = block_reduce_max<real>(v0, red, tid);
+      dua = block_reduce_max<real>(v1, red, tid);
+      const real npri = block_reduce_max<real>(v2, red, tid);
+      const real ndua = fmax(fmax(block_reduce_max<real>(v4, red, tid), block_reduce_max<real>(v5, red, tid)), qnorm);
+      if (pri <= (real)A.eps_abs + (real)A.eps_rel * npri && dua <= (real)A.eps_abs + (real)A.eps_rel * ndua) { status = 1; done = true; }
+      else if (it >= A.max_iter) done = true;
+      else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
+        const real sp = pri / fmax(npri, (real)1e-12), sd = dua / fmax(ndua, (real)1e-12);
+        const real ratio = sqrt(sp / fmax(sd, (real)1e-30));
+        if (ratio > (real)A.adapt_tol || ratio < (real)1 / (real)A.adapt_tol) rho = fmin(fmax(rho * ratio, (real)1e-6), (real)1e6);
+      }
+    }
+    if (!done) {
+      __syncthreads();
+      for (int k = tid; k < n; k += kGenThreads) r0[k] = sigma * x[k] - (real)qg[k] + rho * z1[k] - y1[k];
+      for (int k = tid; k < mt; k += kGenThreads) w[k] = rho * z2[k] - y2[k];
+      __syncthreads();
+    }
+  }
+  real ol = 0;
+  for (int k = tid; k < n; k += kGenThreads) {
+    A.x[(size_t)b * n + k] = (double)z1[k];
+    ol += ((real)0.5 * pd_user * z1[k] + (real)qg[k]) * z1[k];
+  }
+  ol = wave_sum<real>(ol);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = ol;
+  __syncthreads();
+  if (tid == 0) {
+    real o = 0;
+    for (int wv = 0; wv < kGenThreads / 64; ++wv) o += red[wv];
+    A.status[b] = status; A.iters[b] = it; A.pri[b] = (double)pri; A.dua[b] = (double)dua; A.obj[b] = (double)o;
+  }
+}
+
+}  // namespace acnqp

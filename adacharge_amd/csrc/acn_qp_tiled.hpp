@@ -320,7 +320,8 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
     block_max<real, 3>(f, Red, lane, wave, NW);
     qnorm = f[1];
     pd = pd_user;
-    if (f[2] > 0) pd = fmax(pd_user, (real)A.reg_rel * qnorm / f[2]);   // scale-free Tikhonov floor
+    // scale-free Tikhonov floor: reg_rel * |q|_inf / (max(ub) * T_b)
+    if (f[2] > 0) pd = fmax(pd_user, (real)A.reg_rel * qnorm / (f[2] * (real)max(1, A.horizon[b])));
     if (f[0] > 0) {   // a session cannot meet its energy row inside its own bounds
 #pragma unroll
       for (int c = 0; c < CT; ++c)

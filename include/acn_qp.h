@@ -112,7 +112,7 @@ typedef struct {
   double alpha;          /* over-relaxation in (0, 2)                         */
   double adapt_tol;      /* adapt when the residual ratio leaves [1/tol, tol] */
   double reg_rel;        /* scale-free Tikhonov floor: effective pdiag =
-                            max(pdiag, reg_rel * |q|_inf / max(ub)); 0 disables.
+                            max(pdiag, reg_rel * |q|_inf / (max(ub) * T_b)); 0 disables.
                             On LP instances a small floor returns the least-norm
                             LP optimum (exact regularisation)  */
   int32_t precision;     /* 64 or 32: arithmetic type of the ADMM loop        */

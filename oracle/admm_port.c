@@ -67,7 +67,7 @@ static void project_window(int L, const double* v, const double* lb, const doubl
 }
 
 /* returns status: 1 solved, 2 max_iter, 4 empty set */
-static int solve_one(const port_site* S, const port_opts* O, const double* lb, const double* ub_in, const double* q,
+static int solve_one(const port_site* S, const port_opts* O, int horizon, const double* lb, const double* ub_in, const double* q,
                      double pdiag_user, const int32_t* s_off, const int32_t* s_len, const double* s_cap, int eq,
                      const double* peak, double* xout, int* iters_out, double* pri_out, double* dua_out,
                      double* obj_out) {
@@ -104,7 +104,7 @@ static int solve_one(const port_site* S, const port_opts* O, const double* lb, c
     return 4;
   }
   double pd = pdiag_user;
-  if (ubmax > 0) pd = fmax(pd, O->reg_rel * qnorm / ubmax);
+  if (ubmax > 0) pd = fmax(pd, O->reg_rel * qnorm / (ubmax * (double)(horizon > 1 ? horizon : 1)));
   double rho = O->rho;
   const double sigma = O->sigma, alpha = O->alpha;
   for (int k = 0; k < n; ++k) r0[k] = -q[k];
@@ -209,7 +209,7 @@ static int solve_one(const port_site* S, const port_opts* O, const double* lb, c
 }
 
 /* Batch driver: same array layout as include/acn_qp.h (host pointers); `threads` OpenMP threads. */
-int admm_port_solve_batch(const port_site* S, const port_opts* O, int B, const double* lb, const double* ub,
+int admm_port_solve_batch(const port_site* S, const port_opts* O, int B, const int32_t* horizon, const double* lb, const double* ub,
                           const double* q, const double* pdiag, const int32_t* s_off, const int32_t* s_len,
                           const double* s_cap, const uint8_t* s_eq, const double* peak, double* x, int32_t* status,
                           int32_t* iters, double* pri, double* dua, double* obj, int threads) {
@@ -220,7 +220,7 @@ int admm_port_solve_batch(const port_site* S, const port_opts* O, int B, const d
 #endif
   for (int b = 0; b < B; ++b) {
     int it = 0;
-    status[b] = solve_one(S, O, lb + b * nv, ub + b * nv, q + b * nv, pdiag[b], s_off + b * ns, s_len + b * ns,
+    status[b] = solve_one(S, O, horizon[b], lb + b * nv, ub + b * nv, q + b * nv, pdiag[b], s_off + b * ns, s_len + b * ns,
                           s_cap + b * ns, s_eq[b] != 0, peak ? peak + (size_t)b * S->Tm : 0, x + b * nv, &it,
                           pri + b, dua + b, obj + b);
     iters[b] = it;

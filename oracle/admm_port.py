@@ -36,7 +36,7 @@ def max_threads():
 
 
 def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.003, sigma=1e-6, alpha=1.6, adapt_tol=5.0,
-                reg_rel=5e-3, max_iter=20000, check_every=20, adapt_every=40):
+                reg_rel=0.06, max_iter=20000, check_every=20, adapt_every=40):
     """Solve a builder.ProblemBatch-like object on the CPU; same defaults as
     acnqp_default_options.  Returns dict of arrays."""
     lib = _load()
@@ -46,7 +46,7 @@ def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.003, sigma=1
     S = _Site(site.N, batch.Tm, batch.K, site.Mg, site.M, int(site.cone), int(site.has_peak), *[p(a) for a in keep])
     O = _Opts(eps_abs, eps_rel, rho, sigma, alpha, adapt_tol, reg_rel, max_iter, check_every, adapt_every)
     B, N, Tm = batch.B, site.N, batch.Tm
-    arrs = [np.ascontiguousarray(batch.lb, np.float64), np.ascontiguousarray(batch.ub, np.float64),
+    arrs = [np.ascontiguousarray(batch.T, np.int32), np.ascontiguousarray(batch.lb, np.float64), np.ascontiguousarray(batch.ub, np.float64),
             np.ascontiguousarray(batch.q, np.float64), np.ascontiguousarray(batch.pdiag, np.float64),
             np.ascontiguousarray(batch.s_off, np.int32), np.ascontiguousarray(batch.s_len, np.int32),
             np.ascontiguousarray(batch.s_cap, np.float64), np.ascontiguousarray(batch.s_eq, np.uint8)]

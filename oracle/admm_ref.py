@@ -117,7 +117,7 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
     lb, ub, q = batch.lb[b], batch.ub[b], batch.q[b]
     pdiag = float(batch.pdiag[b])
     if ub.max() > 0:
-        pdiag = max(pdiag, opts.reg_rel * np.abs(q).max() / ub.max())
+        pdiag = max(pdiag, opts.reg_rel * np.abs(q).max() / (ub.max() * max(1, T)))
     eq = bool(batch.s_eq[b])
     G, Gh, lam, Q = site.G, site.Ghat, site.lam, site.Q
     Mg = G.shape[0]

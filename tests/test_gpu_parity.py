@@ -255,3 +255,38 @@ def test_fp32_path_reaches_its_tolerance():
     assert np.abs(r32.x - r64.x).max() <= 2e-2   # 6e-4 relative to the 32 A pilot scale
     assert np.abs(r32.obj - r64.obj).max() <= 1e-4 * np.abs(r64.obj).max()
     h.close()
+
+
+# ---- the reference's stress scenarios: N = 54, T = 144 (t_aco.py:286-466), general-shape kernel ---
+def _stress(network, ct, objective):
+    N, T = 54, 144
+    sd = session_generator(N, [0] * N, [T] * N, [10] * N, [10] * N, [32] * N)
+    iface = TestingInterface({"active_sessions": sd, "infrastructure_info": network, "current_time": 0, "period": 5})
+    opt = AdaptiveChargingOptimization(objective, iface, constraint_type=ct)
+    rates = opt.solve(iface.active_sessions(), iface.infrastructure_info())
+    return rates, iface.active_sessions(), iface.infrastructure_info(), opt
+
+
+@pytest.mark.parametrize("ct", ["LINEAR", "SOC"])
+def test_large_feasible_single_phase(ct):   # t_aco.py:286-343, KAT-4 aggregate
+    rates, sessions, infra, opt = _stress(single_phase_single_constraint(54, 32 * 54 / 3), ct, DEFAULT_OBJECTIVE)
+    assert rates.shape == (54, 144)
+    check_invariants(rates, sessions, infra)
+    agg = rates.sum(axis=0)
+    # KAT-4: unique aggregate 576 A for periods 0-53, 49.846 A at 54, 0 after.
+    # Moving charge between periods 53 and 54 costs 1/144 per A, a nearly flat direction of this LP,
+    # so the transition period gets a looser absolute tolerance than the rest.
+    assert np.allclose(agg[:54], 576.0, atol=2e-2)
+    assert abs(agg[54] - 49.846153846) < 0.5 and np.allclose(agg[55:], 0, atol=2e-2)
+    lp_obj = -(rates * np.array([(144 - t) / 144 for t in range(144)])[None, :]).sum()
+    assert abs(lp_obj - (-25411.153846)) <= 1e-5 * 25411.0
+
+
+@pytest.mark.parametrize("ct,obj", [
+    ("SOC", DEFAULT_OBJECTIVE),
+    ("SOC", [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]),
+    ("LINEAR", DEFAULT_OBJECTIVE),
+])
+def test_large_feasible_three_phase(ct, obj):   # t_aco.py:374-466
+    rates, sessions, infra, opt = _stress(three_phase_balanced_network(18, 32 * 54 / 3), ct, obj)
+    check_invariants(rates, sessions, infra)
