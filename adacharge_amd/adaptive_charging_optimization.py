@@ -155,7 +155,7 @@ def demand_charge(rates, infrastructure, interface, baseline_peak=0, **kwargs):
 _HANDLE_CACHE = {}
 
 
-def _site_handle(infrastructure, constraint_type, with_peak, device):
+def _site_handle(infrastructure, constraint_type, with_peak, device, with_flat=False):
     """One uploaded site per (infrastructure content, cone, peak, GPU).  The
     reference rebuilds every atom on every call (adacharge.py:152-158); here the
     site matrix is uploaded once and reused by all later MPC steps."""
@@ -168,11 +168,11 @@ def _site_handle(infrastructure, constraint_type, with_peak, device):
         None if infrastructure.constraint_limits is None else np.asarray(infrastructure.constraint_limits).tobytes(),
         None if infrastructure.phases is None else np.asarray(infrastructure.phases).tobytes(),
         np.asarray(infrastructure.voltages).tobytes(),
-        constraint_type, bool(with_peak), int(device),
+        constraint_type, bool(with_peak), int(device), bool(with_flat),
     )
     ent = _HANDLE_CACHE.get(key)
     if ent is None:
-        site = make_site(infrastructure, constraint_type, with_peak=with_peak)
+        site = make_site(infrastructure, constraint_type, with_peak=with_peak, with_flat=with_flat)
         ent = (site, backend.SiteHandle(site, device))
         if len(_HANDLE_CACHE) > 64:
             _HANDLE_CACHE.clear()
@@ -290,7 +290,12 @@ class AdaptiveChargingOptimization:
             return rates, status
         pl = [None] * B if peak_limits is None else list(peak_limits)
         any_peak = any(pl[k] is not None for k in nonempty)
-        site, handle = _site_handle(infrastructure, self.constraint_type, any_peak, self.device)
+        from .builder import _objective_needs_flat
+
+        site, handle = _site_handle(
+            infrastructure, self.constraint_type, any_peak, self.device,
+            with_flat=_objective_needs_flat(self.objective_configuration),
+        )
         batch = build_batch(
             [session_lists[k] for k in nonempty], infrastructure, self.interface,
             self.objective_configuration, self.constraint_type, self.enforce_energy_equality,

@@ -41,6 +41,7 @@ class SiteData:
     M: int
     cone: int
     has_peak: bool
+    has_flat: bool
     G: np.ndarray
     limits: np.ndarray
     lam: np.ndarray
@@ -52,8 +53,13 @@ class SiteData:
     def Mg(self) -> int:
         return self.G.shape[0]
 
+    @property
+    def flat_row(self) -> int:
+        """Index of the aggregate-power row v = voltages/1e3 (load_flattening), if present."""
+        return self.Mg - 1 - (1 if self.has_peak else 0)
 
-def make_site(infrastructure, constraint_type: str = "SOC", with_peak: bool = False) -> SiteData:
+
+def make_site(infrastructure, constraint_type: str = "SOC", with_peak: bool = False, with_flat: bool = False) -> SiteData:
     N = len(infrastructure.station_ids)
     cm = infrastructure.constraint_matrix
     if cm is None or cm.shape == (0, 0):  # aco.py:145-149
@@ -79,6 +85,8 @@ def make_site(infrastructure, constraint_type: str = "SOC", with_peak: bool = Fa
         cone = CONE_LINEAR
     else:
         _bad_constraint_type(constraint_type)
+    if with_flat:  # aggregate power in kW: charging_power / aggregate_power, aco.py:336-344
+        rows = np.vstack([rows, np.asarray(infrastructure.voltages, float)[None, :] / 1e3])
     if with_peak:
         rows = np.vstack([rows, np.ones((1, N))])
     G = np.ascontiguousarray(rows, dtype=np.float64)
@@ -91,7 +99,7 @@ def make_site(infrastructure, constraint_type: str = "SOC", with_peak: bool = Fa
     else:
         lam, Q, Ghat = np.zeros(0), np.zeros((0, 0)), np.zeros((0, N))
     return SiteData(
-        N, M, cone, bool(with_peak), G, limits, lam,
+        N, M, cone, bool(with_peak), bool(with_flat), G, limits, lam,
         np.ascontiguousarray(Q), np.ascontiguousarray(Ghat),
         np.asarray(infrastructure.voltages, float).copy(),
     )
@@ -133,6 +141,12 @@ class ProblemBatch:
         return self.site.N
 
 
+def _objective_needs_flat(objective) -> bool:
+    from .adaptive_charging_optimization import load_flattening
+
+    return any(c.function is load_flattening and c.coefficient != 0 for c in objective)
+
+
 def objective_terms(objective, infrastructure, interface, N, T, prev_peak=0):
     """Evaluate the objective list on a symbolic rates handle; see
     adaptive_charging_optimization.py in this package for the descriptor
@@ -172,8 +186,11 @@ def build_batch(
     if peak_limits is None:
         peak_limits = [None] * B
     any_peak = any(p is not None for p in peak_limits)
+    need_flat = _objective_needs_flat(objective)
     if site is None:
-        site = make_site(infrastructure, constraint_type, with_peak=any_peak)
+        site = make_site(infrastructure, constraint_type, with_peak=any_peak, with_flat=need_flat)
+    elif need_flat and not site.has_flat:
+        raise ValueError("site was built without the aggregate-power row but the objective uses load_flattening")
     elif any_peak and not site.has_peak:
         raise ValueError("site was built without a peak row but a peak_limit was given")
     station_index = {s: i for i, s in enumerate(infrastructure.station_ids)}

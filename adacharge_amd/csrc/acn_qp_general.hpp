@@ -188,6 +188,7 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
       const int ty = A.rowtype[r];
       real zn = zh2[k];
       if (ty == kRowBox) zn = fmin(zn, RL[r]);
+      else if (ty == kRowQuad) zn = zn * (rho / (rho + (A.lf ? (real)A.lf[b] : (real)0)));
       else if (ty == kRowPeak) {
         const double pv = A.peak ? A.peak[(size_t)b * T + t] : 1e300;
         zn = fmin(zn, pv < (double)M::big ? (real)pv : M::big);

@@ -51,6 +51,7 @@ constexpr int kRowBox = 1;     // z <= limit
 constexpr int kRowSocRe = 2;   // pairs with the next register (kRowSocIm): |(re, im)| <= limit
 constexpr int kRowSocIm = 3;
 constexpr int kRowPeak = 4;    // z <= peak[b][t]
+constexpr int kRowQuad = 5;    // prox of 1/2 lf z^2 (load flattening): z = zh rho / (rho + lf)
 
 struct TiledArgs {
   int B, N, Tm, K, NP, MR;     // NP = 16 * waves (padded EVSEs), MR = 16 * MT (padded site rows)
@@ -62,6 +63,7 @@ struct TiledArgs {
   const double* s_cap;
   const uint8_t* s_eq;
   const double* peak;
+  const double* lf;
   double* x;
   int32_t *status, *iters;
   double *pri, *dua, *obj;
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
   }
 
   const real pd_user = (real)A.pdiag[b];
+  const real lfb = A.lf ? (real)A.lf[b] : (real)0;
   const real sigma = (real)A.sigma, alpha = (real)A.alpha;
   real rho = (real)A.rho0;
   real qnorm, pd;
@@ -590,6 +593,7 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
           const int ty = rtype[mo][r];
           if (ty == kRowBox) zn = fmin(zhr[r], limv[mo][r]);
           else if (ty == kRowPeak) zn = fmin(zhr[r], pk[c]);
+          else if (ty == kRowQuad) zn = zhr[r] * (rho / (rho + lfb));
           else if (ty == kRowSocRe || ty == kRowSocIm) zn = zhr[r] * scl[r >> 1];
           y2[mo][c][r] = rho * (zhr[r] - zn);
           z2[mo][c][r] = zn;

@@ -22,6 +22,9 @@
  *                 LINEAR  (G r[:, t])_j <= limits_j               (aco.py:165-172)
  *                 SOC     |((G r)_j, (G r)_{j+M})|_2 <= limits_j  (aco.py:151-164)
  *                 peak    sum_i r[i, t] <= peak_b[t]              (aco.py:196-198)
+ *   plus, when the site carries a "flat" row v = voltages / 1e3 (kW per A), the objective term
+ *               1/2 lf_b sum_t (v' r[:, t])^2                     (load_flattening, aco.py:403-408;
+ *                                                                  its linear part is already in q)
  *
  * Layouts are C order: r, lb, ub, q are [batch][N][Tm] -- the (N, T) rates
  * matrix the reference returns at aco.py:321, one per problem.
@@ -35,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ACNQP_ABI_VERSION 1
+#define ACNQP_ABI_VERSION 2
 
 /* cone of the infrastructure rows (constraint_type at aco.py:35, 151, 165) */
 #define ACNQP_CONE_LINEAR 0
@@ -61,13 +64,15 @@ typedef struct acnqp_handle acnqp_handle; /* opaque; one per (site, GPU) */
  * contributes to aco.py:126-198.  G is [n_rows][n_evse] row-major:
  *   LINEAR: |constraint_matrix| (n_infra rows)            aco.py:171
  *   SOC:    [C*cos(phi); C*sin(phi)] (2*n_infra rows)     aco.py:156-158
- *   plus one trailing all-ones row iff has_peak           aco.py:197          */
+ *   then one row voltages/1e3 iff has_flat               aco.py:336-344, 406
+ *   then one all-ones row iff has_peak                   aco.py:197          */
 typedef struct {
   int32_t n_evse;        /* N                                   */
   int32_t n_infra;       /* M: rows of constraint_matrix         */
-  int32_t n_rows;        /* rows of G = M or 2M, + has_peak      */
+  int32_t n_rows;        /* rows of G = M or 2M, + has_flat + has_peak */
   int32_t cone;          /* ACNQP_CONE_*                         */
   int32_t has_peak;      /* 0 / 1                                */
+  int32_t has_flat;      /* 0 / 1: aggregate-power row for load_flattening */
   const double* G;       /* [n_rows * n_evse]                    */
   const double* limits;  /* [n_infra]  constraint_limits         */
 } acnqp_site;
@@ -88,6 +93,7 @@ typedef struct {
   const double* s_cap;     /* [B*K*N]    energy cap in A-periods             */
   const uint8_t* s_eq;     /* [B]        1: energy rows are equalities       */
   const double* peak;      /* [B*Tm] or NULL; +inf = unlimited period        */
+  const double* lf;        /* [B] or NULL: weight of 1/2 lf (v' r_t)^2 (2 * load_flattening coefficient) */
 } acnqp_problems;
 
 typedef struct {

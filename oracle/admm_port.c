@@ -19,7 +19,7 @@
 #endif
 
 typedef struct {
-  int N, Tm, K, Mg, M, cone, has_peak;
+  int N, Tm, K, Mg, M, cone, has_peak, has_flat;
   const double *G, *Ghat, *Q, *lam, *limits;  /* G,Ghat [Mg][N]; Q [Mg][Mg] (Q[r][k]) */
 } port_site;
 
@@ -68,7 +68,7 @@ static void project_window(int L, const double* v, const double* lb, const doubl
 
 /* returns status: 1 solved, 2 max_iter, 4 empty set */
 static int solve_one(const port_site* S, const port_opts* O, int horizon, const double* lb, const double* ub_in, const double* q,
-                     double pdiag_user, const int32_t* s_off, const int32_t* s_len, const double* s_cap, int eq,
+                     double pdiag_user, double lf, const int32_t* s_off, const int32_t* s_len, const double* s_cap, int eq,
                      const double* peak, double* xout, int* iters_out, double* pri_out, double* dua_out,
                      double* obj_out) {
   const int N = S->N, T = S->Tm, Mg = S->Mg, M = S->M, K = S->K;
@@ -160,6 +160,11 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
           y2[c * T + t] = rho * (tmpv[c] - za); z2[c * T + t] = za;
         }
       }
+      if (S->has_flat) {   /* prox of 1/2 lf z^2 on the aggregate-power row */
+        const int r = Mg - 1 - S->has_peak;
+        const double za = tmpv[r] * (rho / (rho + lf));
+        y2[r * T + t] = rho * (tmpv[r] - za); z2[r * T + t] = za;
+      }
       if (S->has_peak) {
         const int r = Mg - 1;
         const double lim = peak ? fmin(peak[t], 1e300) : 1e300;
@@ -210,7 +215,7 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
 
 /* Batch driver: same array layout as include/acn_qp.h (host pointers); `threads` OpenMP threads. */
 int admm_port_solve_batch(const port_site* S, const port_opts* O, int B, const int32_t* horizon, const double* lb, const double* ub,
-                          const double* q, const double* pdiag, const int32_t* s_off, const int32_t* s_len,
+                          const double* q, const double* pdiag, const double* lf, const int32_t* s_off, const int32_t* s_len,
                           const double* s_cap, const uint8_t* s_eq, const double* peak, double* x, int32_t* status,
                           int32_t* iters, double* pri, double* dua, double* obj, int threads) {
   const size_t nv = (size_t)S->N * S->Tm, ns = (size_t)S->K * S->N;
@@ -220,7 +225,7 @@ int admm_port_solve_batch(const port_site* S, const port_opts* O, int B, const i
 #endif
   for (int b = 0; b < B; ++b) {
     int it = 0;
-    status[b] = solve_one(S, O, horizon[b], lb + b * nv, ub + b * nv, q + b * nv, pdiag[b], s_off + b * ns, s_len + b * ns,
+    status[b] = solve_one(S, O, horizon[b], lb + b * nv, ub + b * nv, q + b * nv, pdiag[b], lf ? lf[b] : 0.0, s_off + b * ns, s_len + b * ns,
                           s_cap + b * ns, s_eq[b] != 0, peak ? peak + (size_t)b * S->Tm : 0, x + b * nv, &it,
                           pri + b, dua + b, obj + b);
     iters[b] = it;

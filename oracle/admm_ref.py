@@ -99,6 +99,9 @@ def _prox_rows(zh, rho, site, peak_b, T, lf, lf_ext):
     else:
         z[:M] = np.minimum(zh[:M], site.limits[:, None])
         r = M
+    if getattr(site, "has_flat", False):   # prox of 1/2 lf z^2 on the aggregate-power row
+        z[r] = zh[r] * (rho / (rho + lf))
+        r += 1
     if site.has_peak:
         z[r] = np.minimum(zh[r], peak_b)
         r += 1
@@ -150,7 +153,7 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
         z1 = _project_B(zh1, lb, ub, batch.s_off[b], batch.s_len[b], batch.s_cap[b], eq)
         y1 = rho * (zh1 - z1)
         zh2 = alpha * zt2 + (1 - alpha) * z2 + y2 / rho
-        z2 = _prox_rows(zh2, rho, site, peak_b, T, 0.0, None)
+        z2 = _prox_rows(zh2, rho, site, peak_b, T, float(batch.lf[b]), None)
         y2 = rho * (zh2 - z2)
         if it % opts.check_every == 0 or it == opts.max_iter:
             Gty = G.T @ y2

@@ -290,3 +290,27 @@ def test_large_feasible_single_phase(ct):   # t_aco.py:286-343, KAT-4 aggregate
 def test_large_feasible_three_phase(ct, obj):   # t_aco.py:374-466
     rates, sessions, infra, opt = _stress(three_phase_balanced_network(18, 32 * 54 / 3), ct, obj)
     check_invariants(rates, sessions, infra)
+
+
+# ---- load_flattening (aco.py:403-408): quadratic in the aggregate power, prox row on the device ---
+@pytest.mark.parametrize("ct", ["LINEAR", "SOC"])
+def test_load_flattening_matches_oracle(ct):
+    from adacharge_amd import load_flattening, total_energy
+    from oracle.ipm import solve_certified
+    from oracle.ref_problem import build_reference_problem
+
+    infra, iface = H.caltech_interface()
+    ext = np.array([40, 35, 30, 20, 10, 5, 5, 10, 20, 30, 35, 40], float)
+    obj = [ObjectiveComponent(load_flattening, 1.0, {"external_signal": ext}), ObjectiveComponent(total_energy, 1500.0),
+           ObjectiveComponent(equal_share, 1e-3)]
+    spec = [("load_flattening", 1.0, {"external_signal": ext}), ("total_energy", 1500.0, {}), ("equal_share", 1e-3, {})]
+    for seed in (3, 4):
+        sl = sites.random_sessions(infra, 12, np.random.default_rng(seed))
+        opt = AdaptiveChargingOptimization(obj, iface, constraint_type=ct, solver_options=dict(reg_rel=0.0))
+        rates = opt.solve(sl, infra)
+        prob = build_reference_problem(sl, infra, iface, spec, ct)
+        ref, _, cert = solve_certified(prob)
+        assert cert is not None and cert.worst < 1e-7
+        assert np.abs(rates - ref).max() <= RATE_TOL, np.abs(rates - ref).max()
+        assert abs(opt.last_result.obj[0] - prob.objective(ref)) <= 1e-6 * abs(prob.objective(ref))
+        H.assert_infrastructure_satisfied(rates, infra, tol=1e-4)
