@@ -28,7 +28,7 @@ namespace acnqp {
 
 #ifdef ACNQP_STAMPS
 // diagnostic build only: cycles per phase, [block][wave][8]; never read by the kernel
-__device__ unsigned long long g_stamps[1024 * 16 * 8];
+__device__ unsigned long long g_stamps[1024 * 16 * 12];
 #define STAMP(slot)                                                                    \
   do {                                                                                 \
     unsigned long long _t;                                                             \
@@ -121,18 +121,6 @@ template <typename T> __device__ inline T row_max(T v) {
   v = fmax(v, dpp_mov<kRowMirror>(v));
   return v;
 }
-template <typename T> __device__ inline T wave_max(T v) {
-  v = row_max<T>(v);
-  v = fmax(v, __shfl_xor(v, 16));
-  v = fmax(v, __shfl_xor(v, 32));
-  return v;
-}
-template <typename T> __device__ inline T wave_sum(T v) {
-  v = row_sum<T>(v);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
-}
 
 // 1 / sqrt(x): hardware estimate + two Newton steps (full precision for f64, cheaper than sqrt + div)
 __device__ inline double rsqrt_nr(double x) {
@@ -148,27 +136,66 @@ __device__ inline float rsqrt_nr(float x) {
 }
 
 // 1 / n for a small positive integer n (interior-period count of a session window)
-__device__ inline double rcp_small(int n) {
-  const double x = (double)n;
-  double y = __builtin_amdgcn_rcp(x);
-  y = y + y * (1.0 - x * y);   // one Newton step: full double precision for n <= 2^24
+__device__ inline double rcp_small(float nf) {
+  const double x = (double)nf;
+  double y = (double)__builtin_amdgcn_rcpf(nf);   // ~1e-7 relative
+  y = y + y * (1.0 - x * y);                      // ~1e-14
+  y = y + y * (1.0 - x * y);                      // full double precision
   return y;
 }
-__device__ inline float rcp_smallf(int n) { return 1.0f / (float)n; }
 
 // LDS carve-up in units of `real`; shared by host (size) and device (offsets)
+constexpr int kXS = 18;   // row stride (reals) of the per-wave 16 x 16 transpose scratch: 16-B aligned quads
 struct TiledLds {
-  int pbuf, scap, slo, shi, red, total;
+  int pbuf, xpose, red, total;
   __host__ __device__ TiledLds(int NW, int MT, int CT, int NP, int K) {
     int o = 0;
-    pbuf = o; o += 2 * NW * MT * CT * 4 * 64;   // double-buffered partial tiles
-    scap = o; o += K * NP;
-    slo = o;  o += K * NP;
-    shi = o;  o += K * NP;
-    red = o;  o += 16 * kNumRed + 8;
+    pbuf = o;  o += 2 * NW * MT * CT * 4 * 64;   // double-buffered partial tiles
+    xpose = o; o += NW * CT * 16 * kXS;          // C layout <-> session layout, private to each wave
+    red = o;   o += 16 * kNumRed + 8;
     total = (o + 1) & ~1;
   }
 };
+
+// Reductions over the lanes l, l^16, l^32, l^48 (the four quarter-lanes of one EVSE in session
+// layout) with v_permlane16_swap / v_permlane32_swap: swapping a register with itself leaves the
+// two partner values in the two results for EVERY lane, so r[0] (op) r[1] is the pairwise result --
+// plain VALU, no LDS crossbar, and bitwise identical in both partners.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+struct Pair32 { unsigned a, b; };
+struct PairF { float a, b; };
+struct PairD { double a, b; };
+template <int WHICH> __device__ inline Pair32 swap_u32(unsigned v) {
+  const u32x2 r = WHICH == 16 ? __builtin_amdgcn_permlane16_swap(v, v, false, false)
+                              : __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return {r[0], r[1]};
+}
+template <int WHICH> __device__ inline PairF swap_pair(float v) {
+  const Pair32 p = swap_u32<WHICH>(__builtin_bit_cast(unsigned, v));
+  return {__builtin_bit_cast(float, p.a), __builtin_bit_cast(float, p.b)};
+}
+template <int WHICH> __device__ inline PairD swap_pair(double v) {
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+  const Pair32 lo = swap_u32<WHICH>((unsigned)(bits & 0xffffffffull));
+  const Pair32 hi = swap_u32<WHICH>((unsigned)(bits >> 32));
+  return {__builtin_bit_cast(double, ((unsigned long long)hi.a << 32) | lo.a),
+          __builtin_bit_cast(double, ((unsigned long long)hi.b << 32) | lo.b)};
+}
+template <typename T> __device__ inline T quarter_sum(T v) {
+  auto p = swap_pair<16>(v); v = p.a + p.b;
+  auto q = swap_pair<32>(v); return q.a + q.b;
+}
+template <typename T> __device__ inline T quarter_min(T v) {
+  auto p = swap_pair<16>(v); v = fmin(p.a, p.b);
+  auto q = swap_pair<32>(v); return fmin(q.a, q.b);
+}
+template <typename T> __device__ inline T quarter_max(T v) {
+  auto p = swap_pair<16>(v); v = fmax(p.a, p.b);
+  auto q = swap_pair<32>(v); return fmax(q.a, q.b);
+}
+
+template <typename T> __device__ inline T wave_max(T v) { return quarter_max<T>(row_max<T>(v)); }
+template <typename T> __device__ inline T wave_sum(T v) { return quarter_sum<T>(row_sum<T>(v)); }
 
 // Block-wide max of NV per-thread values (2 barriers); every thread gets the result.
 template <typename real, int NV>
@@ -203,9 +230,7 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
   const int N = A.N, Tm = A.Tm, NP = A.NP, MR = A.MR;
   const TiledLds L(NW, MT, CT, NP, A.K);
   real* Pbuf = sm + L.pbuf;
-  real* Scap = sm + L.scap;
-  real* Slo = sm + L.slo;
-  real* Shi = sm + L.shi;
+  real* Xw = sm + L.xpose + (size_t)wave * CT * 16 * kXS;   // this wave's transpose scratch
   real* Red = sm + L.red;
   const real* Gm = static_cast<const real*>(A.G);
   const real* Gh = static_cast<const real*>(A.Ghat);
@@ -268,41 +293,54 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
     }
   }
   const bool eq = A.s_eq[b] != 0;
-  unsigned wmask[KS];          // bit (4 c + r): period 16c+t lies in slot k's window on EVSE(r)
-  unsigned hasm[KS];           // bit r: EVSE(r) has a session in slot k
-  real mu[KS][4];
-  int smode[KS][4];            // 0: root-find each iteration, 2: pinned at ub, 3: pinned at lb
+  // ---- session layout: lane = 16 h + e holds periods 16 c + 4 h + tt (tt = 0..3) of EVSE 16 w + e.
+  // The energy rows are solved here: a session's sum is 4 local adds + two lane exchanges, and one
+  // pass over g(m) serves the wave's 16 sessions at once.
+  const int se = lane & 15, sh = lane >> 4;
+  const int sev = 16 * wave + se;
+  const bool sact = sev < N;
+  real slb[CT][4], sub[CT][4];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+      const int tp = 16 * c + 4 * sh + tt;
+      const bool ok = sact && tp < Tm;
+      const size_t idx = ((size_t)b * N + (ok ? sev : 0)) * Tm + (ok ? tp : 0);
+      slb[c][tt] = ok ? (real)A.lb[idx] : (real)0;
+      sub[c][tt] = ok ? (real)A.ub[idx] : (real)0;
+      if (sub[c][tt] < slb[c][tt]) sub[c][tt] = slb[c][tt];
+    }
+  unsigned swm[KS];            // bit (4 c + tt): that period lies in slot k's window
+  bool shas[KS];
+  int smode[KS];               // 0: root-find each iteration, 2: pinned at ub, 3: pinned at lb
+  real scap[KS], mu[KS];
   bool empty_set = false;
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
-    wmask[k] = 0; hasm[k] = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { mu[k][r] = 0; smode[k][r] = 0; }
+    swm[k] = 0; shas[k] = false; smode[k] = 0; scap[k] = 0; mu[k] = 0;
     if (k < A.K) {   // block-uniform
+      const size_t sidx = ((size_t)b * A.K + k) * N + (sact ? sev : 0);
+      const int off = sact ? A.s_off[sidx] : 0;
+      const int len = sact ? A.s_len[sidx] : 0;
+      real sl = 0, su = 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ev = 16 * wave + M::rowof(g, r);
-        const size_t sidx = ((size_t)b * A.K + k) * N + (evact[r] ? ev : 0);
-        const int off = evact[r] ? A.s_off[sidx] : 0;
-        const int len = evact[r] ? A.s_len[sidx] : 0;
-        real sl = 0, su = 0;
+      for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          const int tt = 16 * c + t;
-          if (tt >= off && tt < off + len && tt < Tm) { wmask[k] |= 1u << (4 * c + r); sl += lbv[c][r]; su += ubv[c][r]; }
+        for (int tt = 0; tt < 4; ++tt) {
+          const int tp = 16 * c + 4 * sh + tt;
+          if (tp >= off && tp < off + len && tp < Tm) { swm[k] |= 1u << (4 * c + tt); sl += slb[c][tt]; su += sub[c][tt]; }
         }
-        sl = row_sum<real>(sl);
-        su = row_sum<real>(su);
-        const real cap = evact[r] ? (real)A.s_cap[sidx] : (real)0;
-        if (len > 0) {
-          hasm[k] |= 1u << r;
-          const real slack = (real)64 * M::proj_tol * fmax((real)1, fabs(cap));
-          if (sl > cap + slack) empty_set = true;
-          if (eq && su < cap - slack) empty_set = true;
-          if (eq && cap >= su) smode[k][r] = 2;
-          else if (cap <= sl) smode[k][r] = 3;
-        }
-        if (t == 0 && evact[r]) { Scap[k * NP + ev] = cap; Slo[k * NP + ev] = sl; Shi[k * NP + ev] = su; }
+      sl = quarter_sum<real>(sl);
+      su = quarter_sum<real>(su);
+      scap[k] = sact ? (real)A.s_cap[sidx] : (real)0;
+      shas[k] = len > 0;
+      if (shas[k]) {
+        const real slack = (real)64 * M::proj_tol * fmax((real)1, fabs(scap[k]));
+        if (sl > scap[k] + slack) empty_set = true;
+        if (eq && su < scap[k] - slack) empty_set = true;
+        if (eq && scap[k] >= su) smode[k] = 2;
+        else if (scap[k] <= sl) smode[k] = 3;
       }
     }
   }
@@ -362,7 +400,7 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
   const real ptol_scale = M::proj_tol;
 
 #ifdef ACNQP_STAMPS
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
   while (!done) {
@@ -434,134 +472,29 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
     }
 
     STAMP(3);   // x~ MFMA + clip
-    // ---- energy rows: exact water-filling per (EVSE register, session slot) ----------------------
-    // z = clip(zh - m) with g(m) = sum_t clip(zh_t - m) = cap.  Newton on the piecewise-linear g from
-    // the previous iteration's m.  Which periods sit at a bound is a pair of wave-wide compare masks
-    // (SGPRs): the interior count is a popcount of the row's 16 mask bits and a step is exact as soon
-    // as it leaves both masks unchanged on the row -- in steady state ONE 16-lane f64 reduction per
-    // register and iteration, everything else branch-free VALU/SALU.  Bisection only as a fallback.
+    // ---- energy rows: exact water-filling in session layout ---------------------------------------
+    // z = clip(zh - m) with g(m) = sum_t clip(zh_t - m) = cap: safeguarded Newton on the piecewise-
+    // linear g, warm-started at the previous iteration's m (typically one step + one verifying pass).
+    {
+      // C layout -> session layout through this wave's private LDS scratch (no workgroup barrier)
 #pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      if (k < A.K) {   // block-uniform
-        real cap[4], m_[4], lo[4], hi[4], tolv[4];
-        bool need[4];
+      for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ev = 16 * wave + M::rowof(g, r);
-          const bool has = (hasm[k] >> r) & 1u;
-          cap[r] = has ? Scap[k * NP + ev] : (real)0;
-          tolv[r] = ptol_scale * fmax((real)1, fabs(cap[r]));
-          need[r] = has && smode[k][r] == 0;
-          m_[r] = mu[k][r];
-          lo[r] = eq ? -M::big : (real)-1;   // inequality: m >= 0, so (-1, .) brackets m = 0
-          hi[r] = M::big;
+        for (int r = 0; r < 4; ++r) Xw[(c * 16 + M::rowof(g, r)) * kXS + t] = zh[c][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      real szh[CT][4], sz[CT][4];
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          szh[c][tt] = Xw[(c * 16 + se) * kXS + 4 * sh + tt];
+          sz[c][tt] = fmin(fmax(szh[c][tt], slb[c][tt]), sub[c][tt]);
         }
-        int guard = 0;
-        while (__any(need[0] | need[1] | need[2] | need[3])) {
-          ++guard;
-          real gs[4];
-          int nfi[4];
-          unsigned long long mub[4][CT], mlb[4][CT];   // (v < ub), (v > lb) lane masks at m
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            real gl = 0;
-            int nl = 0;
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-              const bool inw = (wmask[k] >> (4 * c + r)) & 1u;
-              const real v = zh[c][r] - m_[r];
-              const bool bu = v < ubv[c][r], bl = v > lbv[c][r];
-              gl += inw ? fmin(fmax(v, lbv[c][r]), ubv[c][r]) : (real)0;
-              mub[r][c] = __ballot(bu && inw);
-              mlb[r][c] = __ballot(bl && inw);
-              const unsigned inner = (unsigned)(((mub[r][c] & mlb[r][c]) >> (16 * g)) & 0xFFFFull);
-              nl += __popc(inner);
-            }
-            gs[r] = row_sum<real>(gl);
-            nfi[r] = nl;
-          }
-          real mn[4];
-          bool step[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const real d = gs[r] - cap[r];
-            const bool fin = fabs(d) <= tolv[r] || (!eq && m_[r] <= (real)0 && d <= (real)0) || guard > 120;
-            need[r] = need[r] && !fin;
-            lo[r] = (need[r] && d > 0) ? m_[r] : lo[r];
-            hi[r] = (need[r] && !(d > 0)) ? m_[r] : hi[r];
-          }
-          // flat piece with an open bracket (rare): fetch the true bracket ends so the fallback bisects
-          bool open_any = false;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) open_any |= need[r] && nfi[r] == 0 && !(lo[r] > -M::big && hi[r] < M::big);
-          if (__any(open_any)) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              real lo_l = M::big, hi_l = -M::big;
-#pragma unroll
-              for (int c = 0; c < CT; ++c)
-                if ((wmask[k] >> (4 * c + r)) & 1u) {
-                  lo_l = fmin(lo_l, zh[c][r] - ubv[c][r]);
-                  hi_l = fmax(hi_l, zh[c][r] - lbv[c][r]);
-                }
-              const real lo0 = row_min<real>(lo_l), hi0 = row_max<real>(hi_l);
-              const bool open = need[r] && nfi[r] == 0 && !(lo[r] > -M::big && hi[r] < M::big);
-              lo[r] = open ? fmax(lo[r], lo0) : lo[r];
-              hi[r] = open ? fmin(hi[r], hi0) : hi[r];
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const real d = gs[r] - cap[r];
-            const bool bracketed = lo[r] > -M::big && hi[r] < M::big;
-            const real mid = (real)0.5 * (lo[r] + hi[r]);
-            bool newton = nfi[r] > 0;
-            real cand = newton ? m_[r] + d * rcp_small(nfi[r]) : (bracketed ? mid : fmin(fmax(m_[r] + d, lo[r]), hi[r]));
-            if (!eq && cand < (real)0) { cand = 0; newton = false; }     // inequality: multiplier >= 0
-            const bool inside = cand > lo[r] && cand < hi[r];
-            real alt = bracketed ? mid : fmin(fmax(cand, lo[r]), hi[r]);
-            if (!eq && alt < (real)0) alt = 0;
-            cand = inside ? cand : alt;
-            newton = newton && inside;
-            mn[r] = need[r] ? cand : m_[r];
-            step[r] = need[r] && newton;
-          }
-          // a Newton step that leaves both compare masks unchanged on the row is exact (g is linear
-          // between m and mn)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            unsigned long long changed = 0;
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-              const bool inw = (wmask[k] >> (4 * c + r)) & 1u;
-              const real v = zh[c][r] - mn[r];
-              changed |= (__ballot(v < ubv[c][r] && inw) ^ mub[r][c]) | (__ballot(v > lbv[c][r] && inw) ^ mlb[r][c]);
-            }
-            const bool row_same = ((changed >> (16 * g)) & 0xFFFFull) == 0ull;
-            m_[r] = mn[r];
-            need[r] = need[r] && !(step[r] && row_same);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool has = (hasm[k] >> r) & 1u;
-          if (has && smode[k][r] == 0) mu[k][r] = m_[r];
-#pragma unroll
-          for (int c = 0; c < CT; ++c)
-            if ((wmask[k] >> (4 * c + r)) & 1u) {
-              if (smode[k][r] == 0) z1[c][r] = fmin(fmax(zh[c][r] - m_[r], lbv[c][r]), ubv[c][r]);
-              else if (smode[k][r] == 2) z1[c][r] = ubv[c][r];
-              else z1[c][r] = lbv[c][r];
-            }
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) y1[c][r] = rho * (zh[c][r] - z1[c][r]);
-
-    STAMP(4);   // water-filling + y1
+      STAMP(7);   // C -> session transpose
+      // (the site-row update is independent of the water-filling; it sits here so that its MFMA chain
+      //  and VALU work share one basic block with the first Newton pass and hide each other's latency)
     // ---- site rows: G x~ = Q h^, relaxation, projection onto C, y2 (every wave, redundantly) ---
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -600,6 +533,113 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
         }
       }
     }
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        if (k == 0 || k < A.K) {   // block-uniform; slot 0 always exists
+          const real cap = scap[k];
+          const real tol = ptol_scale * fmax((real)1, fabs(cap));
+#if defined(ACNQP_ABL) && ACNQP_ABL == 1
+          bool need = false;
+#else
+          bool need = shas[k] && smode[k] == 0;
+#endif
+          real m = mu[k];
+          real lo = eq ? -M::big : (real)-1;   // inequality: m >= 0, so (-1, .) brackets m = 0
+          real hi = M::big;
+          int guard = 0;
+          auto newton_pass = [&]() {
+            ++guard;
+
+            real gl = 0, lo_l = M::big, hi_l = -M::big;
+            float nl = 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt) {
+                const bool inw = (swm[k] >> (4 * c + tt)) & 1u;
+                const real v = szh[c][tt] - m;
+                gl += inw ? fmin(fmax(v, slb[c][tt]), sub[c][tt]) : (real)0;
+                nl += (inw && v > slb[c][tt] && v < sub[c][tt]) ? 1.f : 0.f;
+                lo_l = inw ? fmin(lo_l, szh[c][tt] - sub[c][tt]) : lo_l;
+                hi_l = inw ? fmax(hi_l, szh[c][tt] - slb[c][tt]) : hi_l;
+              }
+            const real gs = quarter_sum<real>(gl);
+            const float nf = quarter_sum<float>(nl);
+            const real d = gs - cap;
+            const bool fin = fabs(d) <= tol || (!eq && m <= (real)0 && d <= (real)0) || guard > 120;
+            need = need && !fin;
+            lo = (need && d > 0) ? m : lo;
+            hi = (need && !(d > 0)) ? m : hi;
+            // flat piece with an open bracket (rare): fetch the true bracket ends so the fallback bisects
+            const bool open = need && nf <= 0.f && !(lo > -M::big && hi < M::big);
+            if (__any(open)) {
+              const real lo0 = quarter_min<real>(lo_l), hi0 = quarter_max<real>(hi_l);
+              lo = open ? fmax(lo, lo0) : lo;
+              hi = open ? fmin(hi, hi0) : hi;
+            }
+            const bool bracketed = lo > -M::big && hi < M::big;
+            const real mid = (real)0.5 * (lo + hi);
+            bool newton = nf > 0.f;
+            real cand = newton ? m + d * (real)rcp_small(nf) : (bracketed ? mid : fmin(fmax(m + d, lo), hi));
+            if (!eq && cand < (real)0) { cand = 0; newton = false; }      // inequality: multiplier >= 0
+            real alt = bracketed ? mid : fmin(fmax(cand, lo), hi);
+            if (!eq && alt < (real)0) alt = 0;
+            const bool inside = cand > lo && cand < hi;
+            cand = inside ? cand : alt;
+            newton = newton && inside;
+            // A Newton step that keeps every period of the window on its piece of g (same side of
+            // lb / ub before and after) is exact: g is linear between m and cand.  One OR-reduction
+            // of a flag word over the session's four lanes replaces the verifying pass.
+            unsigned moved = 0;
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt) {
+                const bool inw = (swm[k] >> (4 * c + tt)) & 1u;
+                const real v0 = szh[c][tt] - m, v1 = szh[c][tt] - cand;
+                const bool ch = ((v0 < sub[c][tt]) != (v1 < sub[c][tt])) || ((v0 > slb[c][tt]) != (v1 > slb[c][tt]));
+                moved |= (inw && ch) ? 1u : 0u;
+              }
+            { const Pair32 p = swap_u32<16>(moved); moved = p.a | p.b; }
+            { const Pair32 q = swap_u32<32>(moved); moved = q.a | q.b; }
+            m = need ? cand : m;
+            need = need && !(newton && moved == 0u);
+          };
+          newton_pass();                       // peeled: straight-line with the site-row update above
+          while (__any(need)) newton_pass();   // rare: the active set of some session changed
+          if (shas[k] && smode[k] == 0) mu[k] = m;
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+              if ((swm[k] >> (4 * c + tt)) & 1u) {
+                if (smode[k] == 0) sz[c][tt] = fmin(fmax(szh[c][tt] - m, slb[c][tt]), sub[c][tt]);
+                else if (smode[k] == 2) sz[c][tt] = sub[c][tt];
+                else sz[c][tt] = slb[c][tt];
+              }
+        }
+      }
+      STAMP(8);   // Newton passes
+      // session layout -> C layout
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) Xw[(c * 16 + se) * kXS + 4 * sh + tt] = sz[c][tt];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z1[c][r] = Xw[(c * 16 + M::rowof(g, r)) * kXS + t];
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y1[c][r] = rho * (zh[c][r] - z1[c][r]);
+
+    STAMP(4);   // session -> C transpose + y1
     STAMP(5);   // site rows
     // ---- residuals, termination, rho adaptation (block-uniform decisions) -----------------
     const bool check = (it % A.check_every == 0) || it >= A.max_iter;
@@ -659,7 +699,7 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
   }
 #ifdef ACNQP_STAMPS
   if (lane == 0 && b < 1024)
-    for (int k = 0; k < 8; ++k) g_stamps[(b * 16 + wave) * 8 + k] = st_acc[k];
+    for (int k = 0; k < 12; ++k) g_stamps[(b * 16 + wave) * 12 + k] = st_acc[k];
 #endif
 
   // ---- results: the feasible iterate z1 is the schedule ------------------------------------

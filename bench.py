@@ -250,7 +250,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "acnqp::admm_kernel", "kernel_avg_ms": k_avg_ms,
+                "kernel": "acnqp::admm_tiled_kernel<double, 4, 1, 1, 1>" if args.precision == 64 else "acnqp::admm_tiled_kernel<float, 4, 1, 1, 1>", "kernel_avg_ms": k_avg_ms,
                 "algorithmic_bytes_per_launch": abytes, "bytes_per_qp": per_qp,
                 "note": "LDS-resident iterative solver: HBM is touched once per problem, so the HBM fraction is "
                         "small by construction (SURVEY.md H8); the VALU view is in `valu`",
