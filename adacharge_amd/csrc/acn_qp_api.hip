@@ -223,8 +223,8 @@ hipError_t launch_mt(const acnqp::TiledArgs& a, hipStream_t st) {
 template <typename real>
 hipError_t launch_any(const acnqp::TiledArgs& a, int NW, hipStream_t st) {
   const int CT = (a.Tm + 15) / 16;
-  if (NW == 4) return CT == 1 ? launch_mt<real, 4, 1>(a, st) : launch_mt<real, 4, 2>(a, st);
-  return launch_mt<real, 16, 1>(a, st);
+  (void)NW;   // N <= 64: four waves; wider sites take the general-shape kernel
+  return CT == 1 ? launch_mt<real, 4, 1>(a, st) : launch_mt<real, 4, 2>(a, st);
 }
 
 }  // namespace
@@ -255,8 +255,8 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
   if (!site || !out) return fail(ACNQP_ERR_INVALID, "acnqp_create: null argument");
   *out = nullptr;
   const int N = site->n_evse, M = site->n_infra, Mg = site->n_rows;
-  if (N < 1 || N > 256)
-    return fail(ACNQP_ERR_INVALID, "acnqp_create: n_evse must be in [1, 256] for the tiled kernel");
+  if (N < 1 || N > 1024)
+    return fail(ACNQP_ERR_INVALID, "acnqp_create: n_evse must be in [1, 1024]");
   if (site->cone != ACNQP_CONE_LINEAR && site->cone != ACNQP_CONE_SOC)
     return fail(ACNQP_ERR_INVALID, "acnqp_create: cone must be ACNQP_CONE_LINEAR or ACNQP_CONE_SOC");
   const int expect = (site->cone == ACNQP_CONE_SOC ? 2 * M : M) + (site->has_peak ? 1 : 0) + (site->has_flat ? 1 : 0);
@@ -277,8 +277,8 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
   h->device = device_id;
   h->N = N; h->M = M; h->Mg = Mg; h->cone = site->cone; h->has_peak = site->has_peak ? 1 : 0;
   h->has_flat = site->has_flat ? 1 : 0;
-  h->NW = N <= 64 ? 4 : 16;
-  h->NP = 16 * h->NW;
+  h->NW = 4;
+  h->NP = N <= 64 ? 64 : 16 * ((N + 15) / 16);
   h->G.assign(site->G, site->G + (size_t)Mg * N);
   h->limits.assign(site->limits, site->limits + M);
   hipError_t e = hipEventCreate(&h->ev_start);
@@ -358,7 +358,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.eps_abs = o->eps_abs; a.eps_rel = o->eps_rel; a.rho0 = o->rho; a.sigma = o->sigma; a.alpha = o->alpha;
   a.adapt_tol = o->adapt_tol; a.reg_rel = o->reg_rel;
   a.max_iter = o->max_iter; a.check_every = o->check_every; a.adapt_every = o->adapt_every;
-  const bool tiled = p->t_max <= (h->NW == 4 ? 32 : 16);
+  const bool tiled = h->N <= 64 && p->t_max <= 32;
   acnqp::GeneralArgs ga;
   if (!tiled) {
     // general-shape fallback: state streamed through a global workspace (not graph-capturable: it may allocate)
@@ -370,6 +370,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     ga.pair_stride = o->precision == 32 ? 1 : 4;
     ga.t = a;
   }
+  (void)hipGetLastError();   // drop any stale error so the check below reports this launch only
   HIP_TRY(hipEventRecord(h->ev_start, st));
   hipError_t e = hipSuccess;
   if (tiled) {

@@ -39,10 +39,10 @@ def test_create_rejects_bad_arguments(hip_library):
     h = C.c_void_p()
     assert hip_library.acnqp_create(None, 0, C.byref(h)) == -1
     assert b"null" in hip_library.acnqp_last_error()
-    G = np.ones((1, 300))
+    G = np.ones((1, 2000))
     lim = np.ones(1)
-    desc = backend._Site(300, 1, 1, 0, 0, 0, G.ctypes.data_as(C.c_void_p), lim.ctypes.data_as(C.c_void_p))
-    assert hip_library.acnqp_create(C.byref(desc), 0, C.byref(h)) == -1   # N > 256
+    desc = backend._Site(2000, 1, 1, 0, 0, 0, G.ctypes.data_as(C.c_void_p), lim.ctypes.data_as(C.c_void_p))
+    assert hip_library.acnqp_create(C.byref(desc), 0, C.byref(h)) == -1   # N > 1024
     desc = backend._Site(4, 1, 3, 0, 0, 0, G.ctypes.data_as(C.c_void_p), lim.ctypes.data_as(C.c_void_p))
     assert hip_library.acnqp_create(C.byref(desc), 0, C.byref(h)) == -1   # n_rows inconsistent
     desc = backend._Site(4, 1, 1, 7, 0, 0, G.ctypes.data_as(C.c_void_p), lim.ctypes.data_as(C.c_void_p))
