@@ -396,7 +396,16 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
 
   int status = 2, it = 0;
   real pri = M::big, dua = M::big;
-  bool done = false;
+  bool done = false, have_prev = false;
+  real y1p[CT][4], y2p[MT][CT][4];   // duals at the previous residual check (infeasibility certificate)
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      y1p[c][r] = 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) y2p[m][c][r] = 0;
+    }
   const real ptol_scale = M::proj_tol;
 
 #ifdef ACNQP_STAMPS
@@ -678,7 +687,143 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
       const real eps_p = (real)A.eps_abs + (real)A.eps_rel * npri;
       const real eps_d = (real)A.eps_abs + (real)A.eps_rel * ndua;
       if (pri <= eps_p && dua <= eps_d) { status = 1; done = true; }
-      else if (it >= A.max_iter) { done = true; }
+      if (!done && have_prev) {
+        // ---- primal infeasibility certificate (OSQP's, generalised to the sets B and C) -----------
+        // v = y - y(previous check).  If A'v ~ 0 and the support function of B x C at v is negative,
+        // no point of B x C can satisfy A r = z: infeasible.  For B the support function of a session
+        // is bounded above by phi(l) = l cap + sum_t [ub (v_t - l)+ + lb (v_t - l)-] for any admissible l.
+        real w6[3];
+        w6[0] = w6[1] = w6[2] = 0;   // |v|, |v1 + G'v2|, "unbounded direction" flag
+        real ssum = 0;               // support-function bound, summed over the block
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          vec4 gtv = {0, 0, 0, 0};
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              gtv = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * wave + t], y2[m][c][s] - y2p[m][c][s], gtv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const real v1 = y1[c][r] - y1p[c][r];
+            w6[0] = fmax(w6[0], fabs(v1));
+            w6[1] = fmax(w6[1], fabs(v1 + gtv[r]));
+          }
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const real v2 = y2[m][c][r] - y2p[m][c][r];
+              w6[0] = fmax(w6[0], fabs(v2));
+            }
+          }
+        }
+        block_max<real, 3>(w6, Red, lane, wave, NW);
+        const real vn = w6[0];
+        const real vtol = (real)1e-4 * vn;
+        if (vn > (real)1e-12 * fmax((real)1, qnorm) && w6[1] <= vtol) {
+          real bad = 0;
+          if (wave == 0) {   // the site-row state is replicated: count it once
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+              for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const real v2 = y2[m][c][r] - y2p[m][c][r];
+                  const int ty = rtype[m][r];
+                  if (ty == kRowBox) { ssum += limv[m][r] * fmax(v2, (real)0); if (v2 < -vtol) bad = 1; }
+                  else if (ty == kRowPeak) {
+                    if (pk[c] < M::big) ssum += pk[c] * fmax(v2, (real)0); else if (v2 > vtol) bad = 1;
+                    if (v2 < -vtol) bad = 1;
+                  } else if (ty == kRowSocRe) {
+                    const real vi = y2[m][c][(r + 1) & 3] - y2p[m][c][(r + 1) & 3];
+                    ssum += limv[m][r] * sqrt(v2 * v2 + vi * vi);
+                  } else if (ty == kRowSocIm) {
+                  } else if (fabs(v2) > vtol) bad = 1;   // free / quadratic rows admit no ray
+                }
+          }
+          // sessions: transpose v1 to session layout and bound each session's support function
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xw[(c * 16 + M::rowof(g, r)) * kXS + t] = y1[c][r] - y1p[c][r];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          real sv[CT][4];
+          unsigned covered = 0;
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) sv[c][tt] = Xw[(c * 16 + se) * kXS + 4 * sh + tt];
+#pragma unroll
+          for (int k = 0; k < KS; ++k) {
+            if (k == 0 || k < A.K) {
+              covered |= swm[k];
+              real lmin_l = M::big, lmax_l = -M::big;
+#pragma unroll
+              for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+                  if ((swm[k] >> (4 * c + tt)) & 1u) { lmin_l = fmin(lmin_l, sv[c][tt]); lmax_l = fmax(lmax_l, sv[c][tt]); }
+              real lam3[3];
+              lam3[0] = quarter_min<real>(lmin_l);
+              lam3[1] = quarter_max<real>(lmax_l);
+              lam3[2] = 0;
+              real best = M::big;
+#pragma unroll
+              for (int j = 0; j < 3; ++j) {
+                real l_ = lam3[j];
+                if (!eq) l_ = fmax(l_, (real)0);
+                real ph = 0;
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+#pragma unroll
+                  for (int tt = 0; tt < 4; ++tt)
+                    if ((swm[k] >> (4 * c + tt)) & 1u) {
+                      const real dv = sv[c][tt] - l_;
+                      ph += sub[c][tt] * fmax(dv, (real)0) + slb[c][tt] * fmin(dv, (real)0);
+                    }
+                ph = quarter_sum<real>(ph) + l_ * scap[k];
+                best = fmin(best, ph);
+              }
+              if (shas[k] && sh == 0) ssum += best;   // one lane per session
+            }
+          }
+          // periods outside every window are pinned to lb = ub (= 0): support lb * v
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+              if (!((covered >> (4 * c + tt)) & 1u)) ssum += slb[c][tt] * sv[c][tt];
+          __builtin_amdgcn_wave_barrier();
+          real tot = wave_sum<real>(ssum);
+          real bd[1] = {bad};
+          __syncthreads();
+          if (lane == 0) Red[wave * kNumRed + 7] = tot;
+          block_max<real, 1>(bd, Red, lane, wave, NW);
+          real stot = 0;
+          for (int wv = 0; wv < NW; ++wv) stot += Red[wv * kNumRed + 7];
+          __syncthreads();
+          if (bd[0] == (real)0 && stot < -vtol) { status = 3; done = true; }
+        }
+      }
+      if (!done) {   // snapshot for the next certificate test
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y1p[c][r] = y1[c][r];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) y2p[m][c][r] = y2[m][c][r];
+        have_prev = true;
+      }
+      if (done) {
+      } else if (it >= A.max_iter) { done = true; }
       else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
         const real sp = pri / fmax(npri, (real)1e-12);
         const real sd = dua / fmax(ndua, (real)1e-12);

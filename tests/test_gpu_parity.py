@@ -66,8 +66,11 @@ def test_tiny_infeasible_raises(kw):   # t_aco.py:119-175
     iface = tiny_interface(**kw)
     opt = AdaptiveChargingOptimization(DEFAULT_OBJECTIVE, iface, enforce_energy_equality=True,
                                        solver_options=dict(max_iter=20000))
-    with pytest.raises(InfeasibilityException, match="Solve failed with status"):
+    with pytest.raises(InfeasibilityException, match="Solve failed with status infeasible"):
         opt.solve(iface.active_sessions(), iface.infrastructure_info())
+    # detected by a certificate (empty session set, or the ADMM infeasibility certificate), not by
+    # running out of iterations
+    assert opt.last_result.status[0] in (3, 4) and opt.last_result.iters[0] < 5000
 
 
 def test_tiny_delayed_start():   # t_aco.py:178-191
@@ -435,3 +438,29 @@ def test_offline_algorithm_single_ev():   # shape of t_int.py:311-347
     assert alg.schedule([ev])["PS-1"][0] == pytest.approx(alg.internal_schedule["PS-1"][7])
     with pytest.raises(ValueError):
         alg.schedule([SimpleNamespace(station_id="PS-1", session_id="other")])
+
+
+def test_infeasibility_certificate_in_a_batch():
+    """A batch mixing feasible snapshots with infeasible ones (energy equality that the network cannot
+    carry): the infeasible ones end with the certificate status, the others are untouched."""
+    infra, iface = H.caltech_interface()
+    snaps = sites.snapshot_batch(infra, 12, 8, seed=5, demand_range=(0.5, 3.0))
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    # make problems 2 and 5 infeasible: every session must receive exactly 6.5 kWh within the hour
+    for b in (2, 5):
+        for s in snaps[b]:
+            s.requested_energy = 6.5 + s.energy_delivered
+            s.departure = s.arrival + 12
+            s.min_rates = np.zeros(12)
+            s.max_rates = np.full(12, 32.0)
+    opt = AdaptiveChargingOptimization(obj, iface, enforce_energy_equality=True, solver_options=dict(max_iter=20000))
+    feasible_batch = [snaps[b] for b in range(8) if b not in (2, 5)]
+    # equality rows need demand <= deliverable: keep only sessions that can be served
+    for sl in feasible_batch:
+        for s in sl:
+            s.requested_energy = min(s.requested_energy, 0.9 * 32 * s.remaining_time * 208 * 5 / 60 / 1e3) * 0.25
+    rates, status = opt.solve_batch(snaps, infra)
+    assert status[2] == 3 and status[5] == 3
+    ok = [b for b in range(8) if b not in (2, 5)]
+    assert (status[ok] == 1).all()
+    assert opt.last_result.iters[[2, 5]].max() < 5000
