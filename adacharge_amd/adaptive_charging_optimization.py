@@ -155,7 +155,7 @@ def demand_charge(rates, infrastructure, interface, baseline_peak=0, **kwargs):
 _HANDLE_CACHE = {}
 
 
-def _site_handle(infrastructure, constraint_type, with_peak, device, with_flat=False):
+def _site_handle(infrastructure, constraint_type, with_peak, device, with_flat=False, with_max=False):
     """One uploaded site per (infrastructure content, cone, peak, GPU).  The
     reference rebuilds every atom on every call (adacharge.py:152-158); here the
     site matrix is uploaded once and reused by all later MPC steps."""
@@ -168,11 +168,11 @@ def _site_handle(infrastructure, constraint_type, with_peak, device, with_flat=F
         None if infrastructure.constraint_limits is None else np.asarray(infrastructure.constraint_limits).tobytes(),
         None if infrastructure.phases is None else np.asarray(infrastructure.phases).tobytes(),
         np.asarray(infrastructure.voltages).tobytes(),
-        constraint_type, bool(with_peak), int(device), bool(with_flat),
+        constraint_type, bool(with_peak), int(device), bool(with_flat), bool(with_max),
     )
     ent = _HANDLE_CACHE.get(key)
     if ent is None:
-        site = make_site(infrastructure, constraint_type, with_peak=with_peak, with_flat=with_flat)
+        site = make_site(infrastructure, constraint_type, with_peak=with_peak, with_flat=with_flat, with_max=with_max)
         ent = (site, backend.SiteHandle(site, device))
         if len(_HANDLE_CACHE) > 64:
             _HANDLE_CACHE.clear()
@@ -290,11 +290,12 @@ class AdaptiveChargingOptimization:
             return rates, status
         pl = [None] * B if peak_limits is None else list(peak_limits)
         any_peak = any(pl[k] is not None for k in nonempty)
-        from .builder import _objective_needs_flat
+        from .builder import _objective_needs_flat, _objective_needs_max
 
         site, handle = _site_handle(
             infrastructure, self.constraint_type, any_peak, self.device,
             with_flat=_objective_needs_flat(self.objective_configuration),
+            with_max=_objective_needs_max(self.objective_configuration),
         )
         batch = build_batch(
             [session_lists[k] for k in nonempty], infrastructure, self.interface,

@@ -45,6 +45,7 @@ class _Site(C.Structure):
         ("cone", C.c_int32),
         ("has_peak", C.c_int32),
         ("has_flat", C.c_int32),
+        ("has_max", C.c_int32),
         ("G", C.c_void_p),
         ("limits", C.c_void_p),
     ]
@@ -66,6 +67,8 @@ class _Problems(C.Structure):
         ("s_eq", C.c_void_p),
         ("peak", C.c_void_p),
         ("lf", C.c_void_p),
+        ("dc", C.c_void_p),
+        ("dfloor", C.c_void_p),
     ]
 
 
@@ -208,7 +211,7 @@ class SiteHandle:
         lim = np.ascontiguousarray(site.limits, dtype=np.float64)
         desc = _Site(
             site.N, site.M, site.Mg, 1 if site.cone == CONE_SOC else 0, 1 if site.has_peak else 0,
-            1 if site.has_flat else 0,
+            1 if site.has_flat else 0, 1 if site.has_max else 0,
             _ptr(G) if G.size else None, _ptr(lim) if lim.size else None,
         )
         h = C.c_void_p()
@@ -230,7 +233,7 @@ class SiteHandle:
     def solve(self, batch: ProblemBatch, options: Optional[Options] = None) -> BatchResult:
         if batch.site is not self.site and (
             batch.site.Mg != self.site.Mg or batch.site.N != self.site.N or batch.site.cone != self.site.cone
-            or batch.site.has_flat != self.site.has_flat
+            or batch.site.has_flat != self.site.has_flat or batch.site.has_max != self.site.has_max
         ):
             raise ValueError("batch was built for a different site than this handle")
         o = options if options is not None else default_options()
@@ -248,9 +251,11 @@ class SiteHandle:
         )
         peak = None if batch.peak is None else np.ascontiguousarray(batch.peak, np.float64)
         lf = np.ascontiguousarray(batch.lf, np.float64) if self.site.has_flat else None
+        dc = np.ascontiguousarray(batch.dc, np.float64) if self.site.has_max else None
+        dfl = np.ascontiguousarray(batch.dfloor, np.float64) if self.site.has_max else None
         p = _Problems(B, Tm, batch.K, *[_ptr(arrs[k]) for k in
                                        ("horizon", "lb", "ub", "q", "pdiag", "s_off", "s_len", "s_cap", "s_eq")],
-                      _ptr(peak), _ptr(lf))
+                      _ptr(peak), _ptr(lf), _ptr(dc), _ptr(dfl))
         res = BatchResult(
             np.zeros((B, N, Tm)), np.zeros(B, np.int32), np.zeros(B, np.int32),
             np.zeros(B), np.zeros(B), np.zeros(B),
@@ -261,6 +266,10 @@ class SiteHandle:
         if self.site.has_flat:   # the kernel's obj covers pdiag and q; add 1/2 lf sum_t (v' x_t)^2
             v = self.site.G[self.site.flat_row]
             res.obj = res.obj + 0.5 * batch.lf * np.einsum("n,bnt->bt", v, res.x).__pow__(2).sum(axis=1)
+        if self.site.has_max:   # ... and dc * max(max_t v' x_t, dfloor)
+            v = self.site.G[self.site.max_row]
+            agg = np.einsum("n,bnt->bt", v, res.x)
+            res.obj = res.obj + batch.dc * np.maximum(agg.max(axis=1), batch.dfloor)
         if batch.presolve_status is not None:
             res.status[batch.presolve_status != 0] = STATUS_EMPTY_SET
         return res
@@ -274,6 +283,8 @@ class SiteHandle:
             dev.s_off.data_ptr(), dev.s_len.data_ptr(), dev.s_cap.data_ptr(), dev.s_eq.data_ptr(),
             None if dev.peak is None else dev.peak.data_ptr(),
             dev.lf.data_ptr() if self.site.has_flat else None,
+            dev.dc.data_ptr() if self.site.has_max else None,
+            dev.dfloor.data_ptr() if self.site.has_max else None,
         )
         r = _Results(dev.x.data_ptr(), dev.status.data_ptr(), dev.iters.data_ptr(),
                      dev.pri_res.data_ptr(), dev.dua_res.data_ptr(), dev.obj.data_ptr())
@@ -307,6 +318,8 @@ class DeviceBatch:
         self.s_eq = t(batch.s_eq, np.uint8)
         self.peak = None if batch.peak is None else t(batch.peak, np.float64)
         self.lf = t(batch.lf, np.float64)
+        self.dc = t(batch.dc if batch.dc is not None else np.zeros(batch.B), np.float64)
+        self.dfloor = t(batch.dfloor if batch.dfloor is not None else np.zeros(batch.B), np.float64)
         self.x = torch.zeros((self.B, self.N, self.Tm), dtype=torch.float64, device=dev)
         self.status = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.iters = torch.zeros(self.B, dtype=torch.int32, device=dev)

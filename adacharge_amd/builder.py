@@ -42,6 +42,7 @@ class SiteData:
     cone: int
     has_peak: bool
     has_flat: bool
+    has_max: bool
     G: np.ndarray
     limits: np.ndarray
     lam: np.ndarray
@@ -56,10 +57,16 @@ class SiteData:
     @property
     def flat_row(self) -> int:
         """Index of the aggregate-power row v = voltages/1e3 (load_flattening), if present."""
+        return self.Mg - 1 - (1 if self.has_peak else 0) - (1 if self.has_max else 0)
+
+    @property
+    def max_row(self) -> int:
+        """Index of the aggregate-power row used by demand_charge / peak, if present."""
         return self.Mg - 1 - (1 if self.has_peak else 0)
 
 
-def make_site(infrastructure, constraint_type: str = "SOC", with_peak: bool = False, with_flat: bool = False) -> SiteData:
+def make_site(infrastructure, constraint_type: str = "SOC", with_peak: bool = False, with_flat: bool = False,
+              with_max: bool = False) -> SiteData:
     N = len(infrastructure.station_ids)
     cm = infrastructure.constraint_matrix
     if cm is None or cm.shape == (0, 0):  # aco.py:145-149
@@ -87,6 +94,8 @@ def make_site(infrastructure, constraint_type: str = "SOC", with_peak: bool = Fa
         _bad_constraint_type(constraint_type)
     if with_flat:  # aggregate power in kW: charging_power / aggregate_power, aco.py:336-344
         rows = np.vstack([rows, np.asarray(infrastructure.voltages, float)[None, :] / 1e3])
+    if with_max:  # same aggregate-power row, used by the demand-charge prox (aco.py:387-400)
+        rows = np.vstack([rows, np.asarray(infrastructure.voltages, float)[None, :] / 1e3])
     if with_peak:
         rows = np.vstack([rows, np.ones((1, N))])
     G = np.ascontiguousarray(rows, dtype=np.float64)
@@ -99,7 +108,7 @@ def make_site(infrastructure, constraint_type: str = "SOC", with_peak: bool = Fa
     else:
         lam, Q, Ghat = np.zeros(0), np.zeros((0, 0)), np.zeros((0, N))
     return SiteData(
-        N, M, cone, bool(with_peak), bool(with_flat), G, limits, lam,
+        N, M, cone, bool(with_peak), bool(with_flat), bool(with_max), G, limits, lam,
         np.ascontiguousarray(Q), np.ascontiguousarray(Ghat),
         np.asarray(infrastructure.voltages, float).copy(),
     )
@@ -133,12 +142,20 @@ class ProblemBatch:
     s_cap: np.ndarray           # (B, K, N) f64    energy cap in A-periods
     s_eq: np.ndarray            # (B,) uint8       1 = energy rows are equalities
     peak: Optional[np.ndarray]  # (B, Tm) f64 or None; +inf = no limit in that period
+    dc: np.ndarray = None       # (B,) f64   weight of max(max_t v'r_t, dfloor)   (demand_charge / peak)
+    dfloor: np.ndarray = None   # (B,) f64   previous / baseline peak in kW
     const: np.ndarray = None    # (B,) f64 constant dropped from the objective
     presolve_status: np.ndarray = None  # (B,) int32, nonzero = infeasible before any solve
 
     @property
     def N(self) -> int:
         return self.site.N
+
+
+def _objective_needs_max(objective) -> bool:
+    from .adaptive_charging_optimization import demand_charge, peak
+
+    return any(c.function in (demand_charge, peak) and c.coefficient != 0 for c in objective)
 
 
 def _objective_needs_flat(objective) -> bool:
@@ -165,8 +182,15 @@ def objective_terms(objective, infrastructure, interface, N, T, prev_peak=0):
             "Objective is not concave: the maximised objective has a positive "
             "quadratic coefficient (cvxpy would reject it as non-DCP)."
         )
+    # epigraph terms: the maximised objective holds sum_e w_e * max(max_t agg_power_t, floor_e)
+    dcw, dfloor = 0.0, 0.0
+    if total.epigraph:
+        dcw = -sum(w for w, _ in total.epigraph)
+        if any(w > 0 for w, _ in total.epigraph):
+            raise ValueError("peak enters the maximised objective with a positive weight: not concave")
+        dfloor = max(spec["floor"] for _, spec in total.epigraph)
     # reference maximises `total`; we minimise its negation
-    return -total.lin, 2.0 * total.sq, 2.0 * total.flat, -total.const
+    return -total.lin, 2.0 * total.sq, 2.0 * total.flat, -total.const, dcw, dfloor
 
 
 def build_batch(
@@ -187,8 +211,11 @@ def build_batch(
         peak_limits = [None] * B
     any_peak = any(p is not None for p in peak_limits)
     need_flat = _objective_needs_flat(objective)
+    need_max = _objective_needs_max(objective)
     if site is None:
-        site = make_site(infrastructure, constraint_type, with_peak=any_peak, with_flat=need_flat)
+        site = make_site(infrastructure, constraint_type, with_peak=any_peak, with_flat=need_flat, with_max=need_max)
+    elif need_max and not site.has_max:
+        raise ValueError("site was built without the demand-charge row but the objective uses demand_charge / peak")
     elif need_flat and not site.has_flat:
         raise ValueError("site was built without the aggregate-power row but the objective uses load_flattening")
     elif any_peak and not site.has_peak:
@@ -215,6 +242,8 @@ def build_batch(
     pdiag = np.zeros(B)
     lf = np.zeros(B)
     const = np.zeros(B)
+    dc = np.zeros(B)
+    dfloor = np.zeros(B)
     s_off = np.zeros((B, K, N), dtype=np.int32)
     s_len = np.zeros((B, K, N), dtype=np.int32)
     s_cap = np.zeros((B, K, N))
@@ -253,11 +282,11 @@ def build_batch(
             s_len[b, k, i] = r
             kwh_per_amp_period = volt[i] * period / 1e3 / 60  # aco.py:114
             s_cap[b, k, i] = s.remaining_demand / kwh_per_amp_period
-        qb, pd, lfc, c0 = objective_terms(objective, infrastructure, interface, N, T, prev_peak)
+        qb, pd, lfc, c0, dcw, dfl = objective_terms(objective, infrastructure, interface, N, T, prev_peak)
         q[b, :, :T] = qb
-        pdiag[b], lf[b], const[b] = pd, lfc, c0
+        pdiag[b], lf[b], const[b], dc[b], dfloor[b] = pd, lfc, c0, dcw, dfl
         if peak is not None and peak_limits[b] is not None:  # aco.py:196-198
             peak[b, :T] = np.broadcast_to(np.asarray(peak_limits[b], float), (T,))
     return ProblemBatch(
-        site, B, Tm, K, Ts, lb, ub, q, pdiag, lf, s_off, s_len, s_cap, s_eq, peak, const, presolve
+        site, B, Tm, K, Ts, lb, ub, q, pdiag, lf, s_off, s_len, s_cap, s_eq, peak, dc, dfloor, const, presolve
     )

@@ -105,7 +105,7 @@ struct SiteDev {
 
 struct acnqp_handle {
   int device = 0;
-  int N = 0, M = 0, Mg = 0, cone = 0, has_peak = 0, has_flat = 0;
+  int N = 0, M = 0, Mg = 0, cone = 0, has_peak = 0, has_flat = 0, has_max = 0;
   int NW = 4, NP = 64;
   std::vector<double> G, limits;   // host copy in ABI order
   SiteDev dev64, dev32;
@@ -128,8 +128,8 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
   const bool f64 = sizeof(real) == 8;
   const int N = h->N, M = h->M, NP = h->NP;
   int raw;
-  if (h->cone == ACNQP_CONE_SOC) raw = (f64 ? 8 * ((M + 3) / 4) : 2 * M) + h->has_peak + h->has_flat;
-  else raw = M + h->has_peak + h->has_flat;
+  if (h->cone == ACNQP_CONE_SOC) raw = (f64 ? 8 * ((M + 3) / 4) : 2 * M) + h->has_peak + h->has_flat + h->has_max;
+  else raw = M + h->has_peak + h->has_flat + h->has_max;
   const int MR = 16 * ((raw + 15) / 16 > 0 ? (raw + 15) / 16 : 1);
   if (MR > 48) return fail(ACNQP_ERR_INVALID, "site has too many rows for the tiled kernel (> 48 after padding)");
   std::vector<double> Gi((size_t)MR * NP, 0.0), lim(MR, 0.0);
@@ -150,7 +150,8 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
     for (int c = 0; c < M; ++c) put(c, c, acnqp::kRowBox, h->limits[c]);
     peak_slot = M;
   }
-  if (h->has_flat) { put(peak_slot, h->Mg - 1 - h->has_peak, acnqp::kRowQuad, 0.0); ++peak_slot; }
+  if (h->has_flat) { put(peak_slot, h->Mg - 1 - h->has_peak - h->has_max, acnqp::kRowQuad, 0.0); ++peak_slot; }
+  if (h->has_max) { put(peak_slot, h->Mg - 1 - h->has_peak, acnqp::kRowMax, 0.0); ++peak_slot; }
   if (h->has_peak) put(peak_slot, h->Mg - 1, acnqp::kRowPeak, 0.0);
 
   std::vector<double> GGt((size_t)MR * MR, 0.0), lam, Q;
@@ -259,9 +260,9 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
     return fail(ACNQP_ERR_INVALID, "acnqp_create: n_evse must be in [1, 1024]");
   if (site->cone != ACNQP_CONE_LINEAR && site->cone != ACNQP_CONE_SOC)
     return fail(ACNQP_ERR_INVALID, "acnqp_create: cone must be ACNQP_CONE_LINEAR or ACNQP_CONE_SOC");
-  const int expect = (site->cone == ACNQP_CONE_SOC ? 2 * M : M) + (site->has_peak ? 1 : 0) + (site->has_flat ? 1 : 0);
+  const int expect = (site->cone == ACNQP_CONE_SOC ? 2 * M : M) + (site->has_peak ? 1 : 0) + (site->has_flat ? 1 : 0) + (site->has_max ? 1 : 0);
   if (M < 0 || Mg != expect || Mg > 48)
-    return fail(ACNQP_ERR_INVALID, "acnqp_create: n_rows inconsistent with n_infra/cone/has_peak/has_flat or > 48");
+    return fail(ACNQP_ERR_INVALID, "acnqp_create: n_rows inconsistent with n_infra/cone/has_peak/has_flat/has_max or > 48");
   if (Mg > 0 && !site->G) return fail(ACNQP_ERR_INVALID, "acnqp_create: G is null");
   if (M > 0 && !site->limits) return fail(ACNQP_ERR_INVALID, "acnqp_create: limits is null");
   for (int j = 0; j < M; ++j)
@@ -277,6 +278,7 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
   h->device = device_id;
   h->N = N; h->M = M; h->Mg = Mg; h->cone = site->cone; h->has_peak = site->has_peak ? 1 : 0;
   h->has_flat = site->has_flat ? 1 : 0;
+  h->has_max = site->has_max ? 1 : 0;
   h->NW = 4;
   h->NP = N <= 64 ? 64 : 16 * ((N + 15) / 16);
   h->G.assign(site->G, site->G + (size_t)Mg * N);
@@ -322,6 +324,7 @@ static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, 
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: null problem array");
   if (h->has_peak && !p->peak) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: site has a peak row but peak is null");
   if (h->has_flat && !p->lf) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: site has a flat row but lf is null");
+  if (h->has_max && (!p->dc || !p->dfloor)) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: site has a max row but dc/dfloor is null");
   if (!r->x || !r->status || !r->iters || !r->pri_res || !r->dua_res || !r->obj)
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: null result array");
   if (!(o->eps_abs >= 0) || !(o->eps_rel >= 0) || o->max_iter < 1 || o->check_every < 1 || !(o->rho > 0) ||
@@ -354,6 +357,8 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.horizon = p->horizon; a.lb = p->lb; a.ub = p->ub; a.q = p->q; a.pdiag = p->pdiag;
   a.s_off = p->s_off; a.s_len = p->s_len; a.s_cap = p->s_cap; a.s_eq = p->s_eq; a.peak = h->has_peak ? p->peak : nullptr;
   a.lf = h->has_flat ? p->lf : nullptr;
+  a.dc = h->has_max ? p->dc : nullptr;
+  a.dfloor = h->has_max ? p->dfloor : nullptr;
   a.x = r->x; a.status = r->status; a.iters = r->iters; a.pri = r->pri_res; a.dua = r->dua_res; a.obj = r->obj;
   a.eps_abs = o->eps_abs; a.eps_rel = o->eps_rel; a.rho0 = o->rho; a.sigma = o->sigma; a.alpha = o->alpha;
   a.adapt_tol = o->adapt_tol; a.reg_rel = o->reg_rel;
@@ -417,6 +422,8 @@ int acnqp_solve_batch(acnqp_handle* h, const acnqp_problems* p, const acnqp_opti
   const size_t o_eq = off; off += al(B);
   const size_t o_pk = off; off += al(p->peak ? B * Tm * 8 : 0);
   const size_t o_lf = off; off += al(p->lf ? B * 8 : 0);
+  const size_t o_dc = off; off += al(p->dc ? B * 8 : 0);
+  const size_t o_df = off; off += al(p->dfloor ? B * 8 : 0);
   HIP_TRY(h->in.reserve(off));
   size_t ooff = 0;
   const size_t r_x = ooff; ooff += al(nv * 8);
@@ -440,6 +447,8 @@ int acnqp_solve_batch(acnqp_handle* h, const acnqp_problems* p, const acnqp_opti
   HIP_TRY(hipMemcpyAsync(di + o_eq, p->s_eq, B, hipMemcpyHostToDevice, st));
   if (p->peak) HIP_TRY(hipMemcpyAsync(di + o_pk, p->peak, B * Tm * 8, hipMemcpyHostToDevice, st));
   if (p->lf) HIP_TRY(hipMemcpyAsync(di + o_lf, p->lf, B * 8, hipMemcpyHostToDevice, st));
+  if (p->dc) HIP_TRY(hipMemcpyAsync(di + o_dc, p->dc, B * 8, hipMemcpyHostToDevice, st));
+  if (p->dfloor) HIP_TRY(hipMemcpyAsync(di + o_df, p->dfloor, B * 8, hipMemcpyHostToDevice, st));
   acnqp_problems dp = *p;
   dp.lb = reinterpret_cast<const double*>(di + o_lb);
   dp.ub = reinterpret_cast<const double*>(di + o_ub);
@@ -452,6 +461,8 @@ int acnqp_solve_batch(acnqp_handle* h, const acnqp_problems* p, const acnqp_opti
   dp.s_eq = reinterpret_cast<const uint8_t*>(di + o_eq);
   dp.peak = p->peak ? reinterpret_cast<const double*>(di + o_pk) : nullptr;
   dp.lf = p->lf ? reinterpret_cast<const double*>(di + o_lf) : nullptr;
+  dp.dc = p->dc ? reinterpret_cast<const double*>(di + o_dc) : nullptr;
+  dp.dfloor = p->dfloor ? reinterpret_cast<const double*>(di + o_df) : nullptr;
   acnqp_results dr;
   dr.x = reinterpret_cast<double*>(dout + r_x);
   dr.status = reinterpret_cast<int32_t*>(dout + r_st);

@@ -201,6 +201,31 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
       y2[k] = rho * (zh2[k] - zn);
       z2[k] = zn;
     }
+    // demand charge: horizon-wide prox on the "max" row, one thread (the general kernel favours clarity)
+    if (A.dc != nullptr && (real)A.dc[b] > (real)0 && tid == 0) {
+      for (int r = 0; r < MR; ++r)
+        if (A.rowtype[r] == kRowMax) {
+          const real cw = (real)A.dc[b] * inv_rho, fl = A.dfloor ? (real)A.dfloor[b] : (real)0;
+          const real* zv = zh2 + r * T;
+          real vmax = -M::big;
+          for (int t = 0; t < T; ++t) vmax = fmax(vmax, zv[t]);
+          real tau = vmax - cw;
+          for (int guard = 0; guard < 200; ++guard) {
+            real S = 0, nn = 0;
+            for (int t = 0; t < T; ++t) if (zv[t] > tau) { S += zv[t] - tau; nn += 1; }
+            const real f = S - cw;
+            const real tn = nn > 0 ? tau + f / nn : vmax - cw;
+            if (fabs(f) <= M::proj_tol * fmax((real)1, cw) * (real)16 || tn == tau) break;
+            tau = tn;
+          }
+          const real lev = fmax(tau, fl);
+          for (int t = 0; t < T; ++t) {
+            const real zn = fmin(zv[t], lev);
+            y2[r * T + t] = rho * (zv[t] - zn);
+            z2[r * T + t] = zn;
+          }
+        }
+    }
     __syncthreads();
     for (int k = tid; k < n; k += kGenThreads) y1[k] = rho * (zh[k] - z1[k]);
     // ---- residuals, termination, rho adaptation ------------------------------------------------

@@ -51,6 +51,7 @@ constexpr int kRowBox = 1;     // z <= limit
 constexpr int kRowSocRe = 2;   // pairs with the next register (kRowSocIm): |(re, im)| <= limit
 constexpr int kRowSocIm = 3;
 constexpr int kRowPeak = 4;    // z <= peak[b][t]
+constexpr int kRowMax = 6;     // prox of dc * max(max_t z_t, floor) over the whole horizon (demand charge)
 constexpr int kRowQuad = 5;    // prox of 1/2 lf z^2 (load flattening): z = zh rho / (rho + lf)
 
 struct TiledArgs {
@@ -64,6 +65,7 @@ struct TiledArgs {
   const uint8_t* s_eq;
   const double* peak;
   const double* lf;
+  const double *dc, *dfloor;
   double* x;
   int32_t *status, *iters;
   double *pri, *dua, *obj;
@@ -347,6 +349,9 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
 
   const real pd_user = (real)A.pdiag[b];
   const real lfb = A.lf ? (real)A.lf[b] : (real)0;
+  const real dcb = A.dc ? (real)A.dc[b] : (real)0;
+  const real dfl = A.dfloor ? (real)A.dfloor[b] : (real)0;
+  real tau_max = 0;   // warm start of the demand-charge level
   const real sigma = (real)A.sigma, alpha = (real)A.alpha;
   real rho = (real)A.rho0;
   real qnorm, pd;
@@ -536,11 +541,72 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
           if (ty == kRowBox) zn = fmin(zhr[r], limv[mo][r]);
           else if (ty == kRowPeak) zn = fmin(zhr[r], pk[c]);
           else if (ty == kRowQuad) zn = zhr[r] * (rho / (rho + lfb));
+          // kRowMax: zn = zhr here; the horizon-wide prox follows the tile loop
           else if (ty == kRowSocRe || ty == kRowSocIm) zn = zhr[r] * scl[r >> 1];
           y2[mo][c][r] = rho * (zhr[r] - zn);
           z2[mo][c][r] = zn;
         }
       }
+    }
+    // ---- demand charge: prox of dc * max(max_t z_t, floor) over the whole horizon of the "max" row:
+    // z_t = min(zh_t, tau), tau = max(floor, root of sum_t (zh_t - tau)+ = dc / rho) (Newton on a convex
+    // piecewise-linear function; the row's 16 periods are the 16 lanes of a DPP row).
+    if (A.dc != nullptr && dcb > (real)0) {   // block-uniform
+      real zv[CT];
+      bool mine = false;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) zv[c] = 0;
+#pragma unroll
+      for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (rtype[mo][r] == kRowMax) {
+            mine = true;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) zv[c] = z2[mo][c][r];   // = zh of that row (left unprojected above)
+          }
+      const real cw = dcb * inv_rho;
+      real vmax_l = -M::big;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) vmax_l = (16 * c + t < Tm) ? fmax(vmax_l, zv[c]) : vmax_l;
+      const real vmax = row_max<real>(vmax_l);
+      real tau = tau_max;
+      bool need = mine;
+      int guard = 0;
+      while (__any(need)) {
+        ++guard;
+        real sl = 0;
+        float nl = 0.f;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const real dd = zv[c] - tau;
+          const bool on = (16 * c + t < Tm) && dd > (real)0;
+          sl += on ? dd : (real)0;
+          nl += on ? 1.f : 0.f;
+        }
+        const real S = row_sum<real>(sl);
+        const float nn = row_sum<float>(nl);
+        const real f = S - cw;
+        const real tn = nn > 0.f ? tau + f * (real)rcp_small(nn) : vmax - cw;
+        const bool fin = fabs(f) <= M::proj_tol * fmax((real)1, cw) * (real)16 || tn == tau || guard > 60;
+        tau = (need && !fin) ? tn : tau;
+        need = need && !fin;
+      }
+      tau_max = tau;
+      const real lev = fmax(tau, dfl);
+#pragma unroll
+      for (int mo = 0; mo < MT; ++mo)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (rtype[mo][r] == kRowMax) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+              const real zh_ = z2[mo][c][r];
+              const real zn = (16 * c + t < Tm) ? fmin(zh_, lev) : zh_;
+              y2[mo][c][r] = rho * (zh_ - zn);
+              z2[mo][c][r] = zn;
+            }
+          }
     }
 #pragma unroll
       for (int k = 0; k < KS; ++k) {

@@ -25,6 +25,8 @@
  *   plus, when the site carries a "flat" row v = voltages / 1e3 (kW per A), the objective term
  *               1/2 lf_b sum_t (v' r[:, t])^2                     (load_flattening, aco.py:403-408;
  *                                                                  its linear part is already in q)
+ *   and, when it carries a "max" row (same v), the objective term
+ *               dc_b * max(max_t v' r[:, t], dfloor_b)            (demand_charge / peak, aco.py:387-400)
  *
  * Layouts are C order: r, lb, ub, q are [batch][N][Tm] -- the (N, T) rates
  * matrix the reference returns at aco.py:321, one per problem.
@@ -38,7 +40,7 @@
 extern "C" {
 #endif
 
-#define ACNQP_ABI_VERSION 2
+#define ACNQP_ABI_VERSION 3
 
 /* cone of the infrastructure rows (constraint_type at aco.py:35, 151, 165) */
 #define ACNQP_CONE_LINEAR 0
@@ -65,14 +67,16 @@ typedef struct acnqp_handle acnqp_handle; /* opaque; one per (site, GPU) */
  *   LINEAR: |constraint_matrix| (n_infra rows)            aco.py:171
  *   SOC:    [C*cos(phi); C*sin(phi)] (2*n_infra rows)     aco.py:156-158
  *   then one row voltages/1e3 iff has_flat               aco.py:336-344, 406
+ *   then one row voltages/1e3 iff has_max                aco.py:387-400
  *   then one all-ones row iff has_peak                   aco.py:197          */
 typedef struct {
   int32_t n_evse;        /* N                                   */
   int32_t n_infra;       /* M: rows of constraint_matrix         */
-  int32_t n_rows;        /* rows of G = M or 2M, + has_flat + has_peak */
+  int32_t n_rows;        /* rows of G = M or 2M, + has_flat + has_max + has_peak */
   int32_t cone;          /* ACNQP_CONE_*                         */
   int32_t has_peak;      /* 0 / 1                                */
   int32_t has_flat;      /* 0 / 1: aggregate-power row for load_flattening */
+  int32_t has_max;       /* 0 / 1: aggregate-power row for demand_charge / peak */
   const double* G;       /* [n_rows * n_evse]                    */
   const double* limits;  /* [n_infra]  constraint_limits         */
 } acnqp_site;
@@ -94,6 +98,8 @@ typedef struct {
   const uint8_t* s_eq;     /* [B]        1: energy rows are equalities       */
   const double* peak;      /* [B*Tm] or NULL; +inf = unlimited period        */
   const double* lf;        /* [B] or NULL: weight of 1/2 lf (v' r_t)^2 (2 * load_flattening coefficient) */
+  const double* dc;        /* [B] or NULL: weight (>= 0) of max(max_t v' r_t, dfloor)  [$ per kW]     */
+  const double* dfloor;    /* [B] or NULL: previous / baseline peak in kW (aco.py:390-394)           */
 } acnqp_problems;
 
 typedef struct {

@@ -19,7 +19,7 @@
 #endif
 
 typedef struct {
-  int N, Tm, K, Mg, M, cone, has_peak, has_flat;
+  int N, Tm, K, Mg, M, cone, has_peak, has_flat, has_max;
   const double *G, *Ghat, *Q, *lam, *limits;  /* G,Ghat [Mg][N]; Q [Mg][Mg] (Q[r][k]) */
 } port_site;
 
@@ -68,16 +68,16 @@ static void project_window(int L, const double* v, const double* lb, const doubl
 
 /* returns status: 1 solved, 2 max_iter, 4 empty set */
 static int solve_one(const port_site* S, const port_opts* O, int horizon, const double* lb, const double* ub_in, const double* q,
-                     double pdiag_user, double lf, const int32_t* s_off, const int32_t* s_len, const double* s_cap, int eq,
+                     double pdiag_user, double lf, double dc, double dfloor, const int32_t* s_off, const int32_t* s_len, const double* s_cap, int eq,
                      const double* peak, double* xout, int* iters_out, double* pri_out, double* dua_out,
                      double* obj_out) {
   const int N = S->N, T = S->Tm, Mg = S->Mg, M = S->M, K = S->K;
   const int n = N * T, mt = Mg * T;
-  double* buf = (double*)calloc((size_t)(8 * n + 8 * mt + K * N * 3 + 4 * T + 16), sizeof(double));
+  double* buf = (double*)calloc((size_t)(8 * n + 8 * mt + K * N * 3 + 4 * T + Mg + 32), sizeof(double));
   double *x = buf, *z1 = x + n, *y1 = z1 + n, *r0 = y1 + n, *zh = r0 + n, *ub = zh + n, *xt = ub + n, *gty = xt + n;
   double *z2 = gty + n, *y2 = z2 + mt, *gx = y2 + mt, *w = gx + mt, *wh = w + mt, *gh0 = wh + mt, *eh = gh0 + mt,
          *hh = eh + mt;
-  double *mu = hh + mt, *slo = mu + K * N, *shi = slo + K * N, *tmpv = shi + K * N;
+  double *mu = hh + mt, *slo = mu + K * N, *shi = slo + K * N, *tmpv = shi + K * N, *zmaxrow = tmpv + Mg + 2;
   double qnorm = 0, ubmax = 0;
   for (int k = 0; k < n; ++k) {
     ub[k] = ub_in[k] < lb[k] ? lb[k] : ub_in[k];
@@ -161,15 +161,40 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
         }
       }
       if (S->has_flat) {   /* prox of 1/2 lf z^2 on the aggregate-power row */
-        const int r = Mg - 1 - S->has_peak;
+        const int r = Mg - 1 - S->has_peak - S->has_max;
         const double za = tmpv[r] * (rho / (rho + lf));
         y2[r * T + t] = rho * (tmpv[r] - za); z2[r * T + t] = za;
+      }
+      if (S->has_max) {   /* keep zhat of the demand-charge row; its prox couples all periods */
+        const int r = Mg - 1 - S->has_peak;
+        zmaxrow[t] = tmpv[r];
+        y2[r * T + t] = 0; z2[r * T + t] = tmpv[r];
       }
       if (S->has_peak) {
         const int r = Mg - 1;
         const double lim = peak ? fmin(peak[t], 1e300) : 1e300;
         const double za = fmin(tmpv[r], lim);
         y2[r * T + t] = rho * (tmpv[r] - za); z2[r * T + t] = za;
+      }
+    }
+    if (S->has_max && dc > 0) {   /* prox of dc * max(max_t z_t, floor) on the demand-charge row */
+      const int r = Mg - 1 - S->has_peak;
+      const double cw = dc * inv_rho;
+      double vmax = -1e300;
+      for (int t = 0; t < T; ++t) if (zmaxrow[t] > vmax) vmax = zmaxrow[t];
+      double tau = vmax - cw;
+      for (int guard = 0; guard < 200; ++guard) {
+        double Ssum = 0, nn = 0;
+        for (int t = 0; t < T; ++t) if (zmaxrow[t] > tau) { Ssum += zmaxrow[t] - tau; nn += 1; }
+        const double f = Ssum - cw;
+        const double tn = nn > 0 ? tau + f / nn : vmax - cw;
+        if (fabs(f) <= 1e-13 * fmax(1.0, cw) * 16 || tn == tau) break;
+        tau = tn;
+      }
+      const double lev = fmax(tau, dfloor);
+      for (int t = 0; t < T; ++t) {
+        const double zn = fmin(zmaxrow[t], lev);
+        y2[r * T + t] = rho * (zmaxrow[t] - zn); z2[r * T + t] = zn;
       }
     }
     const int check = (it % O->check_every == 0) || it >= O->max_iter;
@@ -215,7 +240,7 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
 
 /* Batch driver: same array layout as include/acn_qp.h (host pointers); `threads` OpenMP threads. */
 int admm_port_solve_batch(const port_site* S, const port_opts* O, int B, const int32_t* horizon, const double* lb, const double* ub,
-                          const double* q, const double* pdiag, const double* lf, const int32_t* s_off, const int32_t* s_len,
+                          const double* q, const double* pdiag, const double* lf, const double* dc, const double* dfloor, const int32_t* s_off, const int32_t* s_len,
                           const double* s_cap, const uint8_t* s_eq, const double* peak, double* x, int32_t* status,
                           int32_t* iters, double* pri, double* dua, double* obj, int threads) {
   const size_t nv = (size_t)S->N * S->Tm, ns = (size_t)S->K * S->N;
@@ -225,7 +250,7 @@ int admm_port_solve_batch(const port_site* S, const port_opts* O, int B, const i
 #endif
   for (int b = 0; b < B; ++b) {
     int it = 0;
-    status[b] = solve_one(S, O, horizon[b], lb + b * nv, ub + b * nv, q + b * nv, pdiag[b], lf ? lf[b] : 0.0, s_off + b * ns, s_len + b * ns,
+    status[b] = solve_one(S, O, horizon[b], lb + b * nv, ub + b * nv, q + b * nv, pdiag[b], lf ? lf[b] : 0.0, dc ? dc[b] : 0.0, dfloor ? dfloor[b] : 0.0, s_off + b * ns, s_len + b * ns,
                           s_cap + b * ns, s_eq[b] != 0, peak ? peak + (size_t)b * S->Tm : 0, x + b * nv, &it,
                           pri + b, dua + b, obj + b);
     iters[b] = it;

@@ -8,7 +8,7 @@ from .build import build_oracle
 
 
 class _Site(C.Structure):
-    _fields_ = [(k, C.c_int) for k in ("N", "Tm", "K", "Mg", "M", "cone", "has_peak", "has_flat")] + [
+    _fields_ = [(k, C.c_int) for k in ("N", "Tm", "K", "Mg", "M", "cone", "has_peak", "has_flat", "has_max")] + [
         (k, C.c_void_p) for k in ("G", "Ghat", "Q", "lam", "limits")
     ]
 
@@ -43,12 +43,14 @@ def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.003, sigma=1
     site = batch.site
     p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
     keep = [np.ascontiguousarray(a, np.float64) for a in (site.G, site.Ghat, site.Q, site.lam, site.limits)]
-    S = _Site(site.N, batch.Tm, batch.K, site.Mg, site.M, int(site.cone), int(site.has_peak), int(getattr(site, 'has_flat', False)), *[p(a) for a in keep])
+    S = _Site(site.N, batch.Tm, batch.K, site.Mg, site.M, int(site.cone), int(site.has_peak), int(getattr(site, 'has_flat', False)), int(getattr(site, 'has_max', False)), *[p(a) for a in keep])
     O = _Opts(eps_abs, eps_rel, rho, sigma, alpha, adapt_tol, reg_rel, max_iter, check_every, adapt_every)
     B, N, Tm = batch.B, site.N, batch.Tm
     arrs = [np.ascontiguousarray(batch.T, np.int32), np.ascontiguousarray(batch.lb, np.float64), np.ascontiguousarray(batch.ub, np.float64),
             np.ascontiguousarray(batch.q, np.float64), np.ascontiguousarray(batch.pdiag, np.float64),
             np.ascontiguousarray(batch.lf, np.float64),
+            np.ascontiguousarray(batch.dc if batch.dc is not None else np.zeros(batch.B), np.float64),
+            np.ascontiguousarray(batch.dfloor if batch.dfloor is not None else np.zeros(batch.B), np.float64),
             np.ascontiguousarray(batch.s_off, np.int32), np.ascontiguousarray(batch.s_len, np.int32),
             np.ascontiguousarray(batch.s_cap, np.float64), np.ascontiguousarray(batch.s_eq, np.uint8)]
     peak = None if batch.peak is None else np.ascontiguousarray(batch.peak, np.float64)

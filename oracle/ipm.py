@@ -332,7 +332,7 @@ def solve_reference_problem(prob, tol=1e-9, max_iter=100, verbose=False):
         tol=tol, max_iter=max_iter, verbose=verbose,
     )
     res.duals = (z, s)
-    return res.x.reshape(prob.N, prob.T), res
+    return prob.rates_of(res.x), res
 
 
 def solve_lp_highs(prob):
@@ -515,7 +515,7 @@ def polish(prob, rates, duals=None, act_tol=1e-5, max_rounds=25):
             break
         x = np.clip(xr, lb, ub)
     xr, cert = best
-    return xr.reshape(prob.N, prob.T), cert
+    return (xr if prob.n_extra else xr.reshape(prob.N, prob.T)), cert
 
 
 def solve_certified(prob, tol=1e-9, verbose=False):
@@ -526,7 +526,7 @@ def solve_certified(prob, tol=1e-9, verbose=False):
     r0, res = solve_reference_problem(prob, tol=tol, verbose=verbose)
     if res.status not in ("optimal", "optimal_inaccurate"):
         return r0, res, None
-    r1, cert = polish(prob, r0, duals=getattr(res, "duals", None))
+    r1, cert = polish(prob, res.x, duals=getattr(res, "duals", None))
     if cert.worst < 1e-7:
-        return r1, res, cert
+        return prob.rates_of(r1), res, cert
     return r0, res, cert

@@ -40,15 +40,24 @@ class RefProblem:
     A_eq: sp.csr_matrix
     b_eq: np.ndarray
     soc: List[Tuple[sp.csr_matrix, float]] = field(default_factory=list)
-    lb: Optional[np.ndarray] = None  # (N, T) copies of the bound arrays, for checks
+    lb: Optional[np.ndarray] = None  # bounds of every variable, flat (rates first, then extras)
     ub: Optional[np.ndarray] = None
+    n_extra: int = 0                 # epigraph variables appended after vec(rates) (demand_charge)
+    extra_obj: Optional[object] = None   # callable(rates) -> value of the epigraph term at its optimum
 
     @property
     def n(self):
-        return self.N * self.T
+        return self.N * self.T + self.n_extra
+
+    def rates_of(self, x):
+        return np.asarray(x, float).reshape(-1)[: self.N * self.T].reshape(self.N, self.T)
 
     def objective(self, rates: np.ndarray) -> float:
+        """Objective at a rates matrix (extras eliminated at their optimum) or at a full vector."""
         x = np.asarray(rates, float).reshape(-1)
+        if len(x) == self.N * self.T and self.n_extra:
+            nr = self.N * self.T
+            return float(0.5 * x @ (self.P[:nr, :nr] @ x) + self.q[:nr] @ x + self.extra_obj(x.reshape(self.N, self.T)))
         return float(0.5 * x @ (self.P @ x) + self.q @ x)
 
 
@@ -159,6 +168,8 @@ def objective_terms(objective_spec, infrastructure, interface, N, T):
             q += coef * prices[None, :] * (volt[:, None] / 1e3) * (interface.period / 60)
         elif name == "total_energy":  # aco.py:383-384
             q -= coef * (volt[:, None] / 1e3) * (interface.period / 60) * np.ones((1, T))
+        elif name in ("demand_charge", "peak"):  # aco.py:387-400 -- epigraph, handled by the caller
+            continue
         elif name == "load_flattening":  # aco.py:403-408
             ext = kwargs.get("external_signal")
             ext = np.zeros(T) if ext is None else np.asarray(ext, float)
@@ -205,8 +216,38 @@ def build_reference_problem(
         ub_rhs.append(b_e)
         A_eq, b_eq = sp.csr_matrix((0, n)), np.zeros(0)
     P, q = objective_terms(objective_spec, infrastructure, interface, N, T)
-    return RefProblem(
-        N, T, P, q,
-        sp.vstack(ub_blocks, format="csr"), np.concatenate(ub_rhs),
-        A_eq, b_eq, soc, lb, ub,
-    )
+    A_ub = sp.vstack(ub_blocks, format="csr")
+    b_ub = np.concatenate(ub_rhs)
+    lbf, ubf = lb.reshape(-1), ub.reshape(-1)
+    # demand_charge (aco.py:387-400): maximise -dc * max(max_t agg_power_t, prev_peak kW[, baseline_peak])
+    # = minimise dc * p with p >= v' r_t for all t, p >= floor.  One epigraph variable p appended.
+    dc_terms = [(coef, kw) for name, coef, kw in objective_spec if name in ("demand_charge", "peak")]
+    if dc_terms:
+        v = np.asarray(infrastructure.voltages, float) / 1e3
+        w = 0.0
+        floor = -np.inf
+        for (coef, kw), name in zip(dc_terms, [nm for nm, _, _ in objective_spec if nm in ("demand_charge", "peak")]):
+            prev = interface.get_prev_peak() * infrastructure.voltages[0] / 1000
+            base = kw.get("baseline_peak", 0)
+            floor = max(floor, max(prev, base) if base > 0 else prev)
+            w += coef * (interface.get_demand_charge() if name == "demand_charge" else -1.0)
+        if w < 0:
+            raise ValueError("peak enters the maximised objective with a positive sign: not concave")
+        big = 1e7
+        # bounds block stays [-I; I] over ALL variables so that oracle/ipm.polish can fix coordinates
+        A_rest = sp.hstack([A_ub[2 * n :], sp.csr_matrix((A_ub.shape[0] - 2 * n, 1))], format="csr")
+        rows = np.repeat(np.arange(T), N)
+        cols = (np.arange(N)[None, :] * T + np.arange(T)[:, None]).reshape(-1)
+        Apk = sp.hstack([sp.csr_matrix((np.tile(v, T), (rows, cols)), shape=(T, n)), -np.ones((T, 1))], format="csr")
+        I1 = sp.identity(n + 1, format="csr")
+        lbf = np.r_[lbf, floor]
+        ubf = np.r_[ubf, big]
+        A_ub = sp.vstack([-I1, I1, A_rest, Apk], format="csr")
+        b_ub = np.concatenate([-lbf, ubf, b_ub[2 * n :], np.zeros(T)])
+        A_eq = sp.hstack([A_eq, sp.csr_matrix((A_eq.shape[0], 1))], format="csr")
+        soc = [(sp.hstack([F, sp.csr_matrix((2, 1))], format="csr"), g) for F, g in soc]
+        P = sp.block_diag([P, sp.csr_matrix((1, 1))], format="csr")
+        q = np.r_[q, w]
+        extra = lambda r, v=v, w=w, floor=floor: w * max(float((v @ r).max()), floor)
+        return RefProblem(N, T, P, q, A_ub, b_ub, A_eq, b_eq, soc, lbf, ubf, 1, extra)
+    return RefProblem(N, T, P, q, A_ub, b_ub, A_eq, b_eq, soc, lbf, ubf)

@@ -26,7 +26,7 @@ def test_header_symbols_all_exported(hip_library):
 
 
 def test_abi_version_and_defaults(hip_library):
-    assert hip_library.acnqp_abi_version() == 2
+    assert hip_library.acnqp_abi_version() == 3
     o = backend.default_options()
     assert o.precision == 64 and 0 < o.alpha < 2 and o.max_iter > 0 and o.eps_abs > 0
     o2 = backend.default_options(eps_abs=1e-9, max_iter=5)
@@ -41,11 +41,11 @@ def test_create_rejects_bad_arguments(hip_library):
     assert b"null" in hip_library.acnqp_last_error()
     G = np.ones((1, 2000))
     lim = np.ones(1)
-    desc = backend._Site(2000, 1, 1, 0, 0, 0, G.ctypes.data_as(C.c_void_p), lim.ctypes.data_as(C.c_void_p))
+    desc = backend._Site(2000, 1, 1, 0, 0, 0, 0, G.ctypes.data_as(C.c_void_p), lim.ctypes.data_as(C.c_void_p))
     assert hip_library.acnqp_create(C.byref(desc), 0, C.byref(h)) == -1   # N > 1024
-    desc = backend._Site(4, 1, 3, 0, 0, 0, G.ctypes.data_as(C.c_void_p), lim.ctypes.data_as(C.c_void_p))
+    desc = backend._Site(4, 1, 3, 0, 0, 0, 0, G.ctypes.data_as(C.c_void_p), lim.ctypes.data_as(C.c_void_p))
     assert hip_library.acnqp_create(C.byref(desc), 0, C.byref(h)) == -1   # n_rows inconsistent
-    desc = backend._Site(4, 1, 1, 7, 0, 0, G.ctypes.data_as(C.c_void_p), lim.ctypes.data_as(C.c_void_p))
+    desc = backend._Site(4, 1, 1, 7, 0, 0, 0, G.ctypes.data_as(C.c_void_p), lim.ctypes.data_as(C.c_void_p))
     assert hip_library.acnqp_create(C.byref(desc), 0, C.byref(h)) == -1   # bad cone
     assert hip_library.acnqp_solve_batch(None, None, None, None) == -1
     assert hip_library.acnqp_last_kernel_ms(None) < 0

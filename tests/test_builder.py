@@ -69,15 +69,15 @@ def test_builder_matches_reference_statement(ct, eq, peak):
     batch = build_batch([sl], infra, iface, obj, ct, eq, peak_limits=[pk])
     prob = build_reference_problem(sl, infra, iface, spec, ct, eq, pk)
     assert batch.Tm == prob.T and batch.N == prob.N
-    assert np.array_equal(batch.lb[0], prob.lb) and np.array_equal(batch.ub[0], prob.ub)
+    assert np.array_equal(batch.lb[0].reshape(-1), prob.lb) and np.array_equal(batch.ub[0].reshape(-1), prob.ub)
     for _ in range(20):
-        x = rng.uniform(-2, 34, size=(prob.N, prob.T)) * (prob.ub > 0)
+        x = rng.uniform(-2, 34, size=(prob.N, prob.T)) * (prob.ub.reshape(prob.N, prob.T) > 0)
         assert abs(structured_objective(batch, 0, x) - prob.objective(x)) <= 1e-9 * (1 + abs(prob.objective(x)))
         sv, rv = structured_violation(batch, 0, x, infra), reference_violation(prob, x)
         # energy rows are scaled (A-periods vs kWh): compare feasibility verdicts and magnitudes loosely
         assert (sv <= 1e-9) == (rv <= 1e-9)
     # a feasible point for one is feasible for the other
-    x = np.minimum(prob.ub, 0.2) * 0 + prob.lb
+    x = prob.lb.reshape(prob.N, prob.T).copy()
     assert (structured_violation(batch, 0, x, infra) <= 1e-9) == (reference_violation(prob, x) <= 1e-9)
 
 

@@ -464,3 +464,38 @@ def test_infeasibility_certificate_in_a_batch():
     ok = [b for b in range(8) if b not in (2, 5)]
     assert (status[ok] == 1).all()
     assert opt.last_result.iters[[2, 5]].max() < 5000
+
+
+# ---- demand_charge / peak (aco.py:387-400): horizon-wide prox of dc * max(max_t power_t, floor) -----
+@pytest.mark.parametrize("ct,T", [("SOC", 12), ("LINEAR", 12), ("SOC", 24), ("LINEAR", 40)])
+def test_demand_charge_matches_oracle(ct, T):
+    from adacharge_amd import demand_charge, total_energy
+    from adacharge_amd.acn import Interface
+    from oracle.ipm import solve_certified
+    from oracle.ref_problem import build_reference_problem
+
+    infra = sites.caltech54()
+    iface = Interface({"infrastructure_info": infra, "period": 5, "demand_charge": 15.0, "prev_peak": 50.0})
+    obj = [ObjectiveComponent(total_energy, 20.0), ObjectiveComponent(demand_charge), ObjectiveComponent(equal_share, 1e-3)]
+    spec = [("total_energy", 20.0, {}), ("demand_charge", 1.0, {}), ("equal_share", 1e-3, {})]
+    sl = sites.random_sessions(infra, T, np.random.default_rng(3))
+    opt = AdaptiveChargingOptimization(obj, iface, constraint_type=ct, solver_options=dict(reg_rel=0.0))
+    rates = opt.solve(sl, infra)
+    prob = build_reference_problem(sl, infra, iface, spec, ct)
+    ref, _, cert = solve_certified(prob)
+    assert cert is not None and cert.worst < 1e-7
+    v = infra.voltages / 1e3
+    assert abs((v @ rates).max() - (v @ ref).max()) <= 1e-4
+    assert np.abs(rates - ref).max() <= RATE_TOL, np.abs(rates - ref).max()
+    assert abs(opt.last_result.obj[0] - prob.objective(ref)) <= 1e-6 * abs(prob.objective(ref))
+
+
+def test_peak_objective_sign_is_checked():
+    from adacharge_amd import peak
+    from adacharge_amd.acn import Interface
+
+    infra = sites.caltech54()
+    iface = Interface({"infrastructure_info": infra, "period": 5, "prev_peak": 0.0})
+    sl = sites.random_sessions(infra, 12, np.random.default_rng(1))
+    with pytest.raises(ValueError, match="not concave"):
+        AdaptiveChargingOptimization([ObjectiveComponent(peak, 1.0)], iface).solve(sl, infra)
