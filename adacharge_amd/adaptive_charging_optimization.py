@@ -220,6 +220,75 @@ class AdaptiveChargingOptimization:
     # reference's own test tolerances (1e-7 on the peak row, t_aco.py:257) hold
     _SINGLE_DEFAULTS = dict(eps_abs=1e-9, eps_rel=1e-9, max_iter=100000)
 
+    # -- the reference's constraint builders (aco.py:45-198) -----------------------------------
+    # They return cvxpy constraints there; here they return the numeric description of the same
+    # constraint blocks (the arrays the C-ABI consumes), keyed exactly like the reference's dicts.
+    @staticmethod
+    def charging_rate_bounds(rates, active_sessions, evse_index):
+        """aco.py:45-79: ``lb <= rates <= ub``; later sessions overwrite their own window and
+        ``ub < lb`` is replaced by ``lb``."""
+        lb, ub = np.zeros(rates.shape), np.zeros(rates.shape)
+        for session in active_sessions:
+            i = evse_index.index(session.station_id)
+            w = slice(session.arrival_offset, session.arrival_offset + session.remaining_time)
+            lb[i, w] = session.min_rates
+            ub[i, w] = session.max_rates
+        ub[ub < lb] = lb[ub < lb]
+        return {"charging_rate_bounds.lb": lb, "charging_rate_bounds.ub": ub}
+
+    @staticmethod
+    def energy_constraints(rates, active_sessions, infrastructure, period, enforce_energy_equality=False):
+        """aco.py:81-124: one row per session, ``coef * sum(rates[i, off:off+len]) <= (==) rhs``."""
+        out = {}
+        for session in active_sessions:
+            i = infrastructure.get_station_index(session.station_id)
+            out[f"energy_constraints.{session.session_id}"] = dict(
+                evse=i, offset=session.arrival_offset, length=session.remaining_time,
+                coefficient=infrastructure.voltages[i] * period / 1e3 / 60,
+                rhs=session.remaining_demand, equality=bool(enforce_energy_equality),
+            )
+        return out
+
+    @staticmethod
+    def infrastructure_constraints(rates, infrastructure, constraint_type="SOC"):
+        """aco.py:126-179: per constraint id, the row(s) applied to every period and the limit."""
+        from .builder import _bad_constraint_type
+
+        cm = infrastructure.constraint_matrix
+        if cm is None or cm.shape == (0, 0):
+            return {}
+        out = {}
+        if constraint_type == "SOC":
+            if infrastructure.phases is None:
+                raise ValueError("phases is required when using SOC infrastructure constraints.")
+            ph = np.deg2rad(infrastructure.phases)
+            for j, v in enumerate(cm):
+                out[f"infrastructure_constraints.{infrastructure.constraint_ids[j]}"] = dict(
+                    rows=np.stack([v * np.cos(ph), v * np.sin(ph)]), norm="l2", limit=infrastructure.constraint_limits[j])
+        elif constraint_type == "LINEAR":
+            for j, v in enumerate(cm):
+                out[f"infrastructure_constraints.{infrastructure.constraint_ids[j]}"] = dict(
+                    rows=np.abs(v)[None, :], norm="linear", limit=infrastructure.constraint_limits[j])
+        else:
+            _bad_constraint_type(constraint_type)
+        return out
+
+    @staticmethod
+    def peak_constraint(rates, peak_limit):
+        """aco.py:181-198: ``sum(rates, axis=0) <= peak_limit`` if a limit is given."""
+        if peak_limit is not None:
+            return {"peak_constraint": np.broadcast_to(np.asarray(peak_limit, float), (rates.shape[1],)).copy()}
+        return {}
+
+    def build_objective(self, rates, infrastructure, **kwargs):
+        """aco.py:200-218: weighted sum of the objective components (a ``QuadObjective``)."""
+        obj = QuadObjective.zero(rates.shape)
+        for component in self.objective_configuration:
+            merged = dict(kwargs)
+            merged.update(component.kwargs)
+            obj = obj + component.coefficient * component.function(rates, infrastructure, self.interface, **merged)
+        return obj
+
     def build_problem(
         self,
         active_sessions,

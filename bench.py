@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--precision", type=int, default=64, choices=[64, 32])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --one-device rehearses the N > 1 path on a single-GPU box")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -147,11 +150,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists by design)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from adacharge_amd import ObjectiveComponent, equal_share, quick_charge, sites
     from adacharge_amd.acn import Interface
@@ -170,14 +178,18 @@ def main():
     if args.precision == 32:
         opts.eps_abs = opts.eps_rel = 5e-5
     stream = torch.cuda.current_stream().cuda_stream
+    gdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
     gathered = (
-        torch.empty((world * B, batch.N, batch.Tm), dtype=torch.float64, device=dev) if world > 1 else None
+        torch.empty((world * B, batch.N, batch.Tm), dtype=torch.float64, device=gdev) if world > 1 else None
     )
 
     def step():
         handle.solve_device(dbatch, opts, stream=stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, dbatch.x)
+        if world > 1:   # the one collective of the job: every rank ends up with all schedules
+            if args.dist_backend == "nccl":
+                dist.all_gather_into_tensor(gathered, dbatch.x)
+            else:
+                dist.all_gather(list(gathered.chunk(world)), dbatch.x.cpu())
 
     def fence():
         torch.cuda.synchronize()
@@ -196,7 +208,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -205,11 +217,11 @@ def main():
     iters = dbatch.iters.cpu().numpy()
     solved = int((status == 1).sum())
     if world > 1:
-        cnt = torch.tensor([solved, B], dtype=torch.int64, device=dev)
+        cnt = torch.tensor([solved, B], dtype=torch.int64, device=gdev)
         dist.all_reduce(cnt)
         solved_all, total_all = int(cnt[0]), int(cnt[1])
         if rank == 0:   # the gather really carries every rank's schedules
-            assert torch.equal(gathered[:B], dbatch.x)
+            assert torch.equal(gathered[:B].to(dev), dbatch.x)
     else:
         solved_all, total_all = solved, B
 

@@ -35,7 +35,7 @@ def max_threads():
     return int(_load().admm_port_max_threads())
 
 
-def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.003, sigma=1e-6, alpha=1.6, adapt_tol=5.0,
+def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.01, sigma=1e-6, alpha=1.4, adapt_tol=5.0,
                 reg_rel=0.06, max_iter=20000, check_every=20, adapt_every=40):
     """Solve a builder.ProblemBatch-like object on the CPU; same defaults as
     acnqp_default_options.  Returns dict of arrays."""

@@ -151,3 +151,31 @@ def test_site_eigen_identity():
         D = rho / (a + rho * site.lam)
         Kinv = (np.eye(site.N) - site.Ghat.T @ (D[:, None] * site.Ghat)) / a
         assert np.abs(Kinv @ K - np.eye(site.N)).max() < 1e-10
+
+
+def test_reference_constraint_builder_names():
+    """The static builders keep the reference's names and dict keys (aco.py:45-218)."""
+    from adacharge_amd import AdaptiveChargingOptimization, Rates, QuadObjective
+
+    infra, iface = caltech_interface()
+    sl = sites.random_sessions(infra, 12, np.random.default_rng(2), min_rate_fraction=0.3)
+    rates = Rates((54, 12))
+    b = AdaptiveChargingOptimization.charging_rate_bounds(rates, sl, infra.station_ids)
+    batch = build_batch([sl], infra, iface, [ObjectiveComponent(quick_charge)], "SOC")
+    assert np.array_equal(b["charging_rate_bounds.lb"], batch.lb[0]) and np.array_equal(b["charging_rate_bounds.ub"], batch.ub[0])
+    e = AdaptiveChargingOptimization.energy_constraints(rates, sl, infra, 5, True)
+    assert len(e) == len(sl) and all(k.startswith("energy_constraints.") for k in e)
+    s0 = sl[0]
+    row = e[f"energy_constraints.{s0.session_id}"]
+    assert row["equality"] and abs(row["rhs"] / row["coefficient"] - batch.s_cap[0, 0, row["evse"]]) < 1e-9
+    ic = AdaptiveChargingOptimization.infrastructure_constraints(rates, infra, "SOC")
+    assert list(ic) == [f"infrastructure_constraints.{c}" for c in infra.constraint_ids]
+    assert np.allclose(ic["infrastructure_constraints.Pri-A"]["rows"], np.stack([batch.site.G[5], batch.site.G[13]]))
+    assert AdaptiveChargingOptimization.infrastructure_constraints(rates, infra, "LINEAR")["infrastructure_constraints.Pri-A"]["norm"] == "linear"
+    with pytest.raises(ValueError, match="SOC or AFFINE"):
+        AdaptiveChargingOptimization.infrastructure_constraints(rates, infra, "AFFINE")
+    assert AdaptiveChargingOptimization.peak_constraint(rates, None) == {}
+    assert AdaptiveChargingOptimization.peak_constraint(rates, 100.0)["peak_constraint"].shape == (12,)
+    opt = AdaptiveChargingOptimization([ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 0.5)], iface)
+    o = opt.build_objective(rates, infra, prev_peak=0)
+    assert isinstance(o, QuadObjective) and o.sq == 0.5 and np.allclose(o.lin[0], [(12 - t) / 12 for t in range(12)])
