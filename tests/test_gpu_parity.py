@@ -499,3 +499,75 @@ def test_peak_objective_sign_is_checked():
     sl = sites.random_sessions(infra, 12, np.random.default_rng(1))
     with pytest.raises(ValueError, match="not concave"):
         AdaptiveChargingOptimization([ObjectiveComponent(peak, 1.0)], iface).solve(sl, infra)
+
+
+# ---- BASELINE.json configs[4] shape: synthetic 512-EVSE site, horizon 48, load_flattening ---------
+def test_config5_shape_synth512_load_flattening():
+    from adacharge_amd import load_flattening, total_energy
+    from adacharge_amd.acn import Interface
+    from oracle import admm_port
+
+    infra = sites.synth512()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    T = 48
+    ext = 150.0 + 100.0 * np.cos(np.arange(T) / T * 2 * np.pi)
+    obj = [ObjectiveComponent(load_flattening, 1.0, {"external_signal": ext}), ObjectiveComponent(total_energy, 600.0),
+           ObjectiveComponent(equal_share, 1e-3)]
+    snaps = sites.snapshot_batch(infra, T, 2, seed=512, min_sessions=200)
+    batch = build_batch(snaps, infra, iface, obj, "SOC")
+    assert batch.N == 512 and batch.Tm == 48 and batch.site.has_flat
+    h = SiteHandle(batch.site, 0)
+    res = h.solve(batch, default_options(eps_abs=1e-6, eps_rel=1e-6, reg_rel=0.0, max_iter=20000))
+    assert (res.status == 1).all()
+    ref = admm_port.solve_batch(batch, threads=2, eps_abs=1e-6, eps_rel=1e-6, reg_rel=0.0)
+    assert (ref["status"] == 1).all()
+    assert np.abs(ref["x"] - res.x).max() <= 1e-4
+    ph = np.deg2rad(infra.phases)
+    cm = infra.constraint_matrix
+    mag = np.hypot(np.einsum("mn,bnt->bmt", cm * np.cos(ph), res.x), np.einsum("mn,bnt->bmt", cm * np.sin(ph), res.x))
+    assert (mag <= infra.constraint_limits[None, :, None] * (1 + 1e-4) + 1e-2).all()
+    h.close()
+
+
+# ---- closed loop (shape of the reference's integration tests, t_int.py:16-48, without acnsim) ------
+def test_closed_loop_mpc_delivers_all_energy():
+    """A minimal plant: every period the algorithm schedules the plugged-in EVs, the first-period
+    pilot is applied, delivered energy is integrated.  Invariants of t_int.py: pilots feasible for the
+    network every period, no charging while unplugged, >= 99.99 % of the requested energy delivered."""
+    from adacharge_amd import AdaptiveSchedulingAlgorithm
+    from adacharge_amd.acn import Interface, SessionInfo
+
+    infra = sites.caltech54()
+    rng = np.random.default_rng(42)
+    period, horizon_total = 5, 60
+    k = infra.voltages[0] * period / 1e3 / 60
+    evs = []
+    for n, i in enumerate(rng.choice(54, size=30, replace=False)):
+        arr = int(rng.integers(0, 30))
+        dur = int(rng.integers(10, 25))
+        evs.append(dict(station=infra.station_ids[int(i)], sid=f"ev{n}", arrival=arr, departure=arr + dur,
+                        requested=float(rng.uniform(1.0, 0.5 * 32 * dur * k)), delivered=0.0))
+    iface = Interface({"infrastructure_info": infra, "period": period, "current_time": 0, "active_sessions": []})
+    alg = AdaptiveSchedulingAlgorithm([ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)],
+                                      solver="ECOS")
+    alg.register_interface(iface)
+    applied = np.zeros((54, horizon_total))
+    for t in range(horizon_total):
+        active = [e for e in evs if e["arrival"] <= t < e["departure"] and e["requested"] - e["delivered"] > 1e-9]
+        iface.data["current_time"] = t
+        iface.data["active_sessions"] = [
+            SessionInfo(e["station"], e["sid"], e["requested"], e["delivered"], e["arrival"], e["departure"],
+                        current_time=t, max_rates=32.0) for e in active]
+        sched = alg.run()
+        for e in active:
+            r = float(sched[e["station"]][0])
+            applied[infra.get_station_index(e["station"]), t] = r
+            e["delivered"] = min(e["requested"], e["delivered"] + r * k)
+    assert iface.is_feasible({sid: applied[i] for i, sid in enumerate(infra.station_ids)})
+    plugged = np.zeros_like(applied, dtype=bool)
+    for e in evs:
+        plugged[infra.get_station_index(e["station"]), e["arrival"] : e["departure"]] = True
+    assert np.allclose(applied[~plugged], 0)
+    total_req = sum(e["requested"] for e in evs)
+    total_del = sum(e["delivered"] for e in evs)
+    assert total_del / total_req >= 0.9999
