@@ -192,11 +192,11 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
   return ACNQP_OK;
 }
 
-template <typename real, int NW, int CT, int MT, int KS>
-hipError_t launch_tiled(const acnqp::TiledArgs& a, hipStream_t st) {
+template <typename real, int NW, int CT, int MT, int KS, int OCC>
+hipError_t launch_tiled_occ(const acnqp::TiledArgs& a, hipStream_t st) {
   const acnqp::TiledLds L(NW, MT, CT, a.NP, a.K);
   const size_t lds = (size_t)L.total * sizeof(real);
-  auto kern = &acnqp::admm_tiled_kernel<real, NW, CT, MT, KS>;
+  auto kern = &acnqp::admm_tiled_kernel<real, NW, CT, MT, KS, OCC>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -204,6 +204,17 @@ hipError_t launch_tiled(const acnqp::TiledArgs& a, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3(a.B), dim3(NW * 64), lds, st, a);
   return hipGetLastError();
+}
+
+// Two register budgets of the same kernel: one workgroup per CU with the whole register file
+// (latency-optimal when the batch does not exceed the 256 CUs), or two per CU (throughput-optimal for
+// larger batches: the second workgroup hides the first one's dependent-chain latency).
+template <typename real, int NW, int CT, int MT, int KS>
+hipError_t launch_tiled(const acnqp::TiledArgs& a, hipStream_t st) {
+  if constexpr (CT == 1 && MT <= 2 && KS == 1) {
+    if (a.B > 256) return launch_tiled_occ<real, NW, CT, MT, KS, 2>(a, st);
+  }
+  return launch_tiled_occ<real, NW, CT, MT, KS, 1>(a, st);
 }
 
 template <typename real, int NW, int CT, int MT>

@@ -42,6 +42,10 @@ __device__ unsigned long long g_stamps[1024 * 16 * 12];
 #define STAMP(slot) do {} while (0)
 #endif
 
+#ifndef ACNQP_GUARD_MAX
+#define ACNQP_GUARD_MAX 120   // safety bound on water-filling passes per session and iteration
+#endif
+
 constexpr int kMaxK = 4;       // session slots per EVSE
 constexpr int kNumRed = 8;
 
@@ -218,8 +222,8 @@ __device__ inline void block_max(real (&v)[NV], real* Red, int lane, int wave, i
 }
 
 // ---------------------------------------------------------------------------------------
-template <typename real, int NW, int CT, int MT, int KS>
-__global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) {
+template <typename real, int NW, int CT, int MT, int KS, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArgs A) {
   using M = Mfma<real>;
   using vec4 = typename M::vec4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
             const real gs = quarter_sum<real>(gl);
             const float nf = quarter_sum<float>(nl);
             const real d = gs - cap;
-            const bool fin = fabs(d) <= tol || (!eq && m <= (real)0 && d <= (real)0) || guard > 120;
+            const bool fin = fabs(d) <= tol || (!eq && m <= (real)0 && d <= (real)0) || guard > ACNQP_GUARD_MAX;
             need = need && !fin;
             lo = (need && d > 0) ? m : lo;
             hi = (need && !(d > 0)) ? m : hi;
@@ -677,6 +681,8 @@ __global__ __launch_bounds__(NW * 64) void admm_tiled_kernel(const TiledArgs A) 
               }
             { const Pair32 p = swap_u32<16>(moved); moved = p.a | p.b; }
             { const Pair32 q = swap_u32<32>(moved); moved = q.a | q.b; }
+            // no representable progress (the residual sits at rounding level, typical in fp32): stop
+            need = need && cand != m;
             m = need ? cand : m;
             need = need && !(newton && moved == 0u);
           };
