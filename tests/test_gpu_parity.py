@@ -571,3 +571,78 @@ def test_closed_loop_mpc_delivers_all_energy():
     total_req = sum(e["requested"] for e in evs)
     total_del = sum(e["delivered"] for e in evs)
     assert total_del / total_req >= 0.9999
+
+
+# ---- randomised cross-check of rarely used paths against the independent C port -----------------
+def _random_sessions_general(infra, T, rng, two_per_evse, min_rates, demand_scale):
+    from adacharge_amd.acn import SessionInfo
+
+    k = 208 * 5 / 60 / 1e3
+    sessions = []
+    n = infra.num_stations
+    for i in rng.choice(n, size=int(rng.integers(n // 3, n + 1)), replace=False):
+        sid = infra.station_ids[int(i)]
+        if two_per_evse and rng.random() < 0.4 and T >= 8:
+            cut = int(rng.integers(3, T - 3))
+            spans = [(0, cut), (cut + int(rng.integers(0, 2)), T)]
+        else:
+            a = int(rng.integers(0, max(1, T // 3)))
+            spans = [(a, int(rng.integers(a + 1, T + 1)))]
+        for j, (a, d) in enumerate(spans):
+            if d <= a:
+                continue
+            L = d - a
+            mins = np.zeros(L)
+            if min_rates and rng.random() < 0.3:
+                mins[: int(rng.integers(1, L + 1))] = 6.0
+            maxs = np.full(L, 32.0)
+            if rng.random() < 0.2:
+                maxs[int(rng.integers(0, L)):] = 16.0
+            dem = float(rng.uniform(0.2, 1.0) * demand_scale * 32 * L * k)
+            dem = max(dem, mins.sum() * k + 0.01)
+            sessions.append(SessionInfo(sid, f"{sid}-{j}", dem, 0.0, a, d, current_time=0, min_rates=mins, max_rates=maxs))
+    return sessions
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_randomised_paths_match_c_port(case):
+    from adacharge_amd import tou_energy_cost, total_energy
+    from adacharge_amd.acn import Interface
+    from oracle import admm_port
+
+    rng = np.random.default_rng(1000 + case)
+    T = [12, 16, 24, 30, 12, 20, 9, 32][case]
+    ct = ["SOC", "LINEAR"][case % 2]
+    eq = case in (2, 5)
+    two = case in (1, 3, 5, 7)            # K = 2 session slots (KS = 4 kernel variant)
+    with_peak = case in (0, 3, 4, 7)
+    infra = sites.caltech54() if case != 6 else sites.jpl52()
+    iface = Interface({"infrastructure_info": infra, "period": 5, "prices": rng.uniform(0.05, 0.4, size=64)})
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 10.0 ** rng.uniform(-4, -2)),
+           ObjectiveComponent(tou_energy_cost, float(rng.uniform(0, 5))), ObjectiveComponent(total_energy, float(rng.uniform(0, 2)))]
+    B = 24
+    snaps, peaks = [], []
+    for _ in range(B):
+        snaps.append(_random_sessions_general(infra, T, rng, two, min_rates=not eq, demand_scale=0.5 if eq else 1.5))
+        if with_peak:
+            peaks.append(float(rng.uniform(250, 600)) if rng.random() < 0.5 else rng.uniform(250, 600, size=T))
+        else:
+            peaks.append(None)
+    # horizons differ inside the batch (padding path): give the peak vectors their own horizon
+    Ts = [max(s.arrival_offset + s.remaining_time for s in sl) for sl in snaps]
+    peaks = [p if (p is None or np.isscalar(p)) else p[:t] for p, t in zip(peaks, Ts)]
+    batch = build_batch(snaps, infra, iface, obj, ct, eq, peak_limits=peaks)
+    assert (batch.K == 2) == two or not two
+    h = SiteHandle(batch.site, 0)
+    res = h.solve(batch, default_options(max_iter=30000))
+    ref = admm_port.solve_batch(batch, threads=8, max_iter=30000)
+    both = (res.status == 1) & (ref["status"] == 1)
+    assert both.sum() >= B - 2, (res.status, ref["status"])     # an occasional slow instance may hit max_iter
+    assert ((res.status == 1) == (ref["status"] == 1)).all() or (res.status[~both] == 3).all()
+    assert np.abs(res.x[both] - ref["x"][both]).max() <= 5e-4
+    assert np.abs(res.obj[both] - ref["obj"][both]).max() <= 1e-6 * np.abs(ref["obj"][both]).max()
+    # structural invariants on every solved problem
+    assert (res.x[both] <= batch.ub[both] + 1e-9).all() and (res.x[both] >= batch.lb[both] - 1e-9).all()
+    if with_peak:
+        assert (res.x[both].sum(axis=1) <= batch.peak[both] + 2e-3).all()   # 54-term row x primal residual
+    h.close()
