@@ -188,10 +188,10 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
       const int ty = A.rowtype[r];
       real zn = zh2[k];
       if (ty == kRowBox) zn = fmin(zn, RL[r]);
-      else if (ty == kRowQuad) zn = zn * (rho / (rho + (A.lf ? (real)A.lf[b] : (real)0)));
+      else if (ty == kRowQuad) zn = zn * (rho / (rho + (A.lf ? (real)(A.lf[b] / (A.flat_scale * A.flat_scale)) : (real)0)));
       else if (ty == kRowPeak) {
         const double pv = A.peak ? A.peak[(size_t)b * T + t] : 1e300;
-        zn = fmin(zn, pv < (double)M::big ? (real)pv : M::big);
+        zn = fmin(zn, pv < (double)M::big ? (real)(pv * A.peak_scale) : M::big);
       } else if (ty == kRowSocRe || ty == kRowSocIm) {
         const int rr = ty == kRowSocRe ? r : r - GA.pair_stride;
         const real re = zh2[rr * T + t], im = zh2[(rr + GA.pair_stride) * T + t];
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
     if (A.dc != nullptr && (real)A.dc[b] > (real)0 && tid == 0) {
       for (int r = 0; r < MR; ++r)
         if (A.rowtype[r] == kRowMax) {
-          const real cw = (real)A.dc[b] * inv_rho, fl = A.dfloor ? (real)A.dfloor[b] : (real)0;
+          const real cw = (real)(A.dc[b] / A.max_scale) * inv_rho, fl = A.dfloor ? (real)(A.dfloor[b] * A.max_scale) : (real)0;
           const real* zv = zh2 + r * T;
           real vmax = -M::big;
           for (int t = 0; t < T; ++t) vmax = fmax(vmax, zv[t]);

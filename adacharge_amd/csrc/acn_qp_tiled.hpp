@@ -74,6 +74,7 @@ struct TiledArgs {
   int32_t *status, *iters;
   double *pri, *dua, *obj;
   double eps_abs, eps_rel, rho0, sigma, alpha, adapt_tol, reg_rel;
+  double peak_scale, flat_scale, max_scale;   // host-side row equilibration of the prox rows
   int max_iter, check_every, adapt_every;
 };
 
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     const int tt = 16 * c + t;
     double pv = 1e300;
     if (A.peak && tt < Tm) pv = A.peak[(size_t)b * Tm + tt];
-    pk[c] = pv < (double)M::big ? (real)pv : M::big;
+    pk[c] = pv < (double)M::big ? (real)(pv * A.peak_scale) : M::big;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ev = 16 * wave + M::rowof(g, r);
@@ -352,9 +353,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   }
 
   const real pd_user = (real)A.pdiag[b];
-  const real lfb = A.lf ? (real)A.lf[b] : (real)0;
-  const real dcb = A.dc ? (real)A.dc[b] : (real)0;
-  const real dfl = A.dfloor ? (real)A.dfloor[b] : (real)0;
+  // prox rows live in equilibrated units z' = s z:  1/2 lf z^2 = 1/2 (lf / s^2) z'^2,  dc max(z) = (dc / s) max(z')
+  const real lfb = A.lf ? (real)(A.lf[b] / (A.flat_scale * A.flat_scale)) : (real)0;
+  const real dcb = A.dc ? (real)(A.dc[b] / A.max_scale) : (real)0;
+  const real dfl = A.dfloor ? (real)(A.dfloor[b] * A.max_scale) : (real)0;
   real tau_max = 0;   // warm start of the demand-charge level
   const real sigma = (real)A.sigma, alpha = (real)A.alpha;
   real rho = (real)A.rho0;

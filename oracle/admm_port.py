@@ -35,6 +35,41 @@ def max_threads():
     return int(_load().admm_port_max_threads())
 
 
+def equilibrated(site):
+    """Row equilibration exactly as libacn_qp_hip does it internally (acn_qp_api.hip, build_site_dev):
+    every site row (a SOC pair = one row) scaled by 1/sqrt(|g|_2).  Returns
+    (G, Ghat, Q, lam, limits, peak_scale, flat_scale, max_scale)."""
+    G = np.array(site.G, dtype=np.float64, copy=True)
+    lim = np.array(site.limits, dtype=np.float64, copy=True)
+    M = site.M
+    scale = np.ones(G.shape[0])
+    for j in range(G.shape[0]):
+        if site.cone == 1 and M <= j < 2 * M:
+            continue
+        n2 = float((G[j] ** 2).sum())
+        if site.cone == 1 and j < M:
+            n2 += float((G[j + M] ** 2).sum())
+        sc = 1.0 / np.sqrt(np.sqrt(n2)) if n2 > 0 else 1.0
+        scale[j] = sc
+        if site.cone == 1 and j < M:
+            scale[j + M] = sc
+    G *= scale[:, None]
+    lim *= scale[:M]
+    if G.shape[0]:
+        lam, Q = np.linalg.eigh(G @ G.T)
+        lam = np.maximum(lam, 0.0)
+        lam[lam < 1e-12 * max(1.0, lam.max())] = 0.0
+        Gh = Q.T @ G
+        Gh[lam == 0.0] = 0.0
+    else:
+        lam, Q, Gh = np.zeros(0), np.zeros((0, 0)), np.zeros((0, site.N))
+    nrows = G.shape[0]
+    pk = scale[nrows - 1] if site.has_peak else 1.0
+    mx = scale[nrows - 1 - int(site.has_peak)] if getattr(site, "has_max", False) else 1.0
+    fl = scale[nrows - 1 - int(site.has_peak) - int(getattr(site, "has_max", False))] if getattr(site, "has_flat", False) else 1.0
+    return G, np.ascontiguousarray(Gh), np.ascontiguousarray(Q), lam, lim, pk, fl, mx
+
+
 def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.01, sigma=1e-6, alpha=1.4, adapt_tol=5.0,
                 reg_rel=0.06, max_iter=20000, check_every=20, adapt_every=40):
     """Solve a builder.ProblemBatch-like object on the CPU; same defaults as
@@ -42,18 +77,19 @@ def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.01, sigma=1e
     lib = _load()
     site = batch.site
     p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
-    keep = [np.ascontiguousarray(a, np.float64) for a in (site.G, site.Ghat, site.Q, site.lam, site.limits)]
+    Ge, Ghe, Qe, lame, lime, pk_s, fl_s, mx_s = equilibrated(site)
+    keep = [np.ascontiguousarray(a, np.float64) for a in (Ge, Ghe, Qe, lame, lime)]
     S = _Site(site.N, batch.Tm, batch.K, site.Mg, site.M, int(site.cone), int(site.has_peak), int(getattr(site, 'has_flat', False)), int(getattr(site, 'has_max', False)), *[p(a) for a in keep])
     O = _Opts(eps_abs, eps_rel, rho, sigma, alpha, adapt_tol, reg_rel, max_iter, check_every, adapt_every)
     B, N, Tm = batch.B, site.N, batch.Tm
     arrs = [np.ascontiguousarray(batch.T, np.int32), np.ascontiguousarray(batch.lb, np.float64), np.ascontiguousarray(batch.ub, np.float64),
             np.ascontiguousarray(batch.q, np.float64), np.ascontiguousarray(batch.pdiag, np.float64),
-            np.ascontiguousarray(batch.lf, np.float64),
-            np.ascontiguousarray(batch.dc if batch.dc is not None else np.zeros(batch.B), np.float64),
-            np.ascontiguousarray(batch.dfloor if batch.dfloor is not None else np.zeros(batch.B), np.float64),
+            np.ascontiguousarray(batch.lf / (fl_s * fl_s), np.float64),
+            np.ascontiguousarray((batch.dc if batch.dc is not None else np.zeros(batch.B)) / mx_s, np.float64),
+            np.ascontiguousarray((batch.dfloor if batch.dfloor is not None else np.zeros(batch.B)) * mx_s, np.float64),
             np.ascontiguousarray(batch.s_off, np.int32), np.ascontiguousarray(batch.s_len, np.int32),
             np.ascontiguousarray(batch.s_cap, np.float64), np.ascontiguousarray(batch.s_eq, np.uint8)]
-    peak = None if batch.peak is None else np.ascontiguousarray(batch.peak, np.float64)
+    peak = None if batch.peak is None else np.ascontiguousarray(batch.peak * pk_s, np.float64)
     x = np.zeros((B, N, Tm)); status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32)
     pri = np.zeros(B); dua = np.zeros(B); obj = np.zeros(B)
     lib.admm_port_solve_batch(
