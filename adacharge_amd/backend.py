@@ -98,7 +98,7 @@ class Options(C.Structure):
         ("adapt_tol", C.c_double),
         ("reg_rel", C.c_double),
         ("precision", C.c_int32),
-        ("reserved", C.c_int32),
+        ("accel_mem", C.c_int32),
     ]
 
 
@@ -112,6 +112,7 @@ EXPORTED_SYMBOLS = (
     "acnqp_last_error",
     "acnqp_abi_version",
     "acnqp_last_kernel_ms",
+    "acnqp_accel_columns",
 )
 
 _lib = None
@@ -161,6 +162,8 @@ def load_library():
     lib.acnqp_abi_version.restype = C.c_int32
     lib.acnqp_last_kernel_ms.argtypes = [C.c_void_p]
     lib.acnqp_last_kernel_ms.restype = C.c_float
+    lib.acnqp_accel_columns.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.acnqp_accel_columns.restype = C.c_int32
     _lib = lib
     return lib
 
@@ -295,6 +298,11 @@ class SiteHandle:
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.acnqp_last_kernel_ms(self._h))
+
+    def accel_columns(self, t_max: int, k_sessions: int, options: Options) -> int:
+        """Anderson columns the kernels use for this problem shape under ``options`` (shape-only rule)."""
+        return int(self._lib.acnqp_accel_columns(self._h, int(t_max), int(k_sessions), int(options.precision),
+                                                 int(options.accel_mem)))
 
 
 class DeviceBatch:

@@ -1,6 +1,7 @@
 // Host side of the C ABI declared in include/acn_qp.h.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -219,11 +220,26 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
   return ACNQP_OK;
 }
 
+// LDS one workgroup may use: the whole CU when alone, half of it when two share the CU
+constexpr int kLdsPerCu = 160 * 1024;
+constexpr int kAccelMax1 = 5, kAccelMax2 = 5;   // Anderson columns compiled into the OCC = 1 / OCC = 2 variants
+
+// Anderson columns that fit next to the solver's own LDS for this kernel shape (one workgroup per CU)
+template <typename real>
+int accel_capacity(int NW, int MT, int CT, int NP, int K, int occ) {
+  const acnqp::TiledLds base(NW, MT, CT, NP, K, occ == 1 ? kAccelMax1 : kAccelMax2, 1, (int)sizeof(real));
+  const int col = acnqp::TiledLds::column_bytes(NW, MT, CT);
+  const int fixed = base.total * (int)sizeof(real) - col;
+  const int cap = (kLdsPerCu / occ - fixed - 64) / col;
+  return std::max(0, std::min(cap, occ == 1 ? kAccelMax1 : kAccelMax2));
+}
+
 template <typename real, int NW, int CT, int MT, int KS, int OCC>
 hipError_t launch_tiled_occ(const acnqp::TiledArgs& a, hipStream_t st) {
-  const acnqp::TiledLds L(NW, MT, CT, a.NP, a.K);
+  constexpr int AM = OCC == 1 ? kAccelMax1 : kAccelMax2;
+  const acnqp::TiledLds L(NW, MT, CT, a.NP, a.K, AM, std::min(a.accel_mem, AM), (int)sizeof(real));
   const size_t lds = (size_t)L.total * sizeof(real);
-  auto kern = &acnqp::admm_tiled_kernel<real, NW, CT, MT, KS, OCC>;
+  auto kern = &acnqp::admm_tiled_kernel<real, NW, CT, MT, KS, OCC, AM>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -235,19 +251,23 @@ hipError_t launch_tiled_occ(const acnqp::TiledArgs& a, hipStream_t st) {
 
 // Two register budgets of the same kernel: one workgroup per CU with the whole register file
 // (latency-optimal when the batch does not exceed the 256 CUs), or two per CU (throughput-optimal for
-// larger batches: the second workgroup hides the first one's dependent-chain latency).
+// larger batches: the second workgroup hides the first one's dependent-chain latency).  The number of
+// Anderson columns never depends on the batch size (results must not): the two-per-CU variant is only
+// taken when the requested columns fit its smaller ring.
 template <typename real, int NW, int CT, int MT, int KS>
-hipError_t launch_tiled(const acnqp::TiledArgs& a, hipStream_t st) {
+hipError_t launch_tiled(acnqp::TiledArgs a, int requested_accel, hipStream_t st) {
+  a.accel_mem = std::min(requested_accel, accel_capacity<real>(NW, MT, CT, a.NP, a.K, 1));
   if constexpr (CT == 1 && MT <= 2 && KS == 1) {
-    if (a.B > 256) return launch_tiled_occ<real, NW, CT, MT, KS, 2>(a, st);
+    if (a.B > 256 && a.accel_mem <= accel_capacity<real>(NW, MT, CT, a.NP, a.K, 2))
+      return launch_tiled_occ<real, NW, CT, MT, KS, 2>(a, st);
   }
   return launch_tiled_occ<real, NW, CT, MT, KS, 1>(a, st);
 }
 
 template <typename real, int NW, int CT, int MT>
 hipError_t launch_k(const acnqp::TiledArgs& a, hipStream_t st) {
-  if (a.K == 1) return launch_tiled<real, NW, CT, MT, 1>(a, st);
-  return launch_tiled<real, NW, CT, MT, acnqp::kMaxK>(a, st);
+  if (a.K == 1) return launch_tiled<real, NW, CT, MT, 1>(a, a.accel_mem, st);
+  return launch_tiled<real, NW, CT, MT, acnqp::kMaxK>(a, a.accel_mem, st);
 }
 
 template <typename real, int NW, int CT>
@@ -287,7 +307,7 @@ void acnqp_default_options(acnqp_options* o) {
   o->adapt_tol = 5.0;
   o->reg_rel = 0.06;
   o->precision = 64;
-  o->reserved = 0;
+  o->accel_mem = 5;
 }
 
 int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) {
@@ -402,6 +422,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.adapt_tol = o->adapt_tol; a.reg_rel = o->reg_rel;
   a.max_iter = o->max_iter; a.check_every = o->check_every; a.adapt_every = o->adapt_every;
   a.peak_scale = d->peak_scale; a.flat_scale = d->flat_scale; a.max_scale = d->max_scale;
+  a.accel_mem = std::max(0, o->accel_mem);
   const bool tiled = h->N <= 64 && p->t_max <= 32;
   acnqp::GeneralArgs ga;
   if (!tiled) {
@@ -430,6 +451,20 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   HIP_TRY(hipEventRecord(h->ev_stop, st));
   h->timed = true;
   return ACNQP_OK;
+}
+
+int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, int32_t precision, int32_t requested) {
+  if (!h || t_max < 1 || k_sessions < 1 || requested <= 0) return 0;
+  if (!(h->N <= 64 && t_max <= 32)) return 0;   // general-shape kernel: plain ADMM
+  SiteDev* d = &h->dev64;
+  if (precision == 32) {
+    d = &h->dev32;
+    if (!d->ready && build_site_dev<float>(h, d) != ACNQP_OK) return 0;
+  }
+  const int CT = (t_max + 15) / 16, MT = d->MR / 16;
+  const int cap = precision == 32 ? accel_capacity<float>(4, MT, CT, h->NP, k_sessions, 1)
+                                  : accel_capacity<double>(4, MT, CT, h->NP, k_sessions, 1);
+  return std::min(requested, cap);
 }
 
 float acnqp_last_kernel_ms(acnqp_handle* h) {

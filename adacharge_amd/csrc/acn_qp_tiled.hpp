@@ -76,6 +76,7 @@ struct TiledArgs {
   double eps_abs, eps_rel, rho0, sigma, alpha, adapt_tol, reg_rel;
   double peak_scale, flat_scale, max_scale;   // host-side row equilibration of the prox rows
   int max_iter, check_every, adapt_every;
+  int accel_mem;   // Anderson-acceleration columns actually used (<= the kernel's AM, fits its LDS); 0 = off
 };
 
 template <typename real> struct Mfma;
@@ -142,6 +143,19 @@ __device__ inline float rsqrt_nr(float x) {
   return y;
 }
 
+// 1 / x for x > 0: hardware estimate + Newton steps (avoids the long IEEE division sequence)
+__device__ inline double rcp_nr(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  y = y + y * (1.0 - x * y);
+  y = y + y * (1.0 - x * y);
+  return y;
+}
+__device__ inline float rcp_nr(float x) {
+  float y = __builtin_amdgcn_rcpf(x);
+  y = y + y * (1.0f - x * y);
+  return y;
+}
+
 // 1 / n for a small positive integer n (interior-period count of a session window)
 __device__ inline double rcp_small(float nf) {
   const double x = (double)nf;
@@ -154,15 +168,30 @@ __device__ inline double rcp_small(float nf) {
 // LDS carve-up in units of `real`; shared by host (size) and device (offsets)
 constexpr int kXS = 18;   // row stride (reals) of the per-wave 16 x 16 transpose scratch: 16-B aligned quads
 struct TiledLds {
-  int pbuf, xpose, red, total;
-  __host__ __device__ TiledLds(int NW, int MT, int CT, int NP, int K) {
+  int pbuf, xpose, red, aared, aah, hist, total;   // offsets in reals; hist..total hold floats
+  int hist1, hist2;                                // floats per history column: tile part, site-row part
+  __host__ __device__ TiledLds(int NW, int MT, int CT, int NP, int K, int AM, int accel_mem, int real_bytes) {
     int o = 0;
     pbuf = o;  o += 2 * NW * MT * CT * 4 * 64;   // double-buffered partial tiles
     xpose = o; o += NW * CT * 16 * kXS;          // C layout <-> session layout, private to each wave
     red = o;   o += 16 * kNumRed + 8;
+    aared = o; o += accel_mem > 0 ? NW * (AM + 2) : 0;          // per-wave partial dot products
+    aah = o;   o += accel_mem > 0 ? NW * (AM * AM + AM) : 0;    // per-wave copy of the Gram matrix and rhs
+    o = (o + 1) & ~1;
+    hist = o;
+    hist1 = NW * 64 * CT * 4;
+    hist2 = 64 * MT * CT * 4;
+    const int hfloats = 2 * accel_mem * (hist1 + hist2);        // dF ring then dG ring
+    o += (hfloats * 4 + real_bytes - 1) / real_bytes;
     total = (o + 1) & ~1;
   }
+  // bytes of LDS one Anderson column costs, and everything else (to size accel_mem on the host)
+  __host__ static int column_bytes(int NW, int MT, int CT) { return 2 * (NW * 64 * CT * 4 + 64 * MT * CT * 4) * 4; }
 };
+
+// Anderson acceleration of the ADMM fixed-point map (restated in oracle/admm_port.c, see there)
+constexpr int kAaPeriod = 5;
+constexpr double kAaReg = 1e-4, kAaSafe = 1.2;
 
 // Reductions over the lanes l, l^16, l^32, l^48 (the four quarter-lanes of one EVSE in session
 // layout) with v_permlane16_swap / v_permlane32_swap: swapping a register with itself leaves the
@@ -223,7 +252,7 @@ __device__ inline void block_max(real (&v)[NV], real* Red, int lane, int wave, i
 }
 
 // ---------------------------------------------------------------------------------------
-template <typename real, int NW, int CT, int MT, int KS, int OCC>
+template <typename real, int NW, int CT, int MT, int KS, int OCC, int AM>
 __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArgs A) {
   using M = Mfma<real>;
   using vec4 = typename M::vec4;
@@ -235,7 +264,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, t = lane & 15;
   const int N = A.N, Tm = A.Tm, NP = A.NP, MR = A.MR;
-  const TiledLds L(NW, MT, CT, NP, A.K);
+  const int aa_m = AM > 0 ? min(A.accel_mem, AM) : 0;
+  const TiledLds L(NW, MT, CT, NP, A.K, AM, aa_m, (int)sizeof(real));
   real* Pbuf = sm + L.pbuf;
   real* Xw = sm + L.xpose + (size_t)wave * CT * 16 * kXS;   // this wave's transpose scratch
   real* Red = sm + L.red;
@@ -419,6 +449,39 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     }
   const real ptol_scale = M::proj_tol;
 
+  // ---- Anderson acceleration state (block-uniform scalars; vectors in C layout) ----------------------
+  constexpr int AMX = AM > 0 ? AM : 1;
+  real up1[CT][4], fp1[CT][4], gp1[CT][4];             // u, f, g at the previous event (tile part)
+  real up2[MT][CT][4], fp2[MT][CT][4], gp2[MT][CT][4]; // ... site-row part (replicated like z2)
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      up1[c][r] = 0; fp1[c][r] = 0; gp1[c][r] = 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { up2[m][c][r] = 0; fp2[m][c][r] = 0; gp2[m][c][r] = 0; }
+    }
+  int aa_cnt = 0, aa_head = 0, aa_cool = 0, aa_pen = 1;
+  unsigned aa_valid = 0;
+  bool aa_have_prev = false, aa_was = false;
+  real fn_prev = 0;
+  real* AaRed = sm + L.aared;
+  real* AaH = sm + L.aah + (size_t)wave * (AMX * AMX + AMX);   // this wave's copy of (H, b)
+  float* HistF1 = reinterpret_cast<float*>(sm + L.hist);        // dF ring: [slot][tid][CT*4], then [slot][lane][MT*CT*4]
+  float* HistF2 = HistF1 + (size_t)aa_m * L.hist1;
+  float* HistG1 = HistF2 + (size_t)aa_m * L.hist2;              // dG ring, same shape
+  float* HistG2 = HistG1 + (size_t)aa_m * L.hist1;
+  if constexpr (AM > 0) {
+    if (aa_m > 0) {
+      for (int k = lane; k < AMX * AMX + AMX; k += 64) AaH[k] = 0;
+      // dead ring slots are read (with a zero coefficient): they must hold finite numbers
+      float* ring = HistF1;
+      const int nring = 2 * aa_m * (L.hist1 + L.hist2);
+      for (int k = tid; k < nring; k += NW * 64) ring[k] = 0.f;
+      __syncthreads();
+    }
+  }
+
 #ifdef ACNQP_STAMPS
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
@@ -487,11 +550,231 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         const real xn = acc[r] * inv_a;
         zh[c][r] = alpha * xn + ((real)1 - alpha) * z1[c][r] + y1[c][r] * inv_rho;
         x[c][r] = alpha * xn + ((real)1 - alpha) * x[c][r];
-        z1[c][r] = fmin(fmax(zh[c][r], lbv[c][r]), ubv[c][r]);
       }
     }
+    // ---- site rows: G x~ = Q h^ and the pre-projection point zhr (every wave, redundantly) ----------
+    real zhr[MT][CT][4];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int mo = 0; mo < MT; ++mo) {
+        vec4 zt = {0, 0, 0, 0};
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) zt = M::mma(aQ[mo][mi][s], hh[mi][c][s], zt);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gx[mo][c][r] = alpha * zt[r] + ((real)1 - alpha) * gx[mo][c][r];
+          zhr[mo][c][r] = alpha * zt[r] + ((real)1 - alpha) * z2[mo][c][r] + y2[mo][c][r] * inv_rho;
+        }
+      }
+    const bool check = (it % A.check_every == 0) || it >= A.max_iter;
 
-    STAMP(3);   // x~ MFMA + clip
+    STAMP(3);   // x~ MFMA, Q h^ MFMA
+    // ---- Anderson acceleration event: u = (zh, zhr) is the state of the fixed-point map; every
+    // kAaPeriod-th iteration extrapolates it from the last aa_m (dF, dG) column pairs (type II).
+    // Control flow is block-uniform; the single extra barrier carries the partial dot products.
+    // The arithmetic below is branch-free over all AM ring slots (dead slots hold finite stale data
+    // and get a zero coefficient), so the independent dot products / reductions overlap.
+    if constexpr (AM > 0) {
+      if (aa_m > 0 && it % kAaPeriod == 0) {
+        const bool col = aa_have_prev;
+        const int slot = aa_head;
+        const real w0 = wave == 0 ? (real)1 : (real)0;   // the site-row state is replicated: count it once
+        real f1[CT][4], f2[MT][CT][4];
+        float cq1[CT][4], cq2[MT][CT][4];          // the new dF column, as stored
+        real d[AMX + 2];
+        {
+          real fa = 0, fb = 0;
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              f1[c][r] = zh[c][r] - up1[c][r];
+              fa += f1[c][r] * f1[c][r];
+              cq1[c][r] = (float)(f1[c][r] - fp1[c][r]);
+#pragma unroll
+              for (int m = 0; m < MT; ++m) {
+                f2[m][c][r] = zhr[m][c][r] - up2[m][c][r];
+                fb += f2[m][c][r] * f2[m][c][r];
+                cq2[m][c][r] = (float)(f2[m][c][r] - fp2[m][c][r]);
+              }
+            }
+          d[AMX + 1] = fa + w0 * fb;
+        }
+        {   // store the column pair in slot `slot` (speculatively: it only counts once marked live)
+          float* hf = HistF1 + ((size_t)slot * NW * 64 + tid) * (CT * 4);
+          float* hg = HistG1 + ((size_t)slot * NW * 64 + tid) * (CT * 4);
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              hf[c * 4 + r] = cq1[c][r];
+              hg[c * 4 + r] = (float)(zh[c][r] - gp1[c][r]);
+            }
+          if (wave == 0) {
+            float* hf2 = HistF2 + ((size_t)slot * 64 + lane) * (MT * CT * 4);
+            float* hg2 = HistG2 + ((size_t)slot * 64 + lane) * (MT * CT * 4);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  hf2[(m * CT + c) * 4 + r] = cq2[m][c][r];
+                  hg2[(m * CT + c) * 4 + r] = (float)(zhr[m][c][r] - gp2[m][c][r]);
+                }
+          }
+        }
+        // dF_slot . dF_j for every ring slot j, dF_slot . f
+#pragma unroll
+        for (int j = 0; j < AMX; ++j) {
+          const int jj = j < aa_m ? j : aa_m - 1;
+          const float* hj = HistF1 + ((size_t)jj * NW * 64 + tid) * (CT * 4);
+          const float* hj2 = HistF2 + ((size_t)jj * 64 + lane) * (MT * CT * 4);
+          real a1 = 0, a2 = 0;
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              a1 += (real)cq1[c][r] * (real)hj[c * 4 + r];
+#pragma unroll
+              for (int m = 0; m < MT; ++m) a2 += (real)cq2[m][c][r] * (real)hj2[(m * CT + c) * 4 + r];
+            }
+          d[j] = a1 + w0 * a2;
+        }
+        {
+          real a1 = 0, a2 = 0;
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              a1 += (real)cq1[c][r] * f1[c][r];
+#pragma unroll
+              for (int m = 0; m < MT; ++m) a2 += (real)cq2[m][c][r] * f2[m][c][r];
+            }
+          d[AMX] = a1 + w0 * a2;
+        }
+        // block-wide sums: wave reductions (independent chains), one LDS slot per wave, the event's barrier
+#pragma unroll
+        for (int j = 0; j < AMX + 2; ++j) d[j] = wave_sum<real>(d[j]);
+        if (lane == 0) {
+#pragma unroll
+          for (int j = 0; j < AMX + 2; ++j) AaRed[wave * (AMX + 2) + j] = d[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < AMX + 2; ++j) {
+          real sw = 0;
+#pragma unroll
+          for (int wv = 0; wv < NW; ++wv) sw += AaRed[wv * (AMX + 2) + j];
+          d[j] = sw;
+        }
+        STAMP(10);   // event: column, dot products, block reduction
+        const real fn = sqrt(d[AMX + 1]);
+        bool keep = col;
+        if (aa_was && fn > (real)kAaSafe * fn_prev) {
+          // the accelerated step made the residual worse: clear the ring, back off exponentially
+          aa_cnt = 0; aa_head = 0; aa_valid = 0; keep = false;
+          __builtin_amdgcn_wave_barrier();
+          for (int k = lane; k < AMX * AMX + AMX; k += 64) AaH[k] = 0;
+          aa_cool = aa_pen;
+          aa_pen = aa_pen < 64 ? 2 * aa_pen : 64;
+        } else if (aa_cool > 0) --aa_cool;
+        if (keep) {
+          aa_valid |= 1u << slot;
+          if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < AMX; ++j) {
+              if (!((aa_valid >> j) & 1u)) continue;
+              AaH[slot * AMX + j] = d[j];
+              AaH[j * AMX + slot] = d[j];
+              if (j != slot) AaH[AMX * AMX + j] += d[j];   // dF_j . f_k = dF_j . f_(k-1) + dF_j . dF_slot
+            }
+            AaH[AMX * AMX + slot] = d[AMX];
+          }
+          aa_head = slot + 1 == aa_m ? 0 : slot + 1;
+          aa_cnt = aa_cnt < aa_m ? aa_cnt + 1 : aa_m;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            fp1[c][r] = f1[c][r]; gp1[c][r] = zh[c][r];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { fp2[m][c][r] = f2[m][c][r]; gp2[m][c][r] = zhr[m][c][r]; }
+          }
+        aa_have_prev = true; fn_prev = fn; aa_was = false;
+        if (aa_cnt > 0 && aa_cool == 0 && !check) {
+          // gamma = (H + eta I)^-1 b by LDL' (H is a Gram matrix: no pivoting), every lane redundantly
+          real Hm[AMX][AMX], gam[AMX], dd[AMX];
+          real tr = 0;
+#pragma unroll
+          for (int i = 0; i < AMX; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) Hm[i][j] = AaH[i * AMX + j];
+            gam[i] = AaH[AMX * AMX + i];
+            tr += Hm[i][i];                       // dead slots hold zeros
+          }
+          const real eta = (real)kAaReg * tr + (real)(sizeof(real) == 8 ? 1e-300 : 1e-37);
+#pragma unroll
+          for (int i = 0; i < AMX; ++i) Hm[i][i] = ((aa_valid >> i) & 1u) ? Hm[i][i] + eta : (real)1;
+          // right-looking LDL': after column j the trailing block is updated at once (independent FMAs)
+#pragma unroll
+          for (int j = 0; j < AMX; ++j) {
+            dd[j] = rcp_nr(Hm[j][j]);                       // 1 / d_j
+#pragma unroll
+            for (int i = j + 1; i < AMX; ++i) {
+              const real lij = Hm[i][j] * dd[j];
+#pragma unroll
+              for (int k = j + 1; k <= i; ++k) Hm[i][k] -= lij * Hm[k][j];   // column j is still unscaled (l_kj d_j)
+            }
+#pragma unroll
+            for (int i = j + 1; i < AMX; ++i) Hm[i][j] *= dd[j];
+          }
+          // L y = b, D, L' gamma = y: column-oriented so that each stage is a batch of independent FMAs
+#pragma unroll
+          for (int k = 0; k < AMX; ++k)
+#pragma unroll
+            for (int i = k + 1; i < AMX; ++i) gam[i] -= Hm[i][k] * gam[k];
+#pragma unroll
+          for (int i = 0; i < AMX; ++i) gam[i] *= dd[i];
+#pragma unroll
+          for (int k = AMX - 1; k >= 0; --k)
+#pragma unroll
+            for (int i = 0; i < k; ++i) gam[i] -= Hm[k][i] * gam[k];
+          STAMP(11);   // event: LDL' solve
+#pragma unroll
+          for (int j = 0; j < AMX; ++j) {
+            const int jj = j < aa_m ? j : aa_m - 1;
+            const float* hg = HistG1 + ((size_t)jj * NW * 64 + tid) * (CT * 4);
+            const float* hg2 = HistG2 + ((size_t)jj * 64 + lane) * (MT * CT * 4);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                zh[c][r] -= gam[j] * (real)hg[c * 4 + r];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) zhr[m][c][r] -= gam[j] * (real)hg2[(m * CT + c) * 4 + r];
+              }
+          }
+          aa_was = true;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            up1[c][r] = zh[c][r];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) up2[m][c][r] = zhr[m][c][r];
+          }
+      }
+    }
+    STAMP(9);   // Anderson event (amortised)
     // ---- energy rows: exact water-filling in session layout ---------------------------------------
     // z = clip(zh - m) with g(m) = sum_t clip(zh_t - m) = cap: safeguarded Newton on the piecewise-
     // linear g, warm-started at the previous iteration's m (typically one step + one verifying pass).
@@ -513,43 +796,33 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           sz[c][tt] = fmin(fmax(szh[c][tt], slb[c][tt]), sub[c][tt]);
         }
       STAMP(7);   // C -> session transpose
-      // (the site-row update is independent of the water-filling; it sits here so that its MFMA chain
-      //  and VALU work share one basic block with the first Newton pass and hide each other's latency)
-    // ---- site rows: G x~ = Q h^, relaxation, projection onto C, y2 (every wave, redundantly) ---
+      // (the site-row projection is independent of the water-filling; it sits here so that its VALU work
+      //  shares one basic block with the first Newton pass and they hide each other's latency)
+    // ---- site rows: projection of zhr onto C, y2 (every wave, redundantly) ---
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
 #pragma unroll
       for (int mo = 0; mo < MT; ++mo) {
-        vec4 zt = {0, 0, 0, 0};
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) zt = M::mma(aQ[mo][mi][s], hh[mi][c][s], zt);
-        real zhr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          gx[mo][c][r] = alpha * zt[r] + ((real)1 - alpha) * gx[mo][c][r];
-          zhr[r] = alpha * zt[r] + ((real)1 - alpha) * z2[mo][c][r] + y2[mo][c][r] * inv_rho;
-        }
         real scl[2] = {(real)1, (real)1};   // radial clip factor of the register pairs (0,1), (2,3)
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
           if (rtype[mo][2 * pr] == kRowSocRe) {
-            const real re = zhr[2 * pr], im = zhr[2 * pr + 1], lim = limv[mo][2 * pr];
+            const real re = zhr[mo][c][2 * pr], im = zhr[mo][c][2 * pr + 1], lim = limv[mo][2 * pr];
             const real n2 = re * re + im * im;
             if (n2 > lim * lim) scl[pr] = lim * rsqrt_nr(n2);
           }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          real zn = zhr[r];
+          const real zh_ = zhr[mo][c][r];
+          real zn = zh_;
           const int ty = rtype[mo][r];
-          if (ty == kRowBox) zn = fmin(zhr[r], limv[mo][r]);
-          else if (ty == kRowPeak) zn = fmin(zhr[r], pk[c]);
-          else if (ty == kRowQuad) zn = zhr[r] * (rho / (rho + lfb));
-          // kRowMax: zn = zhr here; the horizon-wide prox follows the tile loop
-          else if (ty == kRowSocRe || ty == kRowSocIm) zn = zhr[r] * scl[r >> 1];
-          y2[mo][c][r] = rho * (zhr[r] - zn);
+          if (ty == kRowBox) zn = fmin(zh_, limv[mo][r]);
+          else if (ty == kRowPeak) zn = fmin(zh_, pk[c]);
+          else if (ty == kRowQuad) zn = zh_ * (rho / (rho + lfb));
+          // kRowMax: zn = zh_ here; the horizon-wide prox follows the tile loop
+          else if (ty == kRowSocRe || ty == kRowSocIm) zn = zh_ * scl[r >> 1];
+          y2[mo][c][r] = rho * (zh_ - zn);
           z2[mo][c][r] = zn;
         }
       }
@@ -725,7 +998,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     STAMP(4);   // session -> C transpose + y1
     STAMP(5);   // site rows
     // ---- residuals, termination, rho adaptation (block-uniform decisions) -----------------
-    const bool check = (it % A.check_every == 0) || it >= A.max_iter;
     if (check) {
       real v[6];   // pri, dua, |Ax| |z|, -, |Px|, |A'y|
       v[0] = v[1] = v[2] = v[3] = v[4] = v[5] = 0;
@@ -911,6 +1183,22 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) djv[m][r] = rho / (a + rho * lamv[m][r]);
+          if constexpr (AM > 0) {
+            if (aa_m > 0) {   // the fixed-point map changed: restart the ring from the current (z, y)
+              aa_cnt = 0; aa_head = 0; aa_valid = 0; aa_have_prev = false; aa_was = false;
+              __builtin_amdgcn_wave_barrier();
+              for (int k = lane; k < AMX * AMX + AMX; k += 64) AaH[k] = 0;
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+              for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  up1[c][r] = z1[c][r] + y1[c][r] / rho;
+#pragma unroll
+                  for (int m = 0; m < MT; ++m) up2[m][c][r] = z2[m][c][r] + y2[m][c][r] / rho;
+                }
+            }
+          }
         }
       }
     }

@@ -70,7 +70,7 @@ def flops_per_iteration(N, Tm, site):
     return 4 * Mg * N * Tm + 4 * Mg * Mg * Tm + 20 * N * Tm + 12 * Mg * Tm
 
 
-def cpu_baseline_leg(batch, gpu_x, gpu_status, target_seconds, snaps, infra, iface):
+def cpu_baseline_leg(batch, gpu_x, gpu_status, target_seconds, snaps, infra, iface, accel_mem=0):
     """The ONLY place bench.py touches oracle/: the scalar C port of the device ADMM timed on
     the host cores over a bounded sample, which also serves as the parity check of the sample."""
     from oracle import admm_port
@@ -86,14 +86,14 @@ def cpu_baseline_leg(batch, gpu_x, gpu_status, target_seconds, snaps, infra, ifa
         sb.peak = None if batch.peak is None else batch.peak[:k]
         return sb
 
-    admm_port.solve_batch(sub(min(cores, batch.B)), threads=cores)  # warm the thread pool / caches
+    admm_port.solve_batch(sub(min(cores, batch.B)), threads=cores, accel_mem=accel_mem)  # warm the thread pool / caches
     t0 = time.perf_counter()
-    out = admm_port.solve_batch(batch, threads=cores)   # one pass over the whole rank-0 batch: parity sample
+    out = admm_port.solve_batch(batch, threads=cores, accel_mem=accel_mem)   # one pass over the whole rank-0 batch: parity sample
     one_pass = max(time.perf_counter() - t0, 1e-4)
     reps = int(max(1, min(200, round(target_seconds / one_pass))))
     t0 = time.perf_counter()
     for _ in range(reps):   # bounded sample of the same workload: the batch, `reps` times
-        admm_port.solve_batch(batch, threads=cores)
+        admm_port.solve_batch(batch, threads=cores, accel_mem=accel_mem)
     dt = time.perf_counter() - t0
     n = batch.B
     n_timed = n * reps
@@ -275,10 +275,12 @@ def main():
             "solver": {
                 "solved": solved_all, "problems": total_all,
                 "eps_abs": opts.eps_abs, "eps_rel": opts.eps_rel, "reg_rel": opts.reg_rel,
+                "anderson_columns": handle.accel_columns(batch.Tm, batch.K, opts),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, parity = cpu_baseline_leg(batch, x, status, args.cpu_seconds, snaps, infra, iface)
+            cb, parity = cpu_baseline_leg(batch, x, status, args.cpu_seconds, snaps, infra, iface,
+                                          accel_mem=handle.accel_columns(batch.Tm, batch.K, opts))
             out["cpu_baseline"] = cb
             out["parity"] = parity
         print(json.dumps(out), flush=True)

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define ACNQP_ABI_VERSION 3
+#define ACNQP_ABI_VERSION 4
 
 /* cone of the infrastructure rows (constraint_type at aco.py:35, 151, 165) */
 #define ACNQP_CONE_LINEAR 0
@@ -128,7 +128,10 @@ typedef struct {
                             On LP instances a small floor returns the least-norm
                             LP optimum (exact regularisation)  */
   int32_t precision;     /* 64 or 32: arithmetic type of the ADMM loop        */
-  int32_t reserved;
+  int32_t accel_mem;     /* Anderson acceleration of the ADMM fixed-point map: columns of
+                            history requested (0 = plain ADMM).  The kernels use
+                            min(accel_mem, what fits their LDS for the problem shape);
+                            acnqp_accel_columns reports that number                */
 } acnqp_options;
 
 /* acnqp_create -- uploads the site once.  Replaces the per-call rebuilding of
@@ -162,6 +165,14 @@ int32_t acnqp_abi_version(void);
  * handle, measured with HIP events on the launch stream (valid after the
  * stream has been synchronised); < 0 if none.  Used by bench.py's roofline. */
 float acnqp_last_kernel_ms(acnqp_handle* h);
+
+/* Anderson columns the kernels will actually use for problems of this shape
+ * (t_max periods, k_sessions slots) at the given precision when `requested`
+ * columns are asked for: a function of the shape only, never of the batch
+ * size.  0 for shapes that take the general kernel.  No reference equivalent:
+ * test/bench plumbing so that a CPU restatement can run the same algorithm.  */
+int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, int32_t precision,
+                            int32_t requested);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 /* ORACLE -- test infrastructure only.  Nothing under adacharge_amd/ links this.
  *
- * Scalar C port of the device ADMM (adacharge_amd/csrc/acn_qp_kernel.hpp), same
+ * Scalar C port of the device ADMM (adacharge_amd/csrc/acn_qp_tiled.hpp), same
  * algorithm and same parameters, double precision, one problem per call;
  * oracle/admm_ref.py is its readable numpy twin.  Used (a) as a near-bitwise
  * checker for the HIP kernel and (b) as bench.py's `cpu_baseline` ("port"),
@@ -26,6 +26,7 @@ typedef struct {
 typedef struct {
   double eps_abs, eps_rel, rho, sigma, alpha, adapt_tol, reg_rel;
   int max_iter, check_every, adapt_every;
+  int accel_mem;   /* Anderson-acceleration memory (columns); 0 = plain ADMM */
 } port_opts;
 
 static double clip(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -67,17 +68,73 @@ static void project_window(int L, const double* v, const double* lb, const doubl
 }
 
 /* returns status: 1 solved, 2 max_iter, 4 empty set */
+
+/* ---- Anderson acceleration (type II) of the ADMM fixed-point map, as the tiled HIP kernel does it.
+ * State u = (zhat1, zhat2) = the pre-projection points; every kAaPeriod-th iteration is an "event":
+ *   f = g - u_prev  (g = the plain ADMM update reached from u_prev, kAaPeriod iterations later)
+ *   columns dF = f - f_prev, dG = g - g_prev are kept (as floats) in a ring of accel_mem slots
+ *   gamma = argmin |f - dF gamma|^2 + eta |gamma|^2,  eta = kAaReg * trace(dF'dF)
+ *   u_next = g - dG gamma      (skipped on residual-check iterations and while cooling down)
+ * Safeguard: if the residual norm grew by more than kAaSafe after an accelerated step the ring is
+ * cleared and acceleration pauses for 1, 2, 4, ... 64 events (exponential back-off).            */
+#define AA_MAX 16
+static const int kAaPeriod = 5;
+static const double kAaReg = 1e-4, kAaSafe = 1.2;
+
+/* solve (H + eta I) gamma = b for the valid columns (LDL', no pivoting: H is a Gram matrix) */
+static void aa_solve(int m, const double* H, const double* bvec, unsigned valid, double* gam) {
+  double d[AA_MAX], y[AA_MAX], Hm[AA_MAX][AA_MAX], bb[AA_MAX];
+  double tr = 0;
+  for (int j = 0; j < m; ++j) if ((valid >> j) & 1u) tr += H[j * AA_MAX + j];
+  const double eta = kAaReg * tr + 1e-300;
+  for (int i = 0; i < m; ++i) {
+    const int vi = (valid >> i) & 1u;
+    bb[i] = vi ? bvec[i] : 0.0;
+    for (int j = 0; j < m; ++j) {
+      const int vj = (valid >> j) & 1u;
+      Hm[i][j] = (vi && vj) ? H[i * AA_MAX + j] : 0.0;
+    }
+    Hm[i][i] = vi ? Hm[i][i] + eta : 1.0;
+  }
+  /* right-looking LDL': d[] holds 1/d_j; Hm is overwritten by L (strict lower part) */
+  for (int j = 0; j < m; ++j) {
+    d[j] = 1.0 / Hm[j][j];
+    double u[AA_MAX];
+    for (int i = j + 1; i < m; ++i) u[i] = Hm[i][j];   /* column j before scaling: l_ij d_j */
+    for (int i = j + 1; i < m; ++i) {
+      const double lij = u[i] * d[j];
+      for (int k = j + 1; k <= i; ++k) Hm[i][k] -= lij * u[k];
+      Hm[i][j] = lij;
+    }
+  }
+  /* L y = b, D, L' gamma = y: column-oriented, as on the device */
+  for (int i = 0; i < m; ++i) y[i] = bb[i];
+  for (int k = 0; k < m; ++k) for (int i = k + 1; i < m; ++i) y[i] -= Hm[i][k] * y[k];
+  for (int i = 0; i < m; ++i) y[i] *= d[i];
+  for (int k = m - 1; k >= 0; --k) for (int i = 0; i < k; ++i) y[i] -= Hm[k][i] * y[k];
+  for (int i = 0; i < m; ++i) gam[i] = y[i];
+}
+
 static int solve_one(const port_site* S, const port_opts* O, int horizon, const double* lb, const double* ub_in, const double* q,
                      double pdiag_user, double lf, double dc, double dfloor, const int32_t* s_off, const int32_t* s_len, const double* s_cap, int eq,
                      const double* peak, double* xout, int* iters_out, double* pri_out, double* dua_out,
                      double* obj_out) {
   const int N = S->N, T = S->Tm, Mg = S->Mg, M = S->M, K = S->K;
   const int n = N * T, mt = Mg * T;
-  double* buf = (double*)calloc((size_t)(8 * n + 8 * mt + K * N * 3 + 4 * T + Mg + 32), sizeof(double));
+  const int D = n + mt, MM = O->accel_mem > AA_MAX ? AA_MAX : (O->accel_mem > 0 ? O->accel_mem : 0);
+  double* buf = (double*)calloc((size_t)(8 * n + 8 * mt + K * N * 3 + 4 * T + Mg + 32 + 4 * D), sizeof(double));
+  float* hist = (float*)calloc((size_t)2 * (MM > 0 ? MM : 1) * D, sizeof(float));   /* dF ring, then dG ring */
+  double aaH[AA_MAX * AA_MAX], aab[AA_MAX];
+  memset(aaH, 0, sizeof aaH); memset(aab, 0, sizeof aab);
+  int aa_cnt = 0, aa_head = 0, aa_have_prev = 0, aa_was = 0, aa_cool = 0, aa_pen = 1;
+  unsigned aa_valid = 0;
+  double fn_prev = 0;
   double *x = buf, *z1 = x + n, *y1 = z1 + n, *r0 = y1 + n, *zh = r0 + n, *ub = zh + n, *xt = ub + n, *gty = xt + n;
   double *z2 = gty + n, *y2 = z2 + mt, *gx = y2 + mt, *w = gx + mt, *wh = w + mt, *gh0 = wh + mt, *eh = gh0 + mt,
          *hh = eh + mt;
   double *mu = hh + mt, *slo = mu + K * N, *shi = slo + K * N, *tmpv = shi + K * N, *zmaxrow = tmpv + Mg + 2;
+  double *uprev = zmaxrow + T + 2, *gcur = uprev + D, *fprev = gcur + D, *gprev = fprev + D;
+  float *hF = hist, *hG = hist + (size_t)(MM > 0 ? MM : 1) * D;
   double qnorm = 0, ubmax = 0;
   for (int k = 0; k < n; ++k) {
     ub[k] = ub_in[k] < lb[k] ? lb[k] : ub_in[k];
@@ -100,7 +157,7 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
   if (status == 4) {
     memset(xout, 0, sizeof(double) * n);
     *iters_out = 0; *pri_out = pri; *dua_out = dua; *obj_out = 0;
-    free(buf);
+    free(buf); free(hist);
     return 4;
   }
   double pd = pdiag_user;
@@ -131,8 +188,64 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
         const int k = i * T + t;
         zh[k] = alpha * xn + (1 - alpha) * z1[k] + y1[k] * inv_rho;
         x[k] = alpha * xn + (1 - alpha) * x[k];
-        z1[k] = clip(zh[k], lb[k], ub[k]);
       }
+    /* constraint role: G x~ = Q h^, relaxation; zh2 = pre-projection point of the site rows */
+    double* zh2 = gcur + n;
+    for (int t = 0; t < T; ++t)
+      for (int r = 0; r < Mg; ++r) {
+        double zt = 0;
+        for (int k = 0; k < Mg; ++k) zt += S->Q[r * Mg + k] * hh[k * T + t];
+        gx[r * T + t] = alpha * zt + (1 - alpha) * gx[r * T + t];
+        zh2[r * T + t] = alpha * zt + (1 - alpha) * z2[r * T + t] + y2[r * T + t] * inv_rho;
+      }
+    const int check = (it % O->check_every == 0) || it >= O->max_iter;
+    /* ---- Anderson acceleration event ---- */
+    if (MM > 0 && it % kAaPeriod == 0) {
+      memcpy(gcur, zh, sizeof(double) * n);
+      double fn = 0;
+      for (int k = 0; k < D; ++k) { const double f = gcur[k] - uprev[k]; fn += f * f; }
+      fn = sqrt(fn);
+      if (aa_was && fn > kAaSafe * fn_prev) {   /* the accelerated step made things worse: clear, back off */
+        aa_cnt = 0; aa_head = 0; aa_valid = 0; aa_have_prev = 0;
+        memset(aaH, 0, sizeof aaH); memset(aab, 0, sizeof aab);
+        aa_cool = aa_pen; aa_pen = aa_pen < 64 ? 2 * aa_pen : 64;
+      } else if (aa_cool > 0) --aa_cool;
+      if (aa_have_prev) {
+        const int c = aa_head;
+        float* cf = hF + (size_t)D * c; float* cg = hG + (size_t)D * c;
+        for (int k = 0; k < D; ++k) { cf[k] = (float)((gcur[k] - uprev[k]) - fprev[k]); cg[k] = (float)(gcur[k] - gprev[k]); }
+        aa_valid |= 1u << c;
+        for (int j = 0; j < MM; ++j) {
+          if (!((aa_valid >> j) & 1u)) continue;
+          const float* cj = hF + (size_t)D * j;
+          double dsum = 0;
+          for (int k = 0; k < D; ++k) dsum += (double)cf[k] * (double)cj[k];
+          aaH[c * AA_MAX + j] = aaH[j * AA_MAX + c] = dsum;
+          if (j != c) aab[j] += dsum;   /* dF_j . f_k = dF_j . f_(k-1) + dF_j . dF_c */
+        }
+        double db = 0;
+        for (int k = 0; k < D; ++k) db += (double)cf[k] * (gcur[k] - uprev[k]);
+        aab[c] = db;
+        aa_head = (aa_head + 1) % MM; if (aa_cnt < MM) ++aa_cnt;
+      }
+      for (int k = 0; k < D; ++k) { fprev[k] = gcur[k] - uprev[k]; gprev[k] = gcur[k]; }
+      aa_have_prev = 1; fn_prev = fn; aa_was = 0;
+      if (aa_cnt > 0 && aa_cool == 0 && !check) {
+        double gam[AA_MAX];
+        aa_solve(MM, aaH, aab, aa_valid, gam);
+        for (int j = 0; j < MM; ++j) {
+          if (!((aa_valid >> j) & 1u)) continue;
+          const float* cg = hG + (size_t)D * j;
+          const double gj = gam[j];
+          for (int k = 0; k < D; ++k) gcur[k] -= gj * (double)cg[k];
+        }
+        aa_was = 1;
+      }
+      memcpy(uprev, gcur, sizeof(double) * D);
+      memcpy(zh, gcur, sizeof(double) * n);
+    }
+    /* ---- projections: z1 = Proj_B(zh), z2 = Proj_C(zh2), y = rho (pre-projection - projection) ---- */
+    for (int k = 0; k < n; ++k) z1[k] = clip(zh[k], lb[k], ub[k]);
     for (int k = 0; k < K; ++k)
       for (int i = 0; i < N; ++i) {
         const int L = s_len[k * N + i], o = s_off[k * N + i];
@@ -141,14 +254,8 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
                          shi[k * N + i], &mu[k * N + i], z1 + i * T + o);
       }
     for (int k = 0; k < n; ++k) y1[k] = rho * (zh[k] - z1[k]);
-    /* constraint role */
     for (int t = 0; t < T; ++t) {
-      for (int r = 0; r < Mg; ++r) {
-        double zt = 0;
-        for (int k = 0; k < Mg; ++k) zt += S->Q[r * Mg + k] * hh[k * T + t];
-        gx[r * T + t] = alpha * zt + (1 - alpha) * gx[r * T + t];
-        tmpv[r] = alpha * zt + (1 - alpha) * z2[r * T + t] + y2[r * T + t] * inv_rho;
-      }
+      for (int r = 0; r < Mg; ++r) tmpv[r] = zh2[r * T + t];
       for (int c = 0; c < M; ++c) {
         if (S->cone == 1) {
           const double za = tmpv[c], zb = tmpv[c + M], nrm = sqrt(za * za + zb * zb), lim = S->limits[c];
@@ -197,7 +304,6 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
         y2[r * T + t] = rho * (zmaxrow[t] - zn); z2[r * T + t] = zn;
       }
     }
-    const int check = (it % O->check_every == 0) || it >= O->max_iter;
     int done = 0;
     if (check) {
       double v0 = 0, v1 = 0, v2 = 0, v4 = 0, v5 = 0;
@@ -223,7 +329,15 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
       else if (O->adapt_every > 0 && it % O->adapt_every == 0) {
         const double sp = pri / fmax(npri, 1e-12), sd = dua / fmax(ndua, 1e-12);
         const double ratio = sqrt(sp / fmax(sd, 1e-30));
-        if (ratio > O->adapt_tol || ratio < 1.0 / O->adapt_tol) rho = fmin(fmax(rho * ratio, 1e-6), 1e6);
+        if (ratio > O->adapt_tol || ratio < 1.0 / O->adapt_tol) {
+          rho = fmin(fmax(rho * ratio, 1e-6), 1e6);
+          if (MM > 0) {   /* the fixed-point map changed: restart the ring from the current (z, y) */
+            aa_cnt = 0; aa_head = 0; aa_valid = 0; aa_have_prev = 0; aa_was = 0;
+            memset(aaH, 0, sizeof aaH); memset(aab, 0, sizeof aab);
+            for (int k = 0; k < n; ++k) uprev[k] = z1[k] + y1[k] / rho;
+            for (int k = 0; k < mt; ++k) uprev[n + k] = z2[k] + y2[k] / rho;
+          }
+        }
       }
     }
     if (done) break;
@@ -234,7 +348,7 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
   double obj = 0;
   for (int k = 0; k < n; ++k) { xout[k] = z1[k]; obj += (0.5 * pdiag_user * z1[k] + q[k]) * z1[k]; }
   *iters_out = it; *pri_out = pri; *dua_out = dua; *obj_out = obj;
-  free(buf);
+  free(buf); free(hist);
   return status;
 }
 

@@ -1,7 +1,7 @@
 """ORACLE -- test infrastructure only.  Nothing under adacharge_amd/ may import it.
 
 Readable numpy restatement of the *device algorithm* (the ADMM the HIP kernel
-runs, adacharge_amd/csrc/acn_qp_kernels.hip), one problem at a time, fp64.  It
+runs, adacharge_amd/csrc/acn_qp_tiled.hpp), one problem at a time, fp64.  It
 is not the reference's algorithm (the reference calls cvxpy/ECOS, aco.py:318);
 it exists so that a kernel bug can be told apart from an algorithmic property:
 the kernel must agree with this file to ~1e-9, and this file must agree with
@@ -39,14 +39,86 @@ class AdmmOptions:
     eps_abs: float = 1e-6
     eps_rel: float = 1e-6
     max_iter: int = 20000
-    rho: float = 0.1
+    rho: float = 0.01
     sigma: float = 1e-6
-    alpha: float = 1.6
-    check_every: int = 10
+    alpha: float = 1.4
+    check_every: int = 20
     adaptive_rho: bool = True
-    adapt_every: int = 50
+    adapt_every: int = 40
     adapt_tol: float = 5.0
     reg_rel: float = 0.0
+    equilibrate: bool = True      # row scaling of the site matrix, as the library does internally
+    accel_mem: int = 0            # Anderson-acceleration columns (0 = plain ADMM), see _Anderson
+
+
+AA_PERIOD, AA_REG, AA_SAFE = 5, 1e-4, 1.2
+
+
+class _Anderson:
+    """Type-II Anderson acceleration of the ADMM fixed-point map u -> g(u), u = the stacked
+    pre-projection points (zhat1, zhat2), exactly as oracle/admm_port.c and the tiled HIP kernel do it:
+    an *event* every AA_PERIOD iterations; columns dF = f - f_prev, dG = g - g_prev (stored as
+    float32) in a ring of ``mem`` slots; gamma = argmin |f - dF gamma|^2 + eta |gamma|^2 with
+    eta = AA_REG * trace(dF'dF); u_next = g - dG gamma.  If the residual norm grew by more than
+    AA_SAFE after an accelerated step the ring is cleared and acceleration pauses for
+    1, 2, 4, ... 64 events."""
+
+    def __init__(self, mem, dim):
+        self.m, self.dim = mem, dim
+        self.uprev = np.zeros(dim)
+        self.pen = 1
+        self.cool = 0
+        self.fn_prev = 0.0
+        self.was = False
+        self.restart(None)
+
+    def restart(self, u):
+        self.dF = np.zeros((self.m, self.dim), np.float32)
+        self.dG = np.zeros((self.m, self.dim), np.float32)
+        self.valid = np.zeros(self.m, bool)
+        self.H = np.zeros((self.m, self.m))
+        self.b = np.zeros(self.m)
+        self.head = 0
+        self.fprev = None
+        self.gprev = None
+        self.was = False
+        if u is not None:
+            self.uprev = u.copy()
+
+    def event(self, g, may_apply):
+        f = g - self.uprev
+        fn = float(np.sqrt(f @ f))
+        if self.was and fn > AA_SAFE * self.fn_prev:
+            u = self.uprev
+            self.restart(None)
+            self.uprev = u
+            self.cool, self.pen = self.pen, min(64, 2 * self.pen)
+        elif self.cool > 0:
+            self.cool -= 1
+        if self.fprev is not None:
+            c = self.head
+            self.dF[c] = (f - self.fprev).astype(np.float32)
+            self.dG[c] = (g - self.gprev).astype(np.float32)
+            self.valid[c] = True
+            col = self.dF[c].astype(np.float64)
+            for j in np.flatnonzero(self.valid):
+                d = float(col @ self.dF[j].astype(np.float64))
+                self.H[c, j] = self.H[j, c] = d
+                if j != c:
+                    self.b[j] += d            # dF_j . f_k = dF_j . f_(k-1) + dF_j . dF_c
+            self.b[c] = float(col @ f)
+            self.head = (c + 1) % self.m
+        self.fprev, self.gprev, self.fn_prev, self.was = f, g.copy(), fn, False
+        u = g
+        if self.valid.any() and self.cool == 0 and may_apply:
+            v = np.flatnonzero(self.valid)
+            Hv = self.H[np.ix_(v, v)]
+            eta = AA_REG * np.trace(Hv) + 1e-300
+            gam = np.linalg.solve(Hv + eta * np.eye(len(v)), self.b[v])
+            u = g - gam @ self.dG[v].astype(np.float64)
+            self.was = True
+        self.uprev = u.copy()
+        return u
 
 
 def project_window(v, lb, ub, cap, eq):
@@ -85,19 +157,19 @@ def _project_B(v, lb, ub, s_off, s_len, s_cap, eq):
     return z
 
 
-def _prox_rows(zh, rho, site, peak_b, T, lf, lf_ext):
+def _prox_rows(zh, rho, site, limits, peak_b, T, lf, lf_ext):
     """z-update for the site rows.  zh is (Mg, Tm)."""
     z = zh.copy()
     M = site.M
     if site.cone == CONE_SOC:
         re, im = zh[:M], zh[M : 2 * M]
         nrm = np.hypot(re, im)
-        scale = np.where(nrm > site.limits[:, None], site.limits[:, None] / np.maximum(nrm, 1e-300), 1.0)
+        scale = np.where(nrm > limits[:, None], limits[:, None] / np.maximum(nrm, 1e-300), 1.0)
         z[:M] = re * scale
         z[M : 2 * M] = im * scale
         r = 2 * M
     else:
-        z[:M] = np.minimum(zh[:M], site.limits[:, None])
+        z[:M] = np.minimum(zh[:M], limits[:, None])
         r = M
     if getattr(site, "has_flat", False):   # prox of 1/2 lf z^2 on the aggregate-power row
         z[r] = zh[r] * (rho / (rho + lf))
@@ -122,9 +194,15 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
     if ub.max() > 0:
         pdiag = max(pdiag, opts.reg_rel * np.abs(q).max() / (ub.max() * max(1, T)))
     eq = bool(batch.s_eq[b])
-    G, Gh, lam, Q = site.G, site.Ghat, site.lam, site.Q
-    Mg = G.shape[0]
+    G, Gh, lam, Q, limits = site.G, site.Ghat, site.lam, site.Q, site.limits
     peak_b = batch.peak[b] if batch.peak is not None else None
+    lf_b = float(batch.lf[b])
+    if opts.equilibrate:
+        from .admm_port import equilibrated
+        G, Gh, Q, lam, limits, pk_s, fl_s, _ = equilibrated(site)
+        peak_b = None if peak_b is None else peak_b * pk_s
+        lf_b /= fl_s * fl_s
+    Mg = G.shape[0]
     sig, alpha = opts.sigma, opts.alpha
     rho = opts.rho
     x = np.zeros((N, Tm))
@@ -136,6 +214,7 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
     status = ST_MAX_ITER
     pri = dua = np.inf
     it = 0
+    aa = _Anderson(opts.accel_mem, N * Tm + Mg * Tm) if opts.accel_mem > 0 else None
     for it in range(1, opts.max_iter + 1):
         a = sig + pdiag + rho
         r0 = sig * x - q + rho * z1 - y1
@@ -150,12 +229,16 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
         x = alpha * xt + (1 - alpha) * x
         Gx = alpha * zt2 + (1 - alpha) * Gx
         zh1 = alpha * xt + (1 - alpha) * z1 + y1 / rho
+        zh2 = alpha * zt2 + (1 - alpha) * z2 + y2 / rho
+        check = it % opts.check_every == 0 or it == opts.max_iter
+        if aa is not None and it % AA_PERIOD == 0:
+            u = aa.event(np.concatenate([zh1.ravel(), zh2.ravel()]), not check)
+            zh1, zh2 = u[: N * Tm].reshape(N, Tm), u[N * Tm :].reshape(Mg, Tm)
         z1 = _project_B(zh1, lb, ub, batch.s_off[b], batch.s_len[b], batch.s_cap[b], eq)
         y1 = rho * (zh1 - z1)
-        zh2 = alpha * zt2 + (1 - alpha) * z2 + y2 / rho
-        z2 = _prox_rows(zh2, rho, site, peak_b, T, float(batch.lf[b]), None)
+        z2 = _prox_rows(zh2, rho, site, limits, peak_b, T, lf_b, None)
         y2 = rho * (zh2 - z2)
-        if it % opts.check_every == 0 or it == opts.max_iter:
+        if check:
             Gty = G.T @ y2
             pri = max(np.abs(x - z1).max(), np.abs(Gx - z2).max() if Mg else 0.0)
             dua = np.abs(pdiag * x + q + y1 + Gty).max()
@@ -170,6 +253,8 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
                 ratio = np.sqrt((pri / max(npri, 1e-12)) / max(dua / max(ndua, 1e-12), 1e-30))
                 if ratio > opts.adapt_tol or ratio < 1.0 / opts.adapt_tol:
                     rho = float(np.clip(rho * ratio, 1e-6, 1e6))
+                    if aa is not None:   # the fixed-point map changed: restart the ring from (z, y)
+                        aa.restart(np.concatenate([(z1 + y1 / rho).ravel(), (z2 + y2 / rho).ravel()]))
     # the feasible iterate is z1 (it satisfies bounds and energy rows exactly)
     xs = z1
     obj = 0.5 * pdiag * (xs * xs).sum() + (q * xs).sum()

@@ -26,7 +26,7 @@ def test_header_symbols_all_exported(hip_library):
 
 
 def test_abi_version_and_defaults(hip_library):
-    assert hip_library.acnqp_abi_version() == 3
+    assert hip_library.acnqp_abi_version() == 4
     o = backend.default_options()
     assert o.precision == 64 and 0 < o.alpha < 2 and o.max_iter > 0 and o.eps_abs > 0
     o2 = backend.default_options(eps_abs=1e-9, max_iter=5)
@@ -49,6 +49,7 @@ def test_create_rejects_bad_arguments(hip_library):
     assert hip_library.acnqp_create(C.byref(desc), 0, C.byref(h)) == -1   # bad cone
     assert hip_library.acnqp_solve_batch(None, None, None, None) == -1
     assert hip_library.acnqp_last_kernel_ms(None) < 0
+    assert hip_library.acnqp_accel_columns(None, 12, 1, 64, 10) == 0
     hip_library.acnqp_destroy(None)   # no-op
 
 

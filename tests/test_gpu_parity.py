@@ -345,8 +345,17 @@ def test_config3_horizon24_fp32_and_fp64(site_name):
     sb.B = 4
     for name in ("T", "lb", "ub", "q", "pdiag", "lf", "s_off", "s_len", "s_cap", "s_eq"):
         setattr(sb, name, getattr(batch, name)[:4])
-    ref = admm_port.solve_batch(sb, threads=4)
-    assert np.abs(ref["x"] - r64.x[:4]).max() <= 1e-5
+    # ... near-bitwise without Anderson acceleration (same arithmetic, same iteration counts) ...
+    ref = admm_port.solve_batch(sb, threads=4, accel_mem=0)
+    plain = h.solve(batch, default_options(accel_mem=0))
+    assert np.abs(ref["x"] - plain.x[:4]).max() <= 1e-5
+    assert (ref["iters"] == plain.iters[:4]).all()
+    # ... and to solver tolerance with it (the extrapolation amplifies rounding differences)
+    m_eff = h.accel_columns(batch.Tm, batch.K, default_options())
+    assert m_eff > 0
+    ref = admm_port.solve_batch(sb, threads=4, accel_mem=m_eff)
+    assert np.abs(ref["x"] - r64.x[:4]).max() <= 5e-4
+    assert np.abs(plain.x - r64.x).max() <= 5e-4
     r32 = h.solve(batch, default_options(eps_abs=5e-5, eps_rel=5e-5, precision=32))
     r64l = h.solve(batch, default_options(eps_abs=5e-5, eps_rel=5e-5))
     # fp32 is the throughput configuration of BASELINE.json configs[2], not a parity configuration: on these
@@ -374,7 +383,8 @@ def test_wide_site_general_kernel():
         h = SiteHandle(batch.site, 0)
         res = h.solve(batch, default_options())
         assert (res.status == 1).all()
-        ref = admm_port.solve_batch(batch, threads=8)
+        assert h.accel_columns(batch.Tm, batch.K, default_options()) == 0   # general kernel: plain ADMM
+        ref = admm_port.solve_batch(batch, threads=8, accel_mem=0)
         assert (ref["status"] == 1).all()
         assert np.abs(ref["x"] - res.x).max() <= 1e-5
         h.close()
@@ -635,7 +645,8 @@ def test_randomised_paths_match_c_port(case):
     assert (batch.K == 2) == two or not two
     h = SiteHandle(batch.site, 0)
     res = h.solve(batch, default_options(max_iter=30000))
-    ref = admm_port.solve_batch(batch, threads=8, max_iter=30000)
+    m_eff = h.accel_columns(batch.Tm, batch.K, default_options())
+    ref = admm_port.solve_batch(batch, threads=8, max_iter=30000, accel_mem=m_eff)
     both = (res.status == 1) & (ref["status"] == 1)
     assert both.sum() >= B - 2, (res.status, ref["status"])     # an occasional slow instance may hit max_iter
     assert ((res.status == 1) == (ref["status"] == 1)).all() or (res.status[~both] == 3).all()

@@ -1,5 +1,5 @@
 """Quick perf/correctness probe on the GPU (dev tool)."""
-import sys, time, json
+import os, sys, time, json
 sys.path.insert(0, '.')
 import numpy as np
 import torch
@@ -17,7 +17,8 @@ for ct in ("SOC","LINEAR"):
         batch = build_batch(snaps, infra, iface, obj, ct)
         h = SiteHandle(batch.site, 0)
         dev = DeviceBatch(batch, "cuda:0")
-        o = default_options()
+        o = default_options(accel_mem=int(os.environ.get('ACCEL', '10')))
+        m_eff = h.accel_columns(batch.Tm, batch.K, o)
         st = torch.cuda.current_stream().cuda_stream
         for _ in range(2): h.solve_device(dev, o, stream=st)
         torch.cuda.synchronize()
@@ -25,9 +26,9 @@ for ct in ("SOC","LINEAR"):
         for _ in range(5):
             h.solve_device(dev, o, stream=st); ms.append(h.last_kernel_ms())
         it = dev.iters.cpu().numpy(); stt = dev.status.cpu().numpy()
-        line = f"{ct} B={B} kernel_ms={np.mean(ms):.3f} iters mean {it.mean():.0f} max {it.max()} solved {(stt==1).sum()} us/iter(max) {1e3*np.mean(ms)/it.max():.2f} QP/s {B/np.mean(ms)*1e3:.0f}"
+        line = f"{ct} B={B} accel={m_eff} kernel_ms={np.mean(ms):.3f} iters mean {it.mean():.0f} max {it.max()} solved {(stt==1).sum()} us/iter(max) {1e3*np.mean(ms)/it.max():.2f} QP/s {B/np.mean(ms)*1e3:.0f}"
         if B == 256:
-            ref = admm_port.solve_batch(batch, threads=16)
+            ref = admm_port.solve_batch(batch, threads=16, accel_mem=m_eff)
             x = dev.x.cpu().numpy()
             line += f" | vs port: max|dx| {np.abs(x-ref['x']).max():.2e} iters equal {(it==ref['iters']).mean():.3f}"
         print(line, flush=True)

@@ -8,7 +8,7 @@ from adacharge_amd.builder import build_batch
 from tests import helpers as H
 infra, iface = H.caltech_interface()
 obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
-names = ["r0+P+wh(8mfma)","barrier","psum+eh+hh","xt mfma+clip","xpose back+y1","siterows","check","xpose fwd","newton-other","nt:elem+sums","nt:decide","nt:flags"]
+names = ["r0+P+wh(8mfma)","barrier","psum+eh+hh","xt mfma+clip","xpose back+y1","siterows","check","xpose fwd","newton-other","anderson event","aa:dots+reduce","aa:solve"]
 for ct in ("SOC","LINEAR"):
     snaps = sites.snapshot_batch(infra, 12, 256, seed=20240)
     batch = build_batch(snaps, infra, iface, obj, ct)
