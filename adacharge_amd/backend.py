@@ -113,6 +113,7 @@ EXPORTED_SYMBOLS = (
     "acnqp_abi_version",
     "acnqp_last_kernel_ms",
     "acnqp_accel_columns",
+    "acnqp_kernel_times",
 )
 
 _lib = None
@@ -164,6 +165,8 @@ def load_library():
     lib.acnqp_last_kernel_ms.restype = C.c_float
     lib.acnqp_accel_columns.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.acnqp_accel_columns.restype = C.c_int32
+    lib.acnqp_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int32]
+    lib.acnqp_kernel_times.restype = C.c_int32
     _lib = lib
     return lib
 
@@ -298,6 +301,13 @@ class SiteHandle:
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.acnqp_last_kernel_ms(self._h))
+
+    def kernel_times(self, capacity: int = 64):
+        """Durations (ms) of the launches since the previous call (at most the 64 most recent); blocks
+        until they have finished."""
+        buf = (C.c_float * int(capacity))()
+        n = int(self._lib.acnqp_kernel_times(self._h, buf, int(capacity)))
+        return [float(buf[k]) for k in range(n)]
 
     def accel_columns(self, t_max: int, k_sessions: int, options: Options) -> int:
         """Anderson columns the kernels use for this problem shape under ``options`` (shape-only rule)."""

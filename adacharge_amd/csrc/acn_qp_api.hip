@@ -111,8 +111,9 @@ struct acnqp_handle {
   int NW = 4, NP = 64;
   std::vector<double> G, limits;   // host copy in ABI order
   SiteDev dev64, dev32;
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-  bool timed = false;
+  static constexpr int kEvRing = 64;               // event pairs of the most recent launches
+  hipEvent_t ev_start[kEvRing] = {}, ev_stop[kEvRing] = {};
+  long long launches = 0, reported = 0;           // launches recorded / already handed out by acnqp_kernel_times
   hipStream_t stream = nullptr;   // used by the host-buffer entry point
   DevBuf in, out;                 // staging for the host-buffer entry point
   DevBuf work;                    // workspace of the general-shape kernel
@@ -249,16 +250,16 @@ hipError_t launch_tiled_occ(const acnqp::TiledArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-// Two register budgets of the same kernel: one workgroup per CU with the whole register file
-// (latency-optimal when the batch does not exceed the 256 CUs), or two per CU (throughput-optimal for
-// larger batches: the second workgroup hides the first one's dependent-chain latency).  The number of
-// Anderson columns never depends on the batch size (results must not): the two-per-CU variant is only
-// taken when the requested columns fit its smaller ring.
+// Two register budgets of the same kernel.  The 256-register build lets two workgroups share a CU
+// (the second hides the first one's dependent-chain latency, and problems of a second batch on another
+// stream can move in while stragglers finish); it is taken whenever it exists for the shape and the
+// requested Anderson ring fits half the LDS -- a function of the shape only, never of the batch size,
+// so that a problem's result does not depend on what it is batched with.
 template <typename real, int NW, int CT, int MT, int KS>
 hipError_t launch_tiled(acnqp::TiledArgs a, int requested_accel, hipStream_t st) {
   a.accel_mem = std::min(requested_accel, accel_capacity<real>(NW, MT, CT, a.NP, a.K, 1));
   if constexpr (CT == 1 && MT <= 2 && KS == 1) {
-    if (a.B > 256 && a.accel_mem <= accel_capacity<real>(NW, MT, CT, a.NP, a.K, 2))
+    if (a.accel_mem <= accel_capacity<real>(NW, MT, CT, a.NP, a.K, 2))
       return launch_tiled_occ<real, NW, CT, MT, KS, 2>(a, st);
   }
   return launch_tiled_occ<real, NW, CT, MT, KS, 1>(a, st);
@@ -341,8 +342,11 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
   h->NP = N <= 64 ? 64 : 16 * ((N + 15) / 16);
   h->G.assign(site->G, site->G + (size_t)Mg * N);
   h->limits.assign(site->limits, site->limits + M);
-  hipError_t e = hipEventCreate(&h->ev_start);
-  if (e == hipSuccess) e = hipEventCreate(&h->ev_stop);
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < acnqp_handle::kEvRing && e == hipSuccess; ++k) {
+    e = hipEventCreate(&h->ev_start[k]);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev_stop[k]);
+  }
   if (e == hipSuccess) e = hipStreamCreate(&h->stream);
   if (e != hipSuccess) {
     std::string msg = std::string("acnqp_create: ") + hipGetErrorString(e);
@@ -360,8 +364,10 @@ void acnqp_destroy(acnqp_handle* h) {
   (void)hipSetDevice(h->device);
   h->dev64.release();
   h->dev32.release();
-  if (h->ev_start) (void)hipEventDestroy(h->ev_start);
-  if (h->ev_stop) (void)hipEventDestroy(h->ev_stop);
+  for (int k = 0; k < acnqp_handle::kEvRing; ++k) {
+    if (h->ev_start[k]) (void)hipEventDestroy(h->ev_start[k]);
+    if (h->ev_stop[k]) (void)hipEventDestroy(h->ev_stop[k]);
+  }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   h->in.release();
   h->out.release();
@@ -436,7 +442,8 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     ga.t = a;
   }
   (void)hipGetLastError();   // drop any stale error so the check below reports this launch only
-  HIP_TRY(hipEventRecord(h->ev_start, st));
+  const int evk = (int)(h->launches % acnqp_handle::kEvRing);
+  HIP_TRY(hipEventRecord(h->ev_start[evk], st));
   hipError_t e = hipSuccess;
   if (tiled) {
     e = (o->precision == 32) ? launch_any<float>(a, h->NW, st) : launch_any<double>(a, h->NW, st);
@@ -448,8 +455,8 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     e = hipGetLastError();
   }
   if (e != hipSuccess) return fail(ACNQP_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
-  HIP_TRY(hipEventRecord(h->ev_stop, st));
-  h->timed = true;
+  HIP_TRY(hipEventRecord(h->ev_stop[evk], st));
+  ++h->launches;
   return ACNQP_OK;
 }
 
@@ -467,12 +474,27 @@ int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, 
   return std::min(requested, cap);
 }
 
-float acnqp_last_kernel_ms(acnqp_handle* h) {
-  if (!h || !h->timed) return -1.0f;
-  if (hipEventSynchronize(h->ev_stop) != hipSuccess) return -1.0f;
+static float event_pair_ms(acnqp_handle* h, long long launch) {
+  const int k = (int)(launch % acnqp_handle::kEvRing);
+  if (hipEventSynchronize(h->ev_stop[k]) != hipSuccess) return -1.0f;
   float ms = -1.0f;
-  if (hipEventElapsedTime(&ms, h->ev_start, h->ev_stop) != hipSuccess) return -1.0f;
+  if (hipEventElapsedTime(&ms, h->ev_start[k], h->ev_stop[k]) != hipSuccess) return -1.0f;
   return ms;
+}
+
+float acnqp_last_kernel_ms(acnqp_handle* h) {
+  if (!h || h->launches == 0) return -1.0f;
+  return event_pair_ms(h, h->launches - 1);
+}
+
+int32_t acnqp_kernel_times(acnqp_handle* h, float* out_ms, int32_t capacity) {
+  if (!h || !out_ms || capacity <= 0) return 0;
+  long long first = std::max(h->reported, h->launches - acnqp_handle::kEvRing);
+  first = std::max(first, h->launches - (long long)capacity);
+  int32_t n = 0;
+  for (long long l = first; l < h->launches; ++l) out_ms[n++] = event_pair_ms(h, l);
+  h->reported = h->launches;
+  return n;
 }
 
 int acnqp_solve_batch(acnqp_handle* h, const acnqp_problems* p, const acnqp_options* o, acnqp_results* r) {

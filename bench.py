@@ -11,7 +11,10 @@ already resident in HBM.  Workload = BASELINE.json configs[1]: Caltech-shaped
 own integration-test objective, t_int.py:67-70), the reference's default SOC
 constraints (aco.py:35), fp64 ADMM, batch 256 per GPU (weak scaling: every rank
 gets its own 256 snapshots; for N > 1 each step ends with one RCCL all-gather of
-the schedules so every rank holds the whole job's result).
+the schedules so every rank holds the whole job's result).  `--pipeline D`
+(default 8) keeps D such batches in flight per GPU, each on its own stream: a
+launch lasts as long as its slowest problem, so the next batches' workgroups
+move into the CUs the finished problems have left.
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement), with
 `roofline` (HBM algorithmic bytes / measured kernel time) and `cpu_baseline`
@@ -26,6 +29,11 @@ import os
 import sys
 import time
 
+# Batches are kept in flight on separate HIP streams (--pipeline); the runtime multiplexes streams onto
+# 4 hardware queues by default, and two streams that share a queue run back to back.  Must be set before
+# the HIP runtime initialises (i.e. before torch is imported).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -36,15 +44,34 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6     # vector fp64 (vendor figure)
 
 
+def new_stream(dev):
+    """A fresh HIP stream (hipStreamCreateWithFlags, non-blocking) wrapped for torch.  torch's own stream
+    pool is created 64 streams at a time and shares the hardware queues among them in an order the caller
+    cannot see; streams created here, one per batch in flight and before that pool exists, each get a
+    hardware queue of their own as long as GPU_MAX_HW_QUEUES allows."""
+    import ctypes
+
+    import torch
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    handle = ctypes.c_void_p()
+    rc = hip.hipStreamCreateWithFlags(ctypes.byref(handle), ctypes.c_uint(1))   # hipStreamNonBlocking
+    if rc != 0:
+        raise RuntimeError(f"hipStreamCreateWithFlags failed ({rc})")
+    return torch.cuda.ExternalStream(handle.value, device=dev)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=256, help="problems per GPU per step")
     ap.add_argument("--horizon", type=int, default=12)
     ap.add_argument("--constraint-type", default="SOC", choices=["SOC", "LINEAR"])
     ap.add_argument("--precision", type=int, default=64, choices=[64, 32])
+    ap.add_argument("--pipeline", type=int, default=8,
+                    help="batches kept in flight per GPU, one HIP stream each (1 = strictly one launch at a time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -170,26 +197,34 @@ def main():
     iface = Interface({"infrastructure_info": infra, "period": 5})
     T, B = args.horizon, args.batch
     objective = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
-    snaps = sites.snapshot_batch(infra, T, B, seed=20240 + rank)
-    batch = build_batch(snaps, infra, iface, objective, args.constraint_type)
-    handle = SiteHandle(batch.site, local_rank)
-    dbatch = DeviceBatch(batch, dev)
     opts = default_options(precision=args.precision)
     if args.precision == 32:
         opts.eps_abs = opts.eps_rel = 5e-5
-    stream = torch.cuda.current_stream().cuda_stream
     gdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
-    gathered = (
-        torch.empty((world * B, batch.N, batch.Tm), dtype=torch.float64, device=gdev) if world > 1 else None
-    )
+    # `--pipeline` independent batches per GPU, each with its own inputs, result tensors, HIP stream and
+    # gather buffer: a step launches the next batch on the next stream, so that a batch's stragglers
+    # (the launch lasts as long as its slowest problem) overlap with the following batch's solves.
+    depth = max(1, args.pipeline)
+    slots = []
+    for s_ in range(depth):
+        sn = sites.snapshot_batch(infra, T, B, seed=20240 + rank + 1000 * s_)
+        bt = build_batch(sn, infra, iface, objective, args.constraint_type)
+        slots.append(dict(
+            snaps=sn, batch=bt, handle=SiteHandle(bt.site, local_rank), dbatch=DeviceBatch(bt, dev),
+            stream=new_stream(dev) if depth > 1 else torch.cuda.current_stream(),
+            gathered=torch.empty((world * B, bt.N, bt.Tm), dtype=torch.float64, device=gdev) if world > 1 else None,
+        ))
+    snaps, batch, handle, dbatch = (slots[0][k] for k in ("snaps", "batch", "handle", "dbatch"))
 
-    def step():
-        handle.solve_device(dbatch, opts, stream=stream)
-        if world > 1:   # the one collective of the job: every rank ends up with all schedules
-            if args.dist_backend == "nccl":
-                dist.all_gather_into_tensor(gathered, dbatch.x)
-            else:
-                dist.all_gather(list(gathered.chunk(world)), dbatch.x.cpu())
+    def step(i):
+        sl = slots[i % depth]
+        with torch.cuda.stream(sl["stream"]):
+            sl["handle"].solve_device(sl["dbatch"], opts, stream=sl["stream"].cuda_stream)
+            if world > 1:   # the one collective of the job: every rank ends up with all schedules
+                if args.dist_backend == "nccl":
+                    dist.all_gather_into_tensor(sl["gathered"], sl["dbatch"].x)
+                else:
+                    dist.all_gather(list(sl["gathered"].chunk(world)), sl["dbatch"].x.cpu())
 
     def fence():
         torch.cuda.synchronize()
@@ -197,16 +232,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(depth):     # setup, not warm-up: every slot's first launch (module load, LDS attribute)
+        step(i)
     fence()
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    for sl in slots:
+        sl["handle"].kernel_times()   # discard the warm-up launches
     kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(handle.last_kernel_ms())   # HIP events on the launch stream
+    for i in range(args.steps):
+        step(i)
+        if (i + 1) % (32 * depth) == 0:   # the event ring holds 64 launches per handle
+            for sl in slots:
+                kernel_ms += sl["handle"].kernel_times()
     fence()
     elapsed = time.perf_counter() - t0
+    for sl in slots:
+        kernel_ms += sl["handle"].kernel_times()   # HIP events on the launch streams, read after the fence
+    gathered = slots[0]["gathered"]
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -215,15 +260,17 @@ def main():
     x = dbatch.x.cpu().numpy()
     status = dbatch.status.cpu().numpy()
     iters = dbatch.iters.cpu().numpy()
-    solved = int((status == 1).sum())
+    used = slots
+    solved = int(sum(int((sl["dbatch"].status == 1).sum().item()) for sl in used))
+    iters_all = np.concatenate([sl["dbatch"].iters.cpu().numpy() for sl in used])
     if world > 1:
-        cnt = torch.tensor([solved, B], dtype=torch.int64, device=gdev)
+        cnt = torch.tensor([solved, B * len(used)], dtype=torch.int64, device=gdev)
         dist.all_reduce(cnt)
         solved_all, total_all = int(cnt[0]), int(cnt[1])
         if rank == 0:   # the gather really carries every rank's schedules
             assert torch.equal(gathered[:B].to(dev), dbatch.x)
     else:
-        solved_all, total_all = solved, B
+        solved_all, total_all = solved, B * len(used)
 
     if rank == 0:
         k_avg_ms = float(np.mean(kernel_ms))
@@ -237,8 +284,8 @@ def main():
             except Exception:
                 traffic = None
         fl = flops_per_iteration(batch.N, batch.Tm, batch.site)
-        # SIMT cost: every problem of a launch occupies its CU until its own last iteration
-        valu_tf = float(iters.sum()) * fl / (k_avg_ms * 1e-3) / 1e12
+        # flops of the iterations actually run (mean over the batches in flight) per second of wall time
+        valu_tf = float(iters_all.mean()) * B * args.steps * fl / elapsed / 1e12
         out = {
             "metric": "MPC QP solves/sec whole-node, 54 EVSE x horizon 12; max rate residual vs cvxpy",
             "value": world * B * args.steps / elapsed,
@@ -257,12 +304,14 @@ def main():
                             f"{args.constraint_type} constraints, batch {B} independent MPC snapshots per GPU "
                             f"(BASELINE.json configs[1])",
                 "batch_per_gpu": B, "n_evse": batch.N, "horizon": T, "constraint_type": args.constraint_type,
+                "batches_in_flight_per_gpu": depth,
                 "parallelism": f"dp{world} (one batch shard per GPU" + (", RCCL all-gather of schedules per step)" if world > 1 else ")"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "acnqp::admm_tiled_kernel<double, 4, 1, 1, 1>" if args.precision == 64 else "acnqp::admm_tiled_kernel<float, 4, 1, 1, 1>", "kernel_avg_ms": k_avg_ms,
+                "kernel": "acnqp::admm_tiled_kernel<%s, 4, 1, 1, 1, 2, 5>" % ("double" if args.precision == 64 else "float"),
+                "kernel_avg_ms": k_avg_ms, "launches_timed": len(kernel_ms), "launches_in_flight": depth,
                 "algorithmic_bytes_per_launch": abytes, "bytes_per_qp": per_qp,
                 "note": "LDS-resident iterative solver: HBM is touched once per problem, so the HBM fraction is "
                         "small by construction (SURVEY.md H8); the VALU view is in `valu`",
@@ -270,7 +319,7 @@ def main():
             "valu": {
                 "achieved": valu_tf, "peak": FP64_VALU_PEAK_TF if args.precision == 64 else 157.3, "unit": "TFLOP/s",
                 "frac": valu_tf / (FP64_VALU_PEAK_TF if args.precision == 64 else 157.3),
-                "flops_per_iteration": fl, "iterations_mean": float(iters.mean()), "iterations_max": int(iters.max()),
+                "flops_per_iteration": fl, "iterations_mean": float(iters_all.mean()), "iterations_max": int(iters_all.max()),
             },
             "solver": {
                 "solved": solved_all, "problems": total_all,

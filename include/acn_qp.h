@@ -166,6 +166,13 @@ int32_t acnqp_abi_version(void);
  * stream has been synchronised); < 0 if none.  Used by bench.py's roofline. */
 float acnqp_last_kernel_ms(acnqp_handle* h);
 
+/* Durations (ms, oldest first) of the launches made through this handle since
+ * the previous call -- at most the 64 most recent and at most `capacity` --
+ * without forcing the caller to synchronise between launches (batches kept in
+ * flight on several streams).  Blocks until those launches have finished.
+ * Returns the number of values written.                                      */
+int32_t acnqp_kernel_times(acnqp_handle* h, float* out_ms, int32_t capacity);
+
 /* Anderson columns the kernels will actually use for problems of this shape
  * (t_max periods, k_sessions slots) at the given precision when `requested`
  * columns are asked for: a function of the shape only, never of the batch

@@ -50,6 +50,7 @@ def test_create_rejects_bad_arguments(hip_library):
     assert hip_library.acnqp_solve_batch(None, None, None, None) == -1
     assert hip_library.acnqp_last_kernel_ms(None) < 0
     assert hip_library.acnqp_accel_columns(None, 12, 1, 64, 10) == 0
+    assert hip_library.acnqp_kernel_times(None, None, 0) == 0
     hip_library.acnqp_destroy(None)   # no-op
 
 
