@@ -656,6 +656,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
             }
           d[AMX] = a1 + w0 * a2;
         }
+        // (f, g) of this event replace the previous ones now, so that nothing but zh / zhr crosses the barrier
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            fp1[c][r] = f1[c][r]; gp1[c][r] = zh[c][r];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) { fp2[m][c][r] = f2[m][c][r]; gp2[m][c][r] = zhr[m][c][r]; }
+          }
         // block-wide sums: wave reductions (independent chains), one LDS slot per wave, the event's barrier
 #pragma unroll
         for (int j = 0; j < AMX + 2; ++j) d[j] = wave_sum<real>(d[j]);
@@ -700,53 +709,31 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            fp1[c][r] = f1[c][r]; gp1[c][r] = zh[c][r];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) { fp2[m][c][r] = f2[m][c][r]; gp2[m][c][r] = zhr[m][c][r]; }
-          }
         aa_have_prev = true; fn_prev = fn; aa_was = false;
         if (aa_cnt > 0 && aa_cool == 0 && !check) {
-          // gamma = (H + eta I)^-1 b by LDL' (H is a Gram matrix: no pivoting), every lane redundantly
-          real Hm[AMX][AMX], gam[AMX], dd[AMX];
+          // gamma = (H + eta I)^-1 b: Gauss-Jordan on the augmented AM x (AM + 1) system spread over the
+          // wave, lane 8 i + j holding entry (i, j) (H is a regularised Gram matrix: no pivoting); a few
+          // registers per lane instead of the whole matrix in every lane.
+          static_assert(AMX <= 7, "one 8 x 8 lane tile holds the augmented system");
+          const int gi = lane >> 3, gj = lane & 7;
           real tr = 0;
 #pragma unroll
-          for (int i = 0; i < AMX; ++i) {
-#pragma unroll
-            for (int j = 0; j <= i; ++j) Hm[i][j] = AaH[i * AMX + j];
-            gam[i] = AaH[AMX * AMX + i];
-            tr += Hm[i][i];                       // dead slots hold zeros
-          }
+          for (int i = 0; i < AMX; ++i) tr += AaH[i * AMX + i];          // dead slots hold zeros
           const real eta = (real)kAaReg * tr + (real)(sizeof(real) == 8 ? 1e-300 : 1e-37);
+          real ae = 0;
+          if (gi < AMX && gj <= AMX) ae = gj < AMX ? AaH[gi * AMX + gj] : AaH[AMX * AMX + gi];
+          if (gi < AMX && gi == gj) ae = ((aa_valid >> gi) & 1u) ? ae + eta : (real)1;
 #pragma unroll
-          for (int i = 0; i < AMX; ++i) Hm[i][i] = ((aa_valid >> i) & 1u) ? Hm[i][i] + eta : (real)1;
-          // right-looking LDL': after column j the trailing block is updated at once (independent FMAs)
-#pragma unroll
-          for (int j = 0; j < AMX; ++j) {
-            dd[j] = rcp_nr(Hm[j][j]);                       // 1 / d_j
-#pragma unroll
-            for (int i = j + 1; i < AMX; ++i) {
-              const real lij = Hm[i][j] * dd[j];
-#pragma unroll
-              for (int k = j + 1; k <= i; ++k) Hm[i][k] -= lij * Hm[k][j];   // column j is still unscaled (l_kj d_j)
-            }
-#pragma unroll
-            for (int i = j + 1; i < AMX; ++i) Hm[i][j] *= dd[j];
+          for (int k = 0; k < AMX; ++k) {
+            const real piv = __shfl(ae, 9 * k);
+            const real rk = __shfl(ae, 8 * k + gj);
+            const real ck = __shfl(ae, 8 * gi + k);
+            const real rs = rk * rcp_nr(piv);
+            ae = gi == k ? rs : ae - ck * rs;
           }
-          // L y = b, D, L' gamma = y: column-oriented so that each stage is a batch of independent FMAs
+          real gam[AMX];
 #pragma unroll
-          for (int k = 0; k < AMX; ++k)
-#pragma unroll
-            for (int i = k + 1; i < AMX; ++i) gam[i] -= Hm[i][k] * gam[k];
-#pragma unroll
-          for (int i = 0; i < AMX; ++i) gam[i] *= dd[i];
-#pragma unroll
-          for (int k = AMX - 1; k >= 0; --k)
-#pragma unroll
-            for (int i = 0; i < k; ++i) gam[i] -= Hm[k][i] * gam[k];
+          for (int j = 0; j < AMX; ++j) gam[j] = __shfl(ae, 8 * j + AMX);
           STAMP(11);   // event: LDL' solve
 #pragma unroll
           for (int j = 0; j < AMX; ++j) {

@@ -96,23 +96,20 @@ static void aa_solve(int m, const double* H, const double* bvec, unsigned valid,
     }
     Hm[i][i] = vi ? Hm[i][i] + eta : 1.0;
   }
-  /* right-looking LDL': d[] holds 1/d_j; Hm is overwritten by L (strict lower part) */
-  for (int j = 0; j < m; ++j) {
-    d[j] = 1.0 / Hm[j][j];
-    double u[AA_MAX];
-    for (int i = j + 1; i < m; ++i) u[i] = Hm[i][j];   /* column j before scaling: l_ij d_j */
-    for (int i = j + 1; i < m; ++i) {
-      const double lij = u[i] * d[j];
-      for (int k = j + 1; k <= i; ++k) Hm[i][k] -= lij * u[k];
-      Hm[i][j] = lij;
-    }
+  /* Gauss-Jordan on the augmented system [Hm | b], in the device's operation order (there one lane per
+   * entry): a_ij <- a_ij - a_ik * (a_kj / a_kk), pivot row <- a_kj / a_kk.  No pivoting: regularised Gram matrix. */
+  double A[AA_MAX][AA_MAX + 1];
+  for (int i = 0; i < m; ++i) { for (int j = 0; j < m; ++j) A[i][j] = Hm[i][j]; A[i][m] = bb[i]; }
+  for (int k = 0; k < m; ++k) {
+    const double inv = 1.0 / A[k][k];
+    double rs[AA_MAX + 1], ck[AA_MAX];
+    for (int j = 0; j <= m; ++j) rs[j] = A[k][j] * inv;
+    for (int i = 0; i < m; ++i) ck[i] = A[i][k];
+    for (int i = 0; i < m; ++i)
+      for (int j = 0; j <= m; ++j) A[i][j] = (i == k) ? rs[j] : A[i][j] - ck[i] * rs[j];
   }
-  /* L y = b, D, L' gamma = y: column-oriented, as on the device */
-  for (int i = 0; i < m; ++i) y[i] = bb[i];
-  for (int k = 0; k < m; ++k) for (int i = k + 1; i < m; ++i) y[i] -= Hm[i][k] * y[k];
-  for (int i = 0; i < m; ++i) y[i] *= d[i];
-  for (int k = m - 1; k >= 0; --k) for (int i = 0; i < k; ++i) y[i] -= Hm[k][i] * y[k];
-  for (int i = 0; i < m; ++i) gam[i] = y[i];
+  for (int i = 0; i < m; ++i) gam[i] = A[i][m];
+  (void)d; (void)y;
 }
 
 static int solve_one(const port_site* S, const port_opts* O, int horizon, const double* lb, const double* ub_in, const double* q,

@@ -5,7 +5,7 @@ set -o pipefail
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out/prof_${1:-r01}
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline"
+ARGS="--steps 16 --warmup 8 --no-cpu-baseline"
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 echo "trace rc=$?"

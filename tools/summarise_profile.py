@@ -1,0 +1,51 @@
+"""Turn the rocprofv3 output of tools/profile_r01.sh (gpurun_out/prof_<tag>/) into the committed
+summaries under profiles/: <tag>_kernel_stats.csv, <tag>_pmc_summary.json, hbm_traffic.json.
+
+    python tools/summarise_profile.py r01c
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+KERNEL = "admm_tiled_kernel"
+
+stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+summary = {}
+meta = None
+for f in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True)):
+    per = {}
+    for row in csv.DictReader(open(f)):
+        if KERNEL not in row["Kernel_Name"]:
+            continue
+        per.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
+        per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+        if meta is None:
+            meta = {k: row[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+                                        "Accum_VGPR_Count", "SGPR_Count") if k in row}
+    for name, d in per.items():
+        v = list(d.values())
+        summary[name] = {"dispatches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+summary["_kernel"] = meta
+summary["_command"] = ("rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --steps 16 --warmup 8 "
+                       "--no-cpu-baseline (one pass per counter group, tools/profile_r01.sh)")
+json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
+if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+    fk, wk = summary["FETCH_SIZE"]["mean"], summary["WRITE_SIZE"]["mean"]
+    json.dump({
+        "round": tag,
+        "FETCH_SIZE_KB_per_launch": fk, "WRITE_SIZE_KB_per_launch": wk,
+        "correction": "MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE reports 1/2 of the bytes of a coalesced "
+                      "streaming read -> doubled; WRITE_SIZE exact; KB = 1024 B",
+        "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
+        "raw_uncorrected_bytes_per_launch": (fk + wk) * 1024,
+    }, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in summary.items() if not k.startswith("_")}, indent=1)[:3000])
