@@ -96,9 +96,10 @@ struct SiteDev {
   int MR = 0;                    // padded rows (multiple of 16)
   double peak_scale = 1, flat_scale = 1, max_scale = 1;   // row-equilibration factors of the prox rows
   void *G = nullptr, *Ghat = nullptr, *Q = nullptr, *lam = nullptr, *rowlim = nullptr;
+  void *fragG = nullptr, *fragQ = nullptr;   // Ghat / Q in MFMA A-operand fragment order (tiled kernel)
   int32_t* rowtype = nullptr;
   void release() {
-    for (void** p : {&G, &Ghat, &Q, &lam, &rowlim}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    for (void** p : {&G, &Ghat, &Q, &lam, &rowlim, &fragG, &fragQ}) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (rowtype) (void)hipFree(rowtype);
     rowtype = nullptr;
     ready = false;
@@ -208,7 +209,33 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
     if (e != hipSuccess) return e;
     return hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(real), hipMemcpyHostToDevice);
   };
+  // MFMA A-operand fragments in the order the tiled kernel reads them (one coalesced 64-lane row per
+  // fragment register): see acn_qp_tiled.hpp.  Only sites the tiled kernel can take (NP = 64).
+  std::vector<double> fragG, fragQ;
+  if (NP == 64) {
+    const int NWv = NP / 16, MT = MR / 16;
+    fragG.assign((size_t)NWv * MT * 2 * 4 * 64, 0.0);
+    fragQ.assign((size_t)MT * MT * 2 * 4 * 64, 0.0);
+    for (int lane = 0; lane < 64; ++lane) {
+      const int g = lane >> 4, t = lane & 15;
+      for (int sI = 0; sI < 4; ++sI) {
+        const int ro = acnqp::Mfma<real>::rowof(g, sI);
+        for (int m = 0; m < MT; ++m) {
+          for (int w = 0; w < NWv; ++w) {
+            fragG[((((size_t)w * MT + m) * 2 + 0) * 4 + sI) * 64 + lane] = Gh[(size_t)(16 * m + t) * NP + 16 * w + ro];
+            fragG[((((size_t)w * MT + m) * 2 + 1) * 4 + sI) * 64 + lane] = Gh[(size_t)(16 * m + ro) * NP + 16 * w + t];
+          }
+          for (int mi = 0; mi < MT; ++mi) {   // m plays the role of mo
+            fragQ[((((size_t)m * MT + mi) * 2 + 0) * 4 + sI) * 64 + lane] = Q[(size_t)(16 * mi + ro) * MR + 16 * m + t];
+            fragQ[((((size_t)m * MT + mi) * 2 + 1) * 4 + sI) * 64 + lane] = Q[(size_t)(16 * m + t) * MR + 16 * mi + ro];
+          }
+        }
+      }
+    }
+  }
   hipError_t e = up(&d->G, Gi);
+  if (e == hipSuccess && !fragG.empty()) e = up(&d->fragG, fragG);
+  if (e == hipSuccess && !fragQ.empty()) e = up(&d->fragQ, fragQ);
   if (e == hipSuccess) e = up(&d->Ghat, Gh);
   if (e == hipSuccess) e = up(&d->Q, Q);
   if (e == hipSuccess) e = up(&d->lam, lam);
@@ -418,6 +445,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   acnqp::TiledArgs a;
   a.B = p->batch; a.N = h->N; a.Tm = p->t_max; a.K = p->k_sessions; a.NP = h->NP; a.MR = d->MR;
   a.G = d->G; a.Ghat = d->Ghat; a.Q = d->Q; a.lam = d->lam; a.rowlim = d->rowlim; a.rowtype = d->rowtype;
+  a.fragG = d->fragG; a.fragQ = d->fragQ;
   a.horizon = p->horizon; a.lb = p->lb; a.ub = p->ub; a.q = p->q; a.pdiag = p->pdiag;
   a.s_off = p->s_off; a.s_len = p->s_len; a.s_cap = p->s_cap; a.s_eq = p->s_eq; a.peak = h->has_peak ? p->peak : nullptr;
   a.lf = h->has_flat ? p->lf : nullptr;

@@ -62,6 +62,7 @@ struct TiledArgs {
   int B, N, Tm, K, NP, MR;     // NP = 16 * waves (padded EVSEs), MR = 16 * MT (padded site rows)
   const void *G, *Ghat, *Q, *lam, *rowlim;   // [MR][NP], [MR][NP], [MR][MR], [MR], [MR]  (real)
   const int32_t* rowtype;                     // [MR]
+  const void *fragG, *fragQ;                  // Ghat, Q as MFMA A-operand fragments: [NW][MT][2][4][64], [MT][MT][2][4][64]
   const int32_t* horizon;
   const double *lb, *ub, *q, *pdiag;
   const int32_t *s_off, *s_len;
@@ -275,23 +276,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   const real* Lm = static_cast<const real*>(A.lam);
   const real* RL = static_cast<const real*>(A.rowlim);
 
-  // ---- static MFMA A-operand fragments of this wave ------------------------------------
-  real aP[MT][4];        // Ghat[16m + t'][16w + rowof(g,s)]      (t' = lane & 15 is the A row)
-  real aX[MT][4];        // Ghat[16m + rowof(g,s)][16w + t']
-  real aQt[MT][MT][4];   // Q[16mi + rowof(g,s)][16mo + t']       (w^ = Q' w)
-  real aQ[MT][MT][4];    // Q[16mo + t'][16mi + rowof(g,s)]       (G x~ = Q h^)
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      aP[m][s] = Gh[(size_t)(16 * m + t) * NP + 16 * wave + M::rowof(g, s)];
-      aX[m][s] = Gh[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * wave + t];
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi) {
-        aQt[m][mi][s] = Qm[(size_t)(16 * mi + M::rowof(g, s)) * MR + 16 * m + t];
-        aQ[m][mi][s] = Qm[(size_t)(16 * m + t) * MR + 16 * mi + M::rowof(g, s)];
-      }
-    }
+  // ---- MFMA A-operand fragments of this wave: re-read every iteration from the (L1/L2-resident, shared)
+  // fragment-ordered copies of Ghat and Q (coalesced: one 64-lane row per fragment register) instead of
+  // living in 32 registers per lane across the whole loop
+  //   aP[m][s]      = Ghat[16m + t'][16w + rowof(g,s)]      (t' = lane & 15 is the A row)
+  //   aX[m][s]      = Ghat[16m + rowof(g,s)][16w + t']
+  //   aQt[mo][mi][s] = Q[16mi + rowof(g,s)][16mo + t']      (w^ = Q' w)
+  //   aQ[mo][mi][s]  = Q[16mo + t'][16mi + rowof(g,s)]      (G x~ = Q h^)
   // site-row constants in C layout: row j = 16 m + rowof(g, r)
   real lamv[MT][4], djv[MT][4], limv[MT][4];
   int rtype[MT][4];
@@ -489,6 +480,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   while (!done) {
     ++it;
     real* Pw = Pbuf + (size_t)(it & 1) * NW * MT * CT * 256;
+    const real* FG = static_cast<const real*>(A.fragG) + (size_t)__builtin_amdgcn_readfirstlane(wave) * MT * 2 * 4 * 64;
+    const real* FQ = static_cast<const real*>(A.fragQ);
+    asm volatile("" : "+s"(FG), "+s"(FQ));   // opaque per iteration: keeps the fragment loads inside the loop
 
     // ---- w^ = Q'(rho z2 - y2) and r0 = sigma x - q + rho z1 - y1;  P_w = Ghat_w r0 --------
     vec4 wh[MT][CT], r0[CT];
@@ -500,7 +494,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
       for (int m = 0; m < MT; ++m) {
         vec4 acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = M::mma(aP[m][s], r0[c][s], acc);
+        for (int s = 0; s < 4; ++s) acc = M::mma(FG[((m * 2 + 0) * 4 + s) * 64 + lane], r0[c][s], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Pw[(((wave * MT + m) * CT + c) * 4 + r) * 64 + lane] = acc[r];
       }
@@ -510,7 +504,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = M::mma(aQt[mo][mi][s], rho * z2[mi][c][s] - y2[mi][c][s], acc);
+          for (int s = 0; s < 4; ++s) acc = M::mma(FQ[(((mo * MT + mi) * 2 + 0) * 4 + s) * 64 + lane], rho * z2[mi][c][s] - y2[mi][c][s], acc);
         wh[mo][c] = acc;
       }
     }
@@ -544,7 +538,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = M::mma(aX[m][s], eh[m][c][s], acc);
+        for (int s = 0; s < 4; ++s) acc = M::mma(FG[((m * 2 + 1) * 4 + s) * 64 + lane], eh[m][c][s], acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const real xn = acc[r] * inv_a;
@@ -562,7 +556,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) zt = M::mma(aQ[mo][mi][s], hh[mi][c][s], zt);
+          for (int s = 0; s < 4; ++s) zt = M::mma(FQ[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane], hh[mi][c][s], zt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           gx[mo][c][r] = alpha * zt[r] + ((real)1 - alpha) * gx[mo][c][r];

@@ -16,12 +16,17 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 KERNEL = "admm_tiled_kernel"
 
-stats = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
-if stats:
-    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+if stats:   # newest run only (gpurun merges, it does not delete)
+    shutil.copy(stats[-1], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 summary = {}
 meta = None
-for f in sorted(glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True)):
+newest = {}
+for f in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
+    d_ = os.path.dirname(f)
+    if d_ not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d_]):
+        newest[d_] = f
+for f in sorted(newest.values()):
     per = {}
     for row in csv.DictReader(open(f)):
         if KERNEL not in row["Kernel_Name"]:
