@@ -192,7 +192,7 @@ struct TiledLds {
 
 // Anderson acceleration of the ADMM fixed-point map (restated in oracle/admm_port.c, see there)
 constexpr int kAaPeriod = 5;
-constexpr double kAaReg = 1e-4, kAaSafe = 1.2;
+constexpr double kAaReg = 1e-4, kAaSafe = 1.2, kAaDrift = 1e-3;
 
 // Reductions over the lanes l, l^16, l^32, l^48 (the four quarter-lanes of one EVSE in session
 // layout) with v_permlane16_swap / v_permlane32_swap: swapping a register with itself leaves the
@@ -704,7 +704,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         aa_have_prev = true; fn_prev = fn; aa_was = false;
-        if (aa_cnt > 0 && aa_cool == 0 && !check) {
+        // no extrapolation while the map drifts (|dF_new| <= kAaDrift |f|): the differences are rounding noise
+        real dself = 0;   // |dF_new|^2 (d[slot] without a runtime register index)
+#pragma unroll
+        for (int j = 0; j < AMX; ++j) dself = j == slot ? d[j] : dself;
+        if (aa_cnt > 0 && aa_cool == 0 && !check && dself > (real)(kAaDrift * kAaDrift) * d[AMX + 1]) {
           // gamma = (H + eta I)^-1 b: Gauss-Jordan on the augmented AM x (AM + 1) system spread over the
           // wave, lane 8 i + j holding entry (i, j) (H is a regularised Gram matrix: no pivoting); a few
           // registers per lane instead of the whole matrix in every lane.

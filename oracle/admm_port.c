@@ -75,11 +75,13 @@ static void project_window(int L, const double* v, const double* lb, const doubl
  *   columns dF = f - f_prev, dG = g - g_prev are kept (as floats) in a ring of accel_mem slots
  *   gamma = argmin |f - dF gamma|^2 + eta |gamma|^2,  eta = kAaReg * trace(dF'dF)
  *   u_next = g - dG gamma      (skipped on residual-check iterations and while cooling down)
+ * No extrapolation while |dF_new| <= kAaDrift |f|: the map is drifting (a plateau of the dual), its
+ * differences carry rounding noise only and the least-squares problem is singular.
  * Safeguard: if the residual norm grew by more than kAaSafe after an accelerated step the ring is
  * cleared and acceleration pauses for 1, 2, 4, ... 64 events (exponential back-off).            */
 #define AA_MAX 16
 static const int kAaPeriod = 5;
-static const double kAaReg = 1e-4, kAaSafe = 1.2;
+static const double kAaReg = 1e-4, kAaSafe = 1.2, kAaDrift = 1e-3;
 
 /* solve (H + eta I) gamma = b for the valid columns (LDL', no pivoting: H is a Gram matrix) */
 static void aa_solve(int m, const double* H, const double* bvec, unsigned valid, double* gam) {
@@ -227,7 +229,8 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
       }
       for (int k = 0; k < D; ++k) { fprev[k] = gcur[k] - uprev[k]; gprev[k] = gcur[k]; }
       aa_have_prev = 1; fn_prev = fn; aa_was = 0;
-      if (aa_cnt > 0 && aa_cool == 0 && !check) {
+      const int cnew = (aa_head + MM - 1) % MM;   /* the column this event added (aa_cnt > 0 implies one was) */
+      if (aa_cnt > 0 && aa_cool == 0 && !check && aaH[cnew * AA_MAX + cnew] > kAaDrift * kAaDrift * fn * fn) {
         double gam[AA_MAX];
         aa_solve(MM, aaH, aab, aa_valid, gam);
         for (int j = 0; j < MM; ++j) {

@@ -51,7 +51,7 @@ class AdmmOptions:
     accel_mem: int = 0            # Anderson-acceleration columns (0 = plain ADMM), see _Anderson
 
 
-AA_PERIOD, AA_REG, AA_SAFE = 5, 1e-4, 1.2
+AA_PERIOD, AA_REG, AA_SAFE, AA_DRIFT = 5, 1e-4, 1.2, 1e-3
 
 
 class _Anderson:
@@ -61,7 +61,8 @@ class _Anderson:
     float32) in a ring of ``mem`` slots; gamma = argmin |f - dF gamma|^2 + eta |gamma|^2 with
     eta = AA_REG * trace(dF'dF); u_next = g - dG gamma.  If the residual norm grew by more than
     AA_SAFE after an accelerated step the ring is cleared and acceleration pauses for
-    1, 2, 4, ... 64 events."""
+    1, 2, 4, ... 64 events.  No extrapolation while |dF_new| <= AA_DRIFT |f| (the map is drifting:
+    its differences carry rounding noise only)."""
 
     def __init__(self, mem, dim):
         self.m, self.dim = mem, dim
@@ -108,9 +109,10 @@ class _Anderson:
                     self.b[j] += d            # dF_j . f_k = dF_j . f_(k-1) + dF_j . dF_c
             self.b[c] = float(col @ f)
             self.head = (c + 1) % self.m
+        informative = self.fprev is not None and self.H[(self.head - 1) % self.m, (self.head - 1) % self.m] > (AA_DRIFT * fn) ** 2
         self.fprev, self.gprev, self.fn_prev, self.was = f, g.copy(), fn, False
         u = g
-        if self.valid.any() and self.cool == 0 and may_apply:
+        if self.valid.any() and self.cool == 0 and may_apply and informative:
             v = np.flatnonzero(self.valid)
             Hv = self.H[np.ix_(v, v)]
             eta = AA_REG * np.trace(Hv) + 1e-300
