@@ -152,6 +152,26 @@ class ProblemBatch:
         return self.site.N
 
 
+def scenario_batch(base: ProblemBatch, demand_factor: np.ndarray, problem: int = 0) -> ProblemBatch:
+    """Stochastic-MPC scenarios of ONE problem of ``base`` (BASELINE.json configs[3]): same session windows,
+    bounds and objective, the remaining demand of every session scaled per scenario.  ``demand_factor`` is
+    (S,) -- one factor per scenario -- or (S, K, N) -- one per session slot.  Pure array work (no Python loop
+    over sessions): the energy caps are the only per-scenario data, everything else is broadcast."""
+    f = np.asarray(demand_factor, float)
+    S = f.shape[0]
+    if f.ndim == 1:
+        f = f[:, None, None]
+    if f.shape[1:] not in ((1, 1), base.s_cap.shape[1:]):
+        raise ValueError("demand_factor must have shape (S,) or (S, K, N)")
+    p = slice(problem, problem + 1)
+    rep = lambda a: None if a is None else np.ascontiguousarray(np.broadcast_to(a[p], (S,) + a.shape[1:]))
+    return ProblemBatch(
+        base.site, S, base.Tm, base.K, rep(base.T), rep(base.lb), rep(base.ub), rep(base.q), rep(base.pdiag),
+        rep(base.lf), rep(base.s_off), rep(base.s_len), np.ascontiguousarray(base.s_cap[p] * f), rep(base.s_eq),
+        rep(base.peak), rep(base.dc), rep(base.dfloor), rep(base.const), rep(base.presolve_status),
+    )
+
+
 def _objective_needs_max(objective) -> bool:
     from .adaptive_charging_optimization import demand_charge, peak
 
@@ -221,20 +241,22 @@ def build_batch(
     elif any_peak and not site.has_peak:
         raise ValueError("site was built without a peak row but a peak_limit was given")
     station_index = {s: i for i, s in enumerate(infrastructure.station_ids)}
-    Ts = np.array(
-        [max(s.arrival_offset + s.remaining_time for s in sl) for sl in session_lists], dtype=np.int32
-    )  # aco.py:243-245
+    # one pass over the session objects: (EVSE index, arrival offset, remaining time, session)
+    records = [
+        [(station_index[s.station_id], int(s.arrival_offset), int(s.remaining_time), s) for s in sl]
+        for sl in session_lists
+    ]
+    Ts = np.array([max(o + r for _, o, r, _ in rec) for rec in records], dtype=np.int32)  # aco.py:243-245
     Tm = int(Ts.max())
     volt = np.asarray(infrastructure.voltages, float)
     period = interface.period
+    kwh_per_amp_period = volt * period / 1e3 / 60  # aco.py:114
 
     # sessions per EVSE
     K = 1
-    for sl in session_lists:
-        cnt = {}
-        for s in sl:
-            cnt[s.station_id] = cnt.get(s.station_id, 0) + 1
-        K = max(K, max(cnt.values()))
+    for rec in records:
+        cnt = np.bincount([i for i, _, _, _ in rec], minlength=N)
+        K = max(K, int(cnt.max()))
 
     lb = np.zeros((B, N, Tm))
     ub = np.zeros((B, N, Tm))
@@ -250,39 +272,40 @@ def build_batch(
     s_eq = np.full(B, 1 if enforce_energy_equality else 0, dtype=np.uint8)
     peak = np.full((B, Tm), np.inf) if site.has_peak else None
     presolve = np.zeros(B, dtype=np.int32)
+    terms_by_horizon = {}   # the objective depends on the problem only through its horizon
 
-    for b, sl in enumerate(session_lists):
+    for b, rec in enumerate(records):
         T = int(Ts[b])
-        slot = np.zeros(N, dtype=np.int64)
-        occupied = np.zeros((N, Tm), dtype=bool)
-        for s in sl:  # aco.py:62-73
-            i = station_index[s.station_id]
-            o, r = int(s.arrival_offset), int(s.remaining_time)
-            lb[b, i, o : o + r] = s.min_rates
-            ub[b, i, o : o + r] = s.max_rates
-        bad = ub[b] < lb[b]  # aco.py:75
-        ub[b][bad] = lb[b][bad]
-        for s in sl:  # aco.py:105-123
-            i = station_index[s.station_id]
-            o, r = int(s.arrival_offset), int(s.remaining_time)
+        slot = [0] * N
+        windows = {}   # EVSE -> windows already placed (only consulted when an EVSE hosts a second session)
+        lbb, ubb = lb[b], ub[b]
+        for i, o, r, s in rec:  # aco.py:62-73
+            lbb[i, o : o + r] = s.min_rates
+            ubb[i, o : o + r] = s.max_rates
+        np.maximum(ubb, lbb, out=ubb)  # aco.py:75
+        for i, o, r, s in rec:  # aco.py:105-123
             if r <= 0:
                 # empty window: 0 <= (==) remaining_demand
                 if s.remaining_demand < 0 or (enforce_energy_equality and s.remaining_demand != 0):
                     presolve[b] = 1
                 continue
-            if occupied[i, o : o + r].any():
-                raise ValueError(
-                    f"sessions on EVSE {s.station_id} overlap in time; the structured "
-                    "builder needs disjoint session windows per EVSE"
-                )
-            occupied[i, o : o + r] = True
             k = slot[i]
-            slot[i] += 1
+            if k:
+                if any(o < o2 + r2 and o2 < o + r for o2, r2 in windows[i]):
+                    raise ValueError(
+                        f"sessions on EVSE {s.station_id} overlap in time; the structured "
+                        "builder needs disjoint session windows per EVSE"
+                    )
+                windows[i].append((o, r))
+            else:
+                windows[i] = [(o, r)]
+            slot[i] = k + 1
             s_off[b, k, i] = o
             s_len[b, k, i] = r
-            kwh_per_amp_period = volt[i] * period / 1e3 / 60  # aco.py:114
-            s_cap[b, k, i] = s.remaining_demand / kwh_per_amp_period
-        qb, pd, lfc, c0, dcw, dfl = objective_terms(objective, infrastructure, interface, N, T, prev_peak)
+            s_cap[b, k, i] = s.remaining_demand / kwh_per_amp_period[i]
+        if T not in terms_by_horizon:
+            terms_by_horizon[T] = objective_terms(objective, infrastructure, interface, N, T, prev_peak)
+        qb, pd, lfc, c0, dcw, dfl = terms_by_horizon[T]
         q[b, :, :T] = qb
         pdiag[b], lf[b], const[b], dc[b], dfloor[b] = pd, lfc, c0, dcw, dfl
         if peak is not None and peak_limits[b] is not None:  # aco.py:196-198

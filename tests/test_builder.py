@@ -179,3 +179,26 @@ def test_reference_constraint_builder_names():
     opt = AdaptiveChargingOptimization([ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 0.5)], iface)
     o = opt.build_objective(rates, infra, prev_peak=0)
     assert isinstance(o, QuadObjective) and o.sq == 0.5 and np.allclose(o.lin[0], [(12 - t) / 12 for t in range(12)])
+
+
+def test_scenario_batch_equals_the_session_by_session_builder():
+    """configs[3]: demand scenarios of one snapshot.  The vectorised path must produce exactly the arrays the
+    general builder makes from the scaled SessionInfo lists."""
+    from adacharge_amd import sites
+    from adacharge_amd.builder import scenario_batch
+
+    infra, iface = caltech_interface()
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    base_sessions = sites.snapshot_batch(infra, 12, 1, seed=11)[0]
+    scen = sites.demand_scenarios(base_sessions, 16, np.random.default_rng(5))
+    slow = build_batch(scen, infra, iface, obj, "SOC")
+    base = build_batch([base_sessions], infra, iface, obj, "SOC")
+    with np.errstate(divide="ignore", invalid="ignore"):
+        factor = np.where(base.s_len[0] > 0, slow.s_cap / base.s_cap[0], 1.0)
+    fast = scenario_batch(base, factor)
+    for name in ("T", "lb", "ub", "q", "pdiag", "lf", "s_off", "s_len", "s_eq"):
+        assert np.array_equal(getattr(fast, name), getattr(slow, name)), name
+    assert np.allclose(fast.s_cap, slow.s_cap, rtol=1e-13, atol=0)
+    assert fast.B == 16 and fast.K == slow.K and fast.Tm == slow.Tm
+    uniform = scenario_batch(base, np.array([0.5, 1.0, 2.0]))
+    assert np.allclose(uniform.s_cap[2], 2.0 * base.s_cap[0]) and uniform.B == 3
