@@ -105,41 +105,9 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   int status = 2, it = 0;
   real pri = M::big, dua = M::big;
   bool done = false;
-  while (!done) {
-    ++it;
-    const real a = sigma + pd + rho, inv_a = (real)1 / a, inv_rho = (real)1 / rho;
-    // ---- eigen space: e^ and h^ -------------------------------------------------------------
-    for (int k = tid; k < mt; k += kGenThreads) {
-      const int j = k / T, t = k - j * T;
-      real acc = 0, whj = 0;
-      for (int i = 0; i < N; ++i) acc += Gh[(size_t)j * NP + i] * r0[i * T + t];
-      for (int r = 0; r < MR; ++r) whj += Qm[(size_t)r * MR + j] * w[r * T + t];
-      const real lj = Lm[j];
-      const real e_ = whj - (rho / (a + rho * lj)) * (acc + lj * whj);
-      eh[k] = e_;
-      hh[k] = (acc + lj * e_) * inv_a;
-    }
-    __syncthreads();
-    // ---- x~, relaxation, box clip;  G x~, relaxation of the site rows ---------------------------
-    for (int k = tid; k < n; k += kGenThreads) {
-      const int i = k / T, t = k - i * T;
-      real v = r0[k];
-      for (int j = 0; j < MR; ++j) v += Gh[(size_t)j * NP + i] * eh[j * T + t];
-      const real xn = v * inv_a;
-      const real zz = alpha * xn + ((real)1 - alpha) * z1[k] + y1[k] * inv_rho;
-      zh[k] = zz;
-      x[k] = alpha * xn + ((real)1 - alpha) * x[k];
-      z1[k] = fmin(fmax(zz, (real)lbg[k]), ub[k]);
-    }
-    for (int k = tid; k < mt; k += kGenThreads) {
-      const int r = k / T, t = k - r * T;
-      real zt = 0;
-      for (int j = 0; j < MR; ++j) zt += Qm[(size_t)r * MR + j] * hh[j * T + t];
-      gx[k] = alpha * zt + ((real)1 - alpha) * gx[k];
-      zh2[k] = alpha * zt + ((real)1 - alpha) * z2[k] + y2[k] * inv_rho;
-    }
-    __syncthreads();
-    // ---- energy rows: one thread per session, safeguarded Newton on g(m) = sum clip(zh - m) -------
+  // ---- energy rows: one thread per session, safeguarded Newton on g(m) = sum clip(zh - m); reads zh and the
+  // box-clipped z1, overwrites z1 on the session windows.  Used by the start and by every iteration.
+  auto project_sessions = [&]() __attribute__((always_inline)) {
     for (int s = tid; s < K * N; s += kGenThreads) {
       const int i = s % N;
       const size_t sidx = (size_t)b * K * N + s;
@@ -182,6 +150,64 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
       mu[s] = m;
       for (int t = 0; t < len; ++t) z[t] = fmin(fmax(v[t] - m, (real)lb_[t]), ub_[t]);
     }
+  };
+  // ---- start: the schedule that ignores the site rows (see acn_qp_tiled.hpp): z1 = Proj_B(-kStartGain q),
+  // y1 = -(q + pd z1), z2 = G z1, y2 = 0
+  for (int k = tid; k < n; k += kGenThreads) {
+    zh[k] = -(real)kStartGain * (real)qg[k];
+    z1[k] = fmin(fmax(zh[k], (real)lbg[k]), ub[k]);
+  }
+  __syncthreads();
+  project_sessions();
+  __syncthreads();
+  for (int s = tid; s < K * N; s += kGenThreads) mu[s] = 0;
+  for (int k = tid; k < n; k += kGenThreads) {
+    x[k] = z1[k];
+    y1[k] = -((real)qg[k] + pd * z1[k]);
+    r0[k] = sigma * x[k] - (real)qg[k] + rho * z1[k] - y1[k];
+  }
+  for (int k = tid; k < mt; k += kGenThreads) {
+    const int r = k / T, t = k - r * T;
+    real acc = 0;
+    for (int i = 0; i < N; ++i) acc += Gm[(size_t)r * NP + i] * z1[i * T + t];
+    z2[k] = acc; gx[k] = acc; y2[k] = 0; w[k] = rho * acc;
+  }
+  __syncthreads();
+  while (!done) {
+    ++it;
+    const real a = sigma + pd + rho, inv_a = (real)1 / a, inv_rho = (real)1 / rho;
+    // ---- eigen space: e^ and h^ -------------------------------------------------------------
+    for (int k = tid; k < mt; k += kGenThreads) {
+      const int j = k / T, t = k - j * T;
+      real acc = 0, whj = 0;
+      for (int i = 0; i < N; ++i) acc += Gh[(size_t)j * NP + i] * r0[i * T + t];
+      for (int r = 0; r < MR; ++r) whj += Qm[(size_t)r * MR + j] * w[r * T + t];
+      const real lj = Lm[j];
+      const real e_ = whj - (rho / (a + rho * lj)) * (acc + lj * whj);
+      eh[k] = e_;
+      hh[k] = (acc + lj * e_) * inv_a;
+    }
+    __syncthreads();
+    // ---- x~, relaxation, box clip;  G x~, relaxation of the site rows ---------------------------
+    for (int k = tid; k < n; k += kGenThreads) {
+      const int i = k / T, t = k - i * T;
+      real v = r0[k];
+      for (int j = 0; j < MR; ++j) v += Gh[(size_t)j * NP + i] * eh[j * T + t];
+      const real xn = v * inv_a;
+      const real zz = alpha * xn + ((real)1 - alpha) * z1[k] + y1[k] * inv_rho;
+      zh[k] = zz;
+      x[k] = alpha * xn + ((real)1 - alpha) * x[k];
+      z1[k] = fmin(fmax(zz, (real)lbg[k]), ub[k]);
+    }
+    for (int k = tid; k < mt; k += kGenThreads) {
+      const int r = k / T, t = k - r * T;
+      real zt = 0;
+      for (int j = 0; j < MR; ++j) zt += Qm[(size_t)r * MR + j] * hh[j * T + t];
+      gx[k] = alpha * zt + ((real)1 - alpha) * gx[k];
+      zh2[k] = alpha * zt + ((real)1 - alpha) * z2[k] + y2[k] * inv_rho;
+    }
+    __syncthreads();
+    project_sessions();
     // ---- site rows: projection (internal row order: a SOC pair is `pair_stride` rows apart) -------
     for (int k = tid; k < mt; k += kGenThreads) {
       const int r = k / T, t = k - r * T;

@@ -191,6 +191,7 @@ struct TiledLds {
 };
 
 // Anderson acceleration of the ADMM fixed-point map (restated in oracle/admm_port.c, see there)
+constexpr double kStartGain = 1e5;
 constexpr int kAaPeriod = 5;
 constexpr double kAaReg = 1e-4, kAaSafe = 1.2, kAaDrift = 1e-3;
 
@@ -477,6 +478,193 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
 #endif
+  // ---- projection onto B (energy rows), used by the start and by every iteration; `between` is work that is
+  // independent of the water-filling and is placed inside it to share a basic block with the first Newton pass
+  auto project_B = [&](const real (&zin)[CT][4], auto&& between) __attribute__((always_inline)) {
+    // ---- energy rows: exact water-filling in session layout ---------------------------------------
+    // z = clip(zh - m) with g(m) = sum_t clip(zh_t - m) = cap: safeguarded Newton on the piecewise-
+    // linear g, warm-started at the previous iteration's m (typically one step + one verifying pass).
+      // C layout -> session layout through this wave's private LDS scratch (no workgroup barrier)
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xw[(c * 16 + M::rowof(g, r)) * kXS + t] = zin[c][r];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      real szh[CT][4], sz[CT][4];
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          szh[c][tt] = Xw[(c * 16 + se) * kXS + 4 * sh + tt];
+          sz[c][tt] = fmin(fmax(szh[c][tt], slb[c][tt]), sub[c][tt]);
+        }
+      STAMP(7);   // C -> session transpose
+      // (the site-row projection is independent of the water-filling; it sits here so that its VALU work
+      //  shares one basic block with the first Newton pass and they hide each other's latency)
+      between();
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        if (k == 0 || k < A.K) {   // block-uniform; slot 0 always exists
+          const real cap = scap[k];
+          const real tol = ptol_scale * fmax((real)1, fabs(cap));
+#if defined(ACNQP_ABL) && ACNQP_ABL == 1
+          bool need = false;
+#else
+          bool need = shas[k] && smode[k] == 0;
+#endif
+          real m = mu[k];
+          real lo = eq ? -M::big : (real)-1;   // inequality: m >= 0, so (-1, .) brackets m = 0
+          real hi = M::big;
+          int guard = 0;
+          auto newton_pass = [&]() {
+            ++guard;
+
+            real gl = 0, lo_l = M::big, hi_l = -M::big;
+            float nl = 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt) {
+                const bool inw = (swm[k] >> (4 * c + tt)) & 1u;
+                const real v = szh[c][tt] - m;
+                gl += inw ? fmin(fmax(v, slb[c][tt]), sub[c][tt]) : (real)0;
+                nl += (inw && v > slb[c][tt] && v < sub[c][tt]) ? 1.f : 0.f;
+                lo_l = inw ? fmin(lo_l, szh[c][tt] - sub[c][tt]) : lo_l;
+                hi_l = inw ? fmax(hi_l, szh[c][tt] - slb[c][tt]) : hi_l;
+              }
+            const real gs = quarter_sum<real>(gl);
+            const float nf = quarter_sum<float>(nl);
+            const real d = gs - cap;
+            const bool fin = fabs(d) <= tol || (!eq && m <= (real)0 && d <= (real)0) || guard > ACNQP_GUARD_MAX;
+            need = need && !fin;
+            lo = (need && d > 0) ? m : lo;
+            hi = (need && !(d > 0)) ? m : hi;
+            // flat piece with an open bracket (rare): fetch the true bracket ends so the fallback bisects
+            const bool open = need && nf <= 0.f && !(lo > -M::big && hi < M::big);
+            if (__any(open)) {
+              const real lo0 = quarter_min<real>(lo_l), hi0 = quarter_max<real>(hi_l);
+              lo = open ? fmax(lo, lo0) : lo;
+              hi = open ? fmin(hi, hi0) : hi;
+            }
+            const bool bracketed = lo > -M::big && hi < M::big;
+            const real mid = (real)0.5 * (lo + hi);
+            bool newton = nf > 0.f;
+            real cand = newton ? m + d * (real)rcp_small(nf) : (bracketed ? mid : fmin(fmax(m + d, lo), hi));
+            if (!eq && cand < (real)0) { cand = 0; newton = false; }      // inequality: multiplier >= 0
+            real alt = bracketed ? mid : fmin(fmax(cand, lo), hi);
+            if (!eq && alt < (real)0) alt = 0;
+            const bool inside = cand > lo && cand < hi;
+            cand = inside ? cand : alt;
+            newton = newton && inside;
+            // A Newton step that keeps every period of the window on its piece of g (same side of
+            // lb / ub before and after) is exact: g is linear between m and cand.  One OR-reduction
+            // of a flag word over the session's four lanes replaces the verifying pass.
+            unsigned moved = 0;
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt) {
+                const bool inw = (swm[k] >> (4 * c + tt)) & 1u;
+                const real v0 = szh[c][tt] - m, v1 = szh[c][tt] - cand;
+                const bool ch = ((v0 < sub[c][tt]) != (v1 < sub[c][tt])) || ((v0 > slb[c][tt]) != (v1 > slb[c][tt]));
+                moved |= (inw && ch) ? 1u : 0u;
+              }
+            { const Pair32 p = swap_u32<16>(moved); moved = p.a | p.b; }
+            { const Pair32 q = swap_u32<32>(moved); moved = q.a | q.b; }
+            // no representable progress (the residual sits at rounding level, typical in fp32): stop
+            need = need && cand != m;
+            m = need ? cand : m;
+            need = need && !(newton && moved == 0u);
+          };
+          newton_pass();                       // peeled: straight-line with the site-row update above
+          while (__any(need)) newton_pass();   // rare: the active set of some session changed
+          if (shas[k] && smode[k] == 0) mu[k] = m;
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+              if ((swm[k] >> (4 * c + tt)) & 1u) {
+                if (smode[k] == 0) sz[c][tt] = fmin(fmax(szh[c][tt] - m, slb[c][tt]), sub[c][tt]);
+                else if (smode[k] == 2) sz[c][tt] = sub[c][tt];
+                else sz[c][tt] = slb[c][tt];
+              }
+        }
+      }
+      STAMP(8);   // Newton passes
+      // session layout -> C layout
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) Xw[(c * 16 + se) * kXS + 4 * sh + tt] = sz[c][tt];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) z1[c][r] = Xw[(c * 16 + M::rowof(g, r)) * kXS + t];
+  };
+
+  // ---- start: the schedule that ignores the site rows, z1 = Proj_B(-kStartGain q) (every session served as its
+  // cost vector prefers, inside its bounds and energy row), with the multiplier that makes it stationary,
+  // y1 = -(q + pd z1); site rows at z2 = G z1 = Q (Ghat z1), y2 = 0.  Exact when no site row binds.
+  {
+    real zs[CT][4];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) zs[c][r] = -(real)kStartGain * qv[c][r];
+    project_B(zs, []() {});
+#pragma unroll
+    for (int k = 0; k < KS; ++k) mu[k] = 0;   // the multipliers of this one-off projection are no warm start
+    const real* FG0 = static_cast<const real*>(A.fragG) + (size_t)__builtin_amdgcn_readfirstlane(wave) * MT * 2 * 4 * 64;
+    const real* FQ0 = static_cast<const real*>(A.fragQ);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        x[c][r] = z1[c][r];
+        y1[c][r] = -(qv[c][r] + pd * z1[c][r]);
+        up1[c][r] = z1[c][r] + y1[c][r] * inv_rho;
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        vec4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = M::mma(FG0[((m * 2 + 0) * 4 + s) * 64 + lane], z1[c][s], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pbuf[(((wave * MT + m) * CT + c) * 4 + r) * 64 + lane] = acc[r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      vec4 g0v[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          real g0 = 0;
+#pragma unroll
+          for (int wv = 0; wv < NW; ++wv) g0 += Pbuf[(((wv * MT + m) * CT + c) * 4 + r) * 64 + lane];
+          g0v[m][r] = g0;
+        }
+#pragma unroll
+      for (int mo = 0; mo < MT; ++mo) {
+        vec4 zt = {0, 0, 0, 0};
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) zt = M::mma(FQ0[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane], g0v[mi][s], zt);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { z2[mo][c][r] = zt[r]; gx[mo][c][r] = zt[r]; up2[mo][c][r] = zt[r]; y2[mo][c][r] = 0; }
+      }
+    }
+  }
+
   while (!done) {
     ++it;
     real* Pw = Pbuf + (size_t)(it & 1) * NW * MT * CT * 256;
@@ -760,29 +948,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
       }
     }
     STAMP(9);   // Anderson event (amortised)
-    // ---- energy rows: exact water-filling in session layout ---------------------------------------
-    // z = clip(zh - m) with g(m) = sum_t clip(zh_t - m) = cap: safeguarded Newton on the piecewise-
-    // linear g, warm-started at the previous iteration's m (typically one step + one verifying pass).
-    {
-      // C layout -> session layout through this wave's private LDS scratch (no workgroup barrier)
-#pragma unroll
-      for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Xw[(c * 16 + M::rowof(g, r)) * kXS + t] = zh[c][r];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      real szh[CT][4], sz[CT][4];
-#pragma unroll
-      for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          szh[c][tt] = Xw[(c * 16 + se) * kXS + 4 * sh + tt];
-          sz[c][tt] = fmin(fmax(szh[c][tt], slb[c][tt]), sub[c][tt]);
-        }
-      STAMP(7);   // C -> session transpose
-      // (the site-row projection is independent of the water-filling; it sits here so that its VALU work
-      //  shares one basic block with the first Newton pass and they hide each other's latency)
+    project_B(zh, [&]() __attribute__((always_inline)) {
     // ---- site rows: projection of zhr onto C, y2 (every wave, redundantly) ---
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -872,109 +1038,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
             }
           }
     }
-#pragma unroll
-      for (int k = 0; k < KS; ++k) {
-        if (k == 0 || k < A.K) {   // block-uniform; slot 0 always exists
-          const real cap = scap[k];
-          const real tol = ptol_scale * fmax((real)1, fabs(cap));
-#if defined(ACNQP_ABL) && ACNQP_ABL == 1
-          bool need = false;
-#else
-          bool need = shas[k] && smode[k] == 0;
-#endif
-          real m = mu[k];
-          real lo = eq ? -M::big : (real)-1;   // inequality: m >= 0, so (-1, .) brackets m = 0
-          real hi = M::big;
-          int guard = 0;
-          auto newton_pass = [&]() {
-            ++guard;
-
-            real gl = 0, lo_l = M::big, hi_l = -M::big;
-            float nl = 0.f;
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-              for (int tt = 0; tt < 4; ++tt) {
-                const bool inw = (swm[k] >> (4 * c + tt)) & 1u;
-                const real v = szh[c][tt] - m;
-                gl += inw ? fmin(fmax(v, slb[c][tt]), sub[c][tt]) : (real)0;
-                nl += (inw && v > slb[c][tt] && v < sub[c][tt]) ? 1.f : 0.f;
-                lo_l = inw ? fmin(lo_l, szh[c][tt] - sub[c][tt]) : lo_l;
-                hi_l = inw ? fmax(hi_l, szh[c][tt] - slb[c][tt]) : hi_l;
-              }
-            const real gs = quarter_sum<real>(gl);
-            const float nf = quarter_sum<float>(nl);
-            const real d = gs - cap;
-            const bool fin = fabs(d) <= tol || (!eq && m <= (real)0 && d <= (real)0) || guard > ACNQP_GUARD_MAX;
-            need = need && !fin;
-            lo = (need && d > 0) ? m : lo;
-            hi = (need && !(d > 0)) ? m : hi;
-            // flat piece with an open bracket (rare): fetch the true bracket ends so the fallback bisects
-            const bool open = need && nf <= 0.f && !(lo > -M::big && hi < M::big);
-            if (__any(open)) {
-              const real lo0 = quarter_min<real>(lo_l), hi0 = quarter_max<real>(hi_l);
-              lo = open ? fmax(lo, lo0) : lo;
-              hi = open ? fmin(hi, hi0) : hi;
-            }
-            const bool bracketed = lo > -M::big && hi < M::big;
-            const real mid = (real)0.5 * (lo + hi);
-            bool newton = nf > 0.f;
-            real cand = newton ? m + d * (real)rcp_small(nf) : (bracketed ? mid : fmin(fmax(m + d, lo), hi));
-            if (!eq && cand < (real)0) { cand = 0; newton = false; }      // inequality: multiplier >= 0
-            real alt = bracketed ? mid : fmin(fmax(cand, lo), hi);
-            if (!eq && alt < (real)0) alt = 0;
-            const bool inside = cand > lo && cand < hi;
-            cand = inside ? cand : alt;
-            newton = newton && inside;
-            // A Newton step that keeps every period of the window on its piece of g (same side of
-            // lb / ub before and after) is exact: g is linear between m and cand.  One OR-reduction
-            // of a flag word over the session's four lanes replaces the verifying pass.
-            unsigned moved = 0;
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-              for (int tt = 0; tt < 4; ++tt) {
-                const bool inw = (swm[k] >> (4 * c + tt)) & 1u;
-                const real v0 = szh[c][tt] - m, v1 = szh[c][tt] - cand;
-                const bool ch = ((v0 < sub[c][tt]) != (v1 < sub[c][tt])) || ((v0 > slb[c][tt]) != (v1 > slb[c][tt]));
-                moved |= (inw && ch) ? 1u : 0u;
-              }
-            { const Pair32 p = swap_u32<16>(moved); moved = p.a | p.b; }
-            { const Pair32 q = swap_u32<32>(moved); moved = q.a | q.b; }
-            // no representable progress (the residual sits at rounding level, typical in fp32): stop
-            need = need && cand != m;
-            m = need ? cand : m;
-            need = need && !(newton && moved == 0u);
-          };
-          newton_pass();                       // peeled: straight-line with the site-row update above
-          while (__any(need)) newton_pass();   // rare: the active set of some session changed
-          if (shas[k] && smode[k] == 0) mu[k] = m;
-#pragma unroll
-          for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-              if ((swm[k] >> (4 * c + tt)) & 1u) {
-                if (smode[k] == 0) sz[c][tt] = fmin(fmax(szh[c][tt] - m, slb[c][tt]), sub[c][tt]);
-                else if (smode[k] == 2) sz[c][tt] = sub[c][tt];
-                else sz[c][tt] = slb[c][tt];
-              }
-        }
-      }
-      STAMP(8);   // Newton passes
-      // session layout -> C layout
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) Xw[(c * 16 + se) * kXS + 4 * sh + tt] = sz[c][tt];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) z1[c][r] = Xw[(c * 16 + M::rowof(g, r)) * kXS + t];
-    }
+    });
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll

@@ -80,6 +80,7 @@ static void project_window(int L, const double* v, const double* lb, const doubl
  * Safeguard: if the residual norm grew by more than kAaSafe after an accelerated step the ring is
  * cleared and acceleration pauses for 1, 2, 4, ... 64 events (exponential back-off).            */
 #define AA_MAX 16
+static const double kStartGain = 1e5;
 static const int kAaPeriod = 5;
 static const double kAaReg = 1e-4, kAaSafe = 1.2, kAaDrift = 1e-3;
 
@@ -163,7 +164,28 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
   if (ubmax > 0) pd = fmax(pd, O->reg_rel * qnorm / (ubmax * (double)(horizon > 1 ? horizon : 1)));
   double rho = O->rho;
   const double sigma = O->sigma, alpha = O->alpha;
-  for (int k = 0; k < n; ++k) r0[k] = -q[k];
+  /* Start: the schedule that ignores the site rows, z1 = Proj_B(-kStartGain q) (every session served as its
+   * cost vector prefers, inside its bounds and energy row), with the multiplier that makes it stationary,
+   * y1 = -(q + pd z1); site rows at z2 = G z1, y2 = 0.  Exact when no site row binds. */
+  for (int k = 0; k < n; ++k) { zh[k] = -kStartGain * q[k]; z1[k] = clip(zh[k], lb[k], ub[k]); }
+  for (int k = 0; k < K; ++k)
+    for (int i = 0; i < N; ++i) {
+      const int L = s_len[k * N + i], o = s_off[k * N + i];
+      if (L > 0) {
+        double m0 = 0;
+        project_window(L, zh + i * T + o, lb + i * T + o, ub + i * T + o, s_cap[k * N + i], eq, slo[k * N + i],
+                       shi[k * N + i], &m0, z1 + i * T + o);
+      }
+    }
+  for (int k = 0; k < n; ++k) { x[k] = z1[k]; y1[k] = -(q[k] + pd * z1[k]); uprev[k] = z1[k] + y1[k] / rho; }
+  for (int t = 0; t < T; ++t)
+    for (int r = 0; r < Mg; ++r) {
+      double a2 = 0;
+      for (int i = 0; i < N; ++i) a2 += S->G[r * N + i] * z1[i * T + t];
+      gx[r * T + t] = z2[r * T + t] = uprev[n + r * T + t] = a2;
+    }
+  for (int k = 0; k < n; ++k) r0[k] = sigma * x[k] - q[k] + rho * z1[k] - y1[k];
+  for (int k = 0; k < mt; ++k) w[k] = rho * z2[k] - y2[k];
   for (it = 1; it <= O->max_iter; ++it) {
     const double a = sigma + pd + rho, inv_a = 1.0 / a, inv_rho = 1.0 / rho;
     /* eigen roles */

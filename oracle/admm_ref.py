@@ -51,6 +51,7 @@ class AdmmOptions:
     accel_mem: int = 0            # Anderson-acceleration columns (0 = plain ADMM), see _Anderson
 
 
+START_GAIN = 1e5
 AA_PERIOD, AA_REG, AA_SAFE, AA_DRIFT = 5, 1e-4, 1.2, 1e-3
 
 
@@ -207,16 +208,20 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
     Mg = G.shape[0]
     sig, alpha = opts.sigma, opts.alpha
     rho = opts.rho
-    x = np.zeros((N, Tm))
-    z1 = np.zeros((N, Tm))
-    y1 = np.zeros((N, Tm))
-    z2 = np.zeros((Mg, Tm))
+    # start: the schedule that ignores the site rows, z1 = Proj_B(-START_GAIN q), with the multiplier that
+    # makes it stationary, y1 = -(q + pdiag z1); site rows at z2 = G z1, y2 = 0 (exact when no site row binds)
+    z1 = _project_B(-START_GAIN * q, lb, ub, batch.s_off[b], batch.s_len[b], batch.s_cap[b], eq)
+    x = z1.copy()
+    y1 = -(q + pdiag * z1)
+    z2 = G @ z1
     y2 = np.zeros((Mg, Tm))
-    Gx = np.zeros((Mg, Tm))
+    Gx = z2.copy()
     status = ST_MAX_ITER
     pri = dua = np.inf
     it = 0
     aa = _Anderson(opts.accel_mem, N * Tm + Mg * Tm) if opts.accel_mem > 0 else None
+    if aa is not None:
+        aa.uprev = np.concatenate([(z1 + y1 / rho).ravel(), z2.ravel()])
     for it in range(1, opts.max_iter + 1):
         a = sig + pdiag + rho
         r0 = sig * x - q + rho * z1 - y1
