@@ -328,11 +328,11 @@ void acnqp_default_options(acnqp_options* o) {
   o->eps_rel = 1e-8;
   o->max_iter = 20000;
   o->check_every = 20;
-  o->adapt_every = 40;
-  o->rho = 0.01;
+  o->adapt_every = 20;
+  o->rho = 0.02;
   o->sigma = 1e-6;
   o->alpha = 1.4;
-  o->adapt_tol = 5.0;
+  o->adapt_tol = 3.0;
   o->reg_rel = 0.06;
   o->precision = 64;
   o->accel_mem = 5;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   }
   const real sigma = (real)A.sigma, alpha = (real)A.alpha;
   real rho = (real)A.rho0;
-  int status = 2, it = 0;
+  int status = 2, it = 0, n_adapt = 0;
   real pri = M::big, dua = M::big;
   bool done = false;
   // ---- energy rows: one thread per session, safeguarded Newton on g(m) = sum clip(zh - m); reads zh and the
@@ -282,7 +282,8 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
       else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
         const real sp = pri / fmax(npri, (real)1e-12), sd = dua / fmax(ndua, (real)1e-12);
         const real ratio = sqrt(sp / fmax(sd, (real)1e-30));
-        if (ratio > (real)A.adapt_tol || ratio < (real)1 / (real)A.adapt_tol) rho = fmin(fmax(rho * ratio, (real)1e-6), (real)1e6);
+        const real tol_eff = (real)A.adapt_tol * ((real)1 + (real)n_adapt * (real)(1.0 / kAdaptWiden));
+        if (ratio > tol_eff || ratio < (real)1 / tol_eff) { rho = fmin(fmax(rho * ratio, (real)1e-6), (real)1e6); ++n_adapt; }
       }
     }
     if (!done) {

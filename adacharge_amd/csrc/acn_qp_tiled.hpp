@@ -192,6 +192,7 @@ struct TiledLds {
 
 // Anderson acceleration of the ADMM fixed-point map (restated in oracle/admm_port.c, see there)
 constexpr double kStartGain = 1e5;
+constexpr double kAdaptWiden = 8.0;   // rho adaptation band: adapt_tol (1 + adaptations / kAdaptWiden): no limit cycles
 constexpr int kAaPeriod = 5;
 constexpr double kAaReg = 1e-4, kAaSafe = 1.2, kAaDrift = 1e-3;
 
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
     for (int r = 0; r < 4; ++r) djv[m][r] = rho / (a + rho * lamv[m][r]);
 
-  int status = 2, it = 0;
+  int status = 2, it = 0, n_adapt = 0;
   real pri = M::big, dua = M::big;
   bool done = false, have_prev = false;
   real y1p[CT][4], y2p[MT][CT][4];   // duals at the previous residual check (infeasibility certificate)
@@ -1223,7 +1224,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         const real sp = pri / fmax(npri, (real)1e-12);
         const real sd = dua / fmax(ndua, (real)1e-12);
         const real ratio = sqrt(sp / fmax(sd, (real)1e-30));
-        if (ratio > (real)A.adapt_tol || ratio < (real)1 / (real)A.adapt_tol) {
+        const real tol_eff = (real)A.adapt_tol * ((real)1 + (real)n_adapt * (real)(1.0 / kAdaptWiden));
+        if (ratio > tol_eff || ratio < (real)1 / tol_eff) {
+          ++n_adapt;
           rho = fmin(fmax(rho * ratio, (real)1e-6), (real)1e6);
           a = sigma + pd + rho;
           inv_a = (real)1 / a;

@@ -122,7 +122,9 @@ typedef struct {
   double rho;            /* initial ADMM penalty                              */
   double sigma;          /* proximal weight on x                              */
   double alpha;          /* over-relaxation in (0, 2)                         */
-  double adapt_tol;      /* adapt when the residual ratio leaves [1/tol, tol] */
+  double adapt_tol;      /* adapt when the residual ratio leaves [1/tol, tol];
+                            the band widens by tol/8 with every adaptation made,
+                            so the penalty cannot cycle                          */
   double reg_rel;        /* scale-free Tikhonov floor: effective pdiag =
                             max(pdiag, reg_rel * |q|_inf / (max(ub) * T_b)); 0 disables.
                             On LP instances a small floor returns the least-norm

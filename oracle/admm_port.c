@@ -81,6 +81,7 @@ static void project_window(int L, const double* v, const double* lb, const doubl
  * cleared and acceleration pauses for 1, 2, 4, ... 64 events (exponential back-off).            */
 #define AA_MAX 16
 static const double kStartGain = 1e5;
+static const double kAdaptWiden = 8.0;   /* rho adaptation band: adapt_tol (1 + adaptations / kAdaptWiden) */
 static const int kAaPeriod = 5;
 static const double kAaReg = 1e-4, kAaSafe = 1.2, kAaDrift = 1e-3;
 
@@ -163,6 +164,7 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
   double pd = pdiag_user;
   if (ubmax > 0) pd = fmax(pd, O->reg_rel * qnorm / (ubmax * (double)(horizon > 1 ? horizon : 1)));
   double rho = O->rho;
+  int n_adapt = 0;   /* adaptations made so far: the tolerance band widens with each (no limit cycles) */
   const double sigma = O->sigma, alpha = O->alpha;
   /* Start: the schedule that ignores the site rows, z1 = Proj_B(-kStartGain q) (every session served as its
    * cost vector prefers, inside its bounds and energy row), with the multiplier that makes it stationary,
@@ -351,7 +353,9 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
       else if (O->adapt_every > 0 && it % O->adapt_every == 0) {
         const double sp = pri / fmax(npri, 1e-12), sd = dua / fmax(ndua, 1e-12);
         const double ratio = sqrt(sp / fmax(sd, 1e-30));
-        if (ratio > O->adapt_tol || ratio < 1.0 / O->adapt_tol) {
+        const double tol_eff = O->adapt_tol * (1.0 + n_adapt / kAdaptWiden);
+        if (ratio > tol_eff || ratio < 1.0 / tol_eff) {
+          ++n_adapt;
           rho = fmin(fmax(rho * ratio, 1e-6), 1e6);
           if (MM > 0) {   /* the fixed-point map changed: restart the ring from the current (z, y) */
             aa_cnt = 0; aa_head = 0; aa_valid = 0; aa_have_prev = 0; aa_was = 0;

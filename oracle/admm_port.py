@@ -70,8 +70,8 @@ def equilibrated(site):
     return G, np.ascontiguousarray(Gh), np.ascontiguousarray(Q), lam, lim, pk, fl, mx
 
 
-def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.01, sigma=1e-6, alpha=1.4, adapt_tol=5.0,
-                reg_rel=0.06, max_iter=20000, check_every=20, adapt_every=40, accel_mem=0):
+def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.02, sigma=1e-6, alpha=1.4, adapt_tol=3.0,
+                reg_rel=0.06, max_iter=20000, check_every=20, adapt_every=20, accel_mem=0):
     """Solve a builder.ProblemBatch-like object on the CPU; same defaults as
     acnqp_default_options.  Returns dict of arrays."""
     lib = _load()

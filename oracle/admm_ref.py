@@ -39,19 +39,20 @@ class AdmmOptions:
     eps_abs: float = 1e-6
     eps_rel: float = 1e-6
     max_iter: int = 20000
-    rho: float = 0.01
+    rho: float = 0.02
     sigma: float = 1e-6
     alpha: float = 1.4
     check_every: int = 20
     adaptive_rho: bool = True
-    adapt_every: int = 40
-    adapt_tol: float = 5.0
+    adapt_every: int = 20
+    adapt_tol: float = 3.0
     reg_rel: float = 0.0
     equilibrate: bool = True      # row scaling of the site matrix, as the library does internally
     accel_mem: int = 0            # Anderson-acceleration columns (0 = plain ADMM), see _Anderson
 
 
 START_GAIN = 1e5
+ADAPT_WIDEN = 8.0
 AA_PERIOD, AA_REG, AA_SAFE, AA_DRIFT = 5, 1e-4, 1.2, 1e-3
 
 
@@ -219,6 +220,7 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
     status = ST_MAX_ITER
     pri = dua = np.inf
     it = 0
+    n_adapt = 0
     aa = _Anderson(opts.accel_mem, N * Tm + Mg * Tm) if opts.accel_mem > 0 else None
     if aa is not None:
         aa.uprev = np.concatenate([(z1 + y1 / rho).ravel(), z2.ravel()])
@@ -258,7 +260,9 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
                 break
             if opts.adaptive_rho and it % opts.adapt_every == 0:
                 ratio = np.sqrt((pri / max(npri, 1e-12)) / max(dua / max(ndua, 1e-12), 1e-30))
-                if ratio > opts.adapt_tol or ratio < 1.0 / opts.adapt_tol:
+                tol_eff = opts.adapt_tol * (1.0 + n_adapt / ADAPT_WIDEN)   # the band widens: no limit cycles
+                if ratio > tol_eff or ratio < 1.0 / tol_eff:
+                    n_adapt += 1
                     rho = float(np.clip(rho * ratio, 1e-6, 1e6))
                     if aa is not None:   # the fixed-point map changed: restart the ring from (z, y)
                         aa.restart(np.concatenate([(z1 + y1 / rho).ravel(), (z2 + y2 / rho).ravel()]))
