@@ -669,9 +669,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   while (!done) {
     ++it;
     real* Pw = Pbuf + (size_t)(it & 1) * NW * MT * CT * 256;
-    const real* FG = static_cast<const real*>(A.fragG) + (size_t)__builtin_amdgcn_readfirstlane(wave) * MT * 2 * 4 * 64;
-    const real* FQ = static_cast<const real*>(A.fragQ);
-    asm volatile("" : "+s"(FG), "+s"(FQ));   // opaque per iteration: keeps the fragment loads inside the loop
+    // an offset the compiler cannot see through keeps the fragment loads inside the loop (the base pointers stay
+    // kernel arguments, i.e. provably global memory: global_load, not flat_load)
+    unsigned frag_off = (unsigned)__builtin_amdgcn_readfirstlane(wave) * (MT * 2 * 4 * 64), zero_off = 0;
+    asm volatile("" : "+s"(frag_off), "+s"(zero_off));
+    const real* FG = static_cast<const real*>(A.fragG) + frag_off;
+    const real* FQ = static_cast<const real*>(A.fragQ) + zero_off;
 
     // ---- w^ = Q'(rho z2 - y2) and r0 = sigma x - q + rho z1 - y1;  P_w = Ghat_w r0 --------
     vec4 wh[MT][CT], r0[CT];
