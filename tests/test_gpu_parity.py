@@ -657,3 +657,36 @@ def test_randomised_paths_match_c_port(case):
     if with_peak:
         assert (res.x[both].sum(axis=1) <= batch.peak[both] + 2e-3).all()   # 54-term row x primal residual
     h.close()
+
+
+# ---- introspection entry points added for benchmarking / CPU restatements ------------------------------
+def test_accel_columns_and_kernel_times():
+    import torch
+
+    from adacharge_amd.backend import DeviceBatch
+
+    infra, iface = H.caltech_interface()
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    batch = build_batch(sites.snapshot_batch(infra, 12, 8, seed=1), infra, iface, obj, "SOC")
+    h = SiteHandle(batch.site, 0)
+    o = default_options()
+    assert o.accel_mem == 5 and h.accel_columns(batch.Tm, batch.K, o) == 5
+    assert h.accel_columns(batch.Tm, batch.K, default_options(accel_mem=0)) == 0
+    assert h.accel_columns(batch.Tm, batch.K, default_options(accel_mem=3)) == 3
+    assert h.accel_columns(batch.Tm, batch.K, default_options(accel_mem=64)) == 5     # what the kernels hold
+    assert h.accel_columns(144, 1, o) == 0                                            # general kernel: plain ADMM
+    h.kernel_times()   # forget earlier launches
+    dev = DeviceBatch(batch, "cuda:0")
+    for _ in range(3):
+        h.solve_device(dev, o, stream=torch.cuda.current_stream().cuda_stream)
+    times = h.kernel_times()
+    assert len(times) == 3 and all(t > 0 for t in times)
+    assert h.kernel_times() == []
+    assert abs(h.last_kernel_ms() - times[-1]) < 1e-6
+    # acceleration on/off: same schedule to solver tolerance, fewer iterations with it
+    plain = h.solve(batch, default_options(accel_mem=0))
+    fast = h.solve(batch, o)
+    assert (plain.status == 1).all() and (fast.status == 1).all()
+    assert np.abs(plain.x - fast.x).max() <= 1e-4 * 32
+    assert fast.iters.sum() < plain.iters.sum()
+    h.close()
