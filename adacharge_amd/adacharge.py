@@ -167,7 +167,7 @@ class AdaptiveSchedulingAlgorithm(BaseAlgorithm):
         for sl, r, st in zip(pre, rates, status):
             if len(sl) == 0:
                 out.append({})
-            elif st != 1:
+            elif st not in (1, 5):   # OPTIMAL / OPTIMAL_INACCURATE, as aco.py:319
                 out.append(None)
             else:
                 r = self._postprocess(r, sl, infrastructure)

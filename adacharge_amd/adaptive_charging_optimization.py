@@ -324,7 +324,7 @@ class AdaptiveChargingOptimization:
         )
         from . import backend
 
-        if status[0] != backend.STATUS_SOLVED:  # aco.py:319-320
+        if status[0] not in backend.ACCEPTED_STATUSES:  # aco.py:319-320 (OPTIMAL or OPTIMAL_INACCURATE)
             raise InfeasibilityException(
                 f"Solve failed with status {backend.STATUS_NAMES.get(int(status[0]), status[0])}"
             )

@@ -24,12 +24,15 @@ STATUS_SOLVED = 1
 STATUS_MAX_ITER = 2
 STATUS_PRIMAL_INFEASIBLE = 3
 STATUS_EMPTY_SET = 4
+STATUS_SOLVED_INACCURATE = 5   # cp.OPTIMAL_INACCURATE: accepted by the reference (aco.py:319)
+ACCEPTED_STATUSES = (STATUS_SOLVED, STATUS_SOLVED_INACCURATE)
 STATUS_NAMES = {
     STATUS_UNSET: "unset",
     STATUS_SOLVED: "optimal",
     STATUS_MAX_ITER: "max_iter_reached",
     STATUS_PRIMAL_INFEASIBLE: "infeasible",
     STATUS_EMPTY_SET: "infeasible",
+    STATUS_SOLVED_INACCURATE: "optimal_inaccurate",
 }
 
 

@@ -278,7 +278,11 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
       const real npri = block_reduce_max<real>(v2, red, tid);
       const real ndua = fmax(fmax(block_reduce_max<real>(v4, red, tid), block_reduce_max<real>(v5, red, tid)), qnorm);
       if (pri <= (real)A.eps_abs + (real)A.eps_rel * npri && dua <= (real)A.eps_abs + (real)A.eps_rel * ndua) { status = 1; done = true; }
-      else if (it >= A.max_iter) done = true;
+      else if (it >= A.max_iter) {
+        done = true;
+        if (pri <= (real)kInaccurate * ((real)A.eps_abs + (real)A.eps_rel * npri) &&
+            dua <= (real)kInaccurate * ((real)A.eps_abs + (real)A.eps_rel * ndua)) status = 5;   // solved, inaccurately
+      }
       else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
         const real sp = pri / fmax(npri, (real)1e-12), sd = dua / fmax(ndua, (real)1e-12);
         const real ratio = sqrt(sp / fmax(sd, (real)1e-30));

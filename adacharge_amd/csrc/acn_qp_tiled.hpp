@@ -192,6 +192,7 @@ struct TiledLds {
 
 // Anderson acceleration of the ADMM fixed-point map (restated in oracle/admm_port.c, see there)
 constexpr double kStartGain = 1e5;
+constexpr double kInaccurate = 100.0;   // max_iter with residuals within this factor of tolerance: SOLVED_INACCURATE
 constexpr double kAdaptWiden = 8.0;   // rho adaptation band: adapt_tol (1 + adaptations / kAdaptWiden): no limit cycles
 constexpr int kAaPeriod = 5;
 constexpr double kAaReg = 1e-4, kAaSafe = 1.2, kAaDrift = 1e-3;
@@ -1222,7 +1223,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         have_prev = true;
       }
       if (done) {
-      } else if (it >= A.max_iter) { done = true; }
+      } else if (it >= A.max_iter) {
+        done = true;
+        if (pri <= (real)kInaccurate * eps_p && dua <= (real)kInaccurate * eps_d) status = 5;   // solved, inaccurately
+      }
       else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
         const real sp = pri / fmax(npri, (real)1e-12);
         const real sd = dua / fmax(ndua, (real)1e-12);

@@ -53,6 +53,9 @@ extern "C" {
 #define ACNQP_STATUS_MAX_ITER 2           /* residuals above tolerance      */
 #define ACNQP_STATUS_PRIMAL_INFEASIBLE 3  /* ADMM certificate (cp.INFEASIBLE) */
 #define ACNQP_STATUS_EMPTY_SET 4          /* a session's bounds cannot meet its energy row */
+#define ACNQP_STATUS_SOLVED_INACCURATE 5   /* max_iter reached with both residuals within 100x their
+                                             tolerance: cp.OPTIMAL_INACCURATE, which the reference
+                                             accepts (aco.py:319)              */
 
 /* return codes (never C++ exceptions across the ABI) */
 #define ACNQP_OK 0

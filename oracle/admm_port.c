@@ -349,7 +349,10 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
       pri = v0; dua = v1;
       const double npri = v2, ndua = fmax(fmax(v4, v5), qnorm);
       if (pri <= O->eps_abs + O->eps_rel * npri && dua <= O->eps_abs + O->eps_rel * ndua) { status = 1; done = 1; }
-      else if (it >= O->max_iter) done = 1;
+      else if (it >= O->max_iter) {
+        done = 1;
+        if (pri <= 100.0 * (O->eps_abs + O->eps_rel * npri) && dua <= 100.0 * (O->eps_abs + O->eps_rel * ndua)) status = 5;   /* solved, inaccurately */
+      }
       else if (O->adapt_every > 0 && it % O->adapt_every == 0) {
         const double sp = pri / fmax(npri, 1e-12), sd = dua / fmax(ndua, 1e-12);
         const double ratio = sqrt(sp / fmax(sd, 1e-30));

@@ -29,6 +29,7 @@ ST_SOLVED = 1
 ST_MAX_ITER = 2
 ST_PRIMAL_INFEASIBLE = 3
 ST_PRESOLVE_INFEASIBLE = 4
+ST_SOLVED_INACCURATE = 5
 
 CONE_LINEAR = 0
 CONE_SOC = 1
@@ -258,6 +259,8 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
             if pri <= opts.eps_abs + opts.eps_rel * npri and dua <= opts.eps_abs + opts.eps_rel * ndua:
                 status = ST_SOLVED
                 break
+            if it == opts.max_iter and pri <= 100 * (opts.eps_abs + opts.eps_rel * npri) and dua <= 100 * (opts.eps_abs + opts.eps_rel * ndua):
+                status = ST_SOLVED_INACCURATE
             if opts.adaptive_rho and it % opts.adapt_every == 0:
                 ratio = np.sqrt((pri / max(npri, 1e-12)) / max(dua / max(ndua, 1e-12), 1e-30))
                 tol_eff = opts.adapt_tol * (1.0 + n_adapt / ADAPT_WIDEN)   # the band widens: no limit cycles

@@ -690,3 +690,29 @@ def test_accel_columns_and_kernel_times():
     assert np.abs(plain.x - fast.x).max() <= 1e-4 * 32
     assert fast.iters.sum() < plain.iters.sum()
     h.close()
+
+
+def test_max_iter_with_small_residuals_is_optimal_inaccurate():
+    """cvxpy's OPTIMAL_INACCURATE is accepted by the reference (aco.py:319).  The counterpart here: the iteration
+    limit is hit while both residuals are within 100x their tolerance."""
+    from adacharge_amd import backend
+
+    infra, iface = H.caltech_interface()
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    snaps = sites.snapshot_batch(infra, 12, 32, seed=4)
+    opt = AdaptiveChargingOptimization(obj, iface, solver_options=dict(eps_abs=1e-8, eps_rel=1e-8, max_iter=100000))
+    opt.solve_batch(snaps, infra)
+    hardest = int(np.argmax(opt.last_result.iters))      # a congested snapshot: the start is not the answer
+    sl = snaps[hardest]
+    full = opt.solve(sl, infra)
+    it_full = int(opt.last_result.iters[0])
+    assert it_full > 60
+    # stop 20-40 iterations early: residuals are close to, not at, tolerance -> accepted, schedule close
+    early = AdaptiveChargingOptimization(obj, iface, solver_options=dict(eps_abs=1e-8, eps_rel=1e-8, max_iter=it_full - 30))
+    rates = early.solve(sl, infra)
+    assert int(early.last_result.status[0]) == backend.STATUS_SOLVED_INACCURATE
+    assert np.abs(rates - full).max() <= 5e-3
+    # stop far too early: not accepted
+    hopeless = AdaptiveChargingOptimization(obj, iface, solver_options=dict(eps_abs=1e-8, eps_rel=1e-8, max_iter=5))
+    with pytest.raises(InfeasibilityException, match="max_iter_reached"):
+        hopeless.solve(sl, infra)
