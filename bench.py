@@ -53,12 +53,16 @@ def new_stream(dev):
 
     import torch
 
-    hip = ctypes.CDLL("libamdhip64.so")
-    handle = ctypes.c_void_p()
-    rc = hip.hipStreamCreateWithFlags(ctypes.byref(handle), ctypes.c_uint(1))   # hipStreamNonBlocking
-    if rc != 0:
-        raise RuntimeError(f"hipStreamCreateWithFlags failed ({rc})")
-    return torch.cuda.ExternalStream(handle.value, device=dev)
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        handle = ctypes.c_void_p()
+        rc = hip.hipStreamCreateWithFlags(ctypes.byref(handle), ctypes.c_uint(1))   # hipStreamNonBlocking
+        if rc != 0 or not handle.value:
+            raise RuntimeError(f"hipStreamCreateWithFlags failed ({rc})")
+        return torch.cuda.ExternalStream(handle.value, device=dev)
+    except Exception as exc:   # still correct, possibly less overlap: a stream of torch's pool
+        print(f"[bench] own HIP stream unavailable ({exc}); using a torch pool stream", file=sys.stderr)
+        return torch.cuda.Stream(device=dev)
 
 
 def parse():
