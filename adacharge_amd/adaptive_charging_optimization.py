@@ -215,6 +215,7 @@ class AdaptiveChargingOptimization:
         self.solver_options = dict(solver_options or {})
         self.device = device
         self.last_result = None
+        self.last_batch = None
 
     # the single-problem API asks for tighter residuals than the batch default so that the
     # reference's own test tolerances (1e-7 on the peak row, t_aco.py:257) hold
@@ -375,6 +376,7 @@ class AdaptiveChargingOptimization:
         opts.update(self.solver_options)
         res = handle.solve(batch, backend.default_options(**opts))
         self.last_result = res
+        self.last_batch = batch   # the structured problems behind last_result (diagnostics, tests)
         if verbose:
             for j, k in enumerate(nonempty):
                 print(

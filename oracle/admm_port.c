@@ -124,6 +124,8 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
   const int n = N * T, mt = Mg * T;
   const int D = n + mt, MM = O->accel_mem > AA_MAX ? AA_MAX : (O->accel_mem > 0 ? O->accel_mem : 0);
   double* buf = (double*)calloc((size_t)(8 * n + 8 * mt + K * N * 3 + 4 * T + Mg + 32 + 4 * D), sizeof(double));
+  double* yprev = (double*)calloc((size_t)D + 8, sizeof(double));   /* duals at the previous check (certificate) */
+  int have_yprev = 0;
   float* hist = (float*)calloc((size_t)2 * (MM > 0 ? MM : 1) * D, sizeof(float));   /* dF ring, then dG ring */
   double aaH[AA_MAX * AA_MAX], aab[AA_MAX];
   memset(aaH, 0, sizeof aaH); memset(aab, 0, sizeof aab);
@@ -158,7 +160,7 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
   if (status == 4) {
     memset(xout, 0, sizeof(double) * n);
     *iters_out = 0; *pri_out = pri; *dua_out = dua; *obj_out = 0;
-    free(buf); free(hist);
+    free(buf); free(hist); free(yprev);
     return 4;
   }
   double pd = pdiag_user;
@@ -349,7 +351,79 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
       pri = v0; dua = v1;
       const double npri = v2, ndua = fmax(fmax(v4, v5), qnorm);
       if (pri <= O->eps_abs + O->eps_rel * npri && dua <= O->eps_abs + O->eps_rel * ndua) { status = 1; done = 1; }
-      else if (it >= O->max_iter) {
+      if (!done && have_yprev) {
+        /* ---- primal infeasibility certificate, as the tiled kernel tests it (acn_qp_tiled.hpp): v = y - y(previous
+         * check); if A'v ~ 0 and the support function of B x C at v is negative, no point of B x C solves A r = z. */
+        double vn = 0, atv = 0;
+        for (int i = 0; i < N; ++i)
+          for (int t = 0; t < T; ++t) {
+            const int k = i * T + t;
+            const double v1 = y1[k] - yprev[k];
+            double gtv = 0;
+            for (int j = 0; j < Mg; ++j) gtv += S->G[j * N + i] * (y2[j * T + t] - yprev[n + j * T + t]);
+            vn = fmax(vn, fabs(v1));
+            atv = fmax(atv, fabs(v1 + gtv));
+          }
+        for (int k = 0; k < mt; ++k) vn = fmax(vn, fabs(y2[k] - yprev[n + k]));
+        const double vtol = 1e-4 * vn;
+        if (vn > 1e-12 * fmax(1.0, qnorm) && atv <= vtol) {
+          int bad = 0;
+          double ssum = 0;
+          for (int t = 0; t < T; ++t)
+            for (int r = 0; r < Mg; ++r) {
+              const double v2 = y2[r * T + t] - yprev[n + r * T + t];
+              if (r < M && S->cone == 1) {          /* disc: radius * |(v_re, v_im)| */
+                const double vi = y2[(r + M) * T + t] - yprev[n + (r + M) * T + t];
+                ssum += S->limits[r] * sqrt(v2 * v2 + vi * vi);
+              } else if (r < 2 * M && S->cone == 1) {
+              } else if (r < M) {                    /* box: z <= limit */
+                ssum += S->limits[r] * fmax(v2, 0.0);
+                if (v2 < -vtol) bad = 1;
+              } else if (S->has_peak && r == Mg - 1) {
+                const double pk = peak ? peak[t] : 1e300;
+                if (pk < 1e300) ssum += pk * fmax(v2, 0.0); else if (v2 > vtol) bad = 1;
+                if (v2 < -vtol) bad = 1;
+              } else if (fabs(v2) > vtol) bad = 1;   /* prox rows admit no ray */
+            }
+          /* sessions: phi(l) = l cap + sum_t [ub (v_t - l)+ + lb (v_t - l)-] bounds the support function for any
+           * admissible l; evaluated at min v, max v, 0.  Periods outside every window are pinned to lb (= ub). */
+          for (int k = 0; k < n; ++k) xt[k] = 0;   /* coverage flags (xt is free here) */
+          for (int k = 0; k < K; ++k)
+            for (int i = 0; i < N; ++i) {
+              const int L = s_len[k * N + i], o = s_off[k * N + i];
+              if (L <= 0) continue;
+              double lmin = 1e300, lmax = -1e300;
+              for (int t = o; t < o + L && t < T; ++t) {
+                const double v1 = y1[i * T + t] - yprev[i * T + t];
+                lmin = fmin(lmin, v1); lmax = fmax(lmax, v1);
+                xt[i * T + t] = 1;
+              }
+              double best = 1e300;
+              const double cand[3] = {lmin, lmax, 0.0};
+              for (int j = 0; j < 3; ++j) {
+                double l_ = cand[j];
+                if (!eq) l_ = fmax(l_, 0.0);
+                double ph = l_ * s_cap[k * N + i];
+                for (int t = o; t < o + L && t < T; ++t) {
+                  const double dv = (y1[i * T + t] - yprev[i * T + t]) - l_;
+                  ph += ub[i * T + t] * fmax(dv, 0.0) + lb[i * T + t] * fmin(dv, 0.0);
+                }
+                best = fmin(best, ph);
+              }
+              ssum += best;
+            }
+          for (int k = 0; k < n; ++k)
+            if (xt[k] == 0) ssum += lb[k] * (y1[k] - yprev[k]);
+          if (!bad && ssum < -vtol) { status = 3; done = 1; }
+        }
+      }
+      if (!done) {
+        memcpy(yprev, y1, sizeof(double) * n);
+        memcpy(yprev + n, y2, sizeof(double) * mt);
+        have_yprev = 1;
+      }
+      if (done) {
+      } else if (it >= O->max_iter) {
         done = 1;
         if (pri <= 100.0 * (O->eps_abs + O->eps_rel * npri) && dua <= 100.0 * (O->eps_abs + O->eps_rel * ndua)) status = 5;   /* solved, inaccurately */
       }
@@ -377,7 +451,7 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
   double obj = 0;
   for (int k = 0; k < n; ++k) { xout[k] = z1[k]; obj += (0.5 * pdiag_user * z1[k] + q[k]) * z1[k]; }
   *iters_out = it; *pri_out = pri; *dua_out = dua; *obj_out = obj;
-  free(buf); free(hist);
+  free(buf); free(hist); free(yprev);
   return status;
 }
 

@@ -76,3 +76,26 @@ def test_anderson_acceleration_halves_the_iterations_and_keeps_the_answer():
     assert fast["iters"].mean() <= 0.7 * plain["iters"].mean()
     assert np.abs(fast["x"] - plain["x"]).max() <= 1e-4 * 32
     assert np.abs(fast["obj"] - plain["obj"]).max() <= 1e-7 * np.abs(plain["obj"]).max()
+
+
+def test_c_port_certifies_infeasible_problems():
+    """The reference's two infeasible scenarios (t_aco.py:119-175: a deadline too short, a network too small for
+    an energy *equality*) end with the certificate status in the C port, like on the device, instead of max_iter."""
+    from oracle import admm_port
+    from tests.acn_testing import TestingInterface, session_generator, single_phase_single_constraint
+
+    for kw in (dict(departures=[12, 4]), dict(limit=30)):
+        N = 2
+        dep = kw.get("departures", [12, 12])
+        sd = session_generator(N, [0] * N, dep, [3.3] * N, [3.3] * N, [32] * N)
+        net = single_phase_single_constraint(N, kw.get("limit", 64))
+        iface = TestingInterface({"active_sessions": sd, "infrastructure_info": net, "current_time": 0, "period": 5})
+        batch = build_batch([iface.active_sessions()], iface.infrastructure_info(), iface,
+                            [ObjectiveComponent(quick_charge)], "SOC", True)
+        if batch.presolve_status[0]:
+            continue   # caught before iterating (a session's own bounds cannot meet its energy row)
+        out = admm_port.solve_batch(batch, threads=1, accel_mem=5)
+        # an empty session set (4) is caught before iterating, the network case by the certificate (3)
+        assert out["status"][0] in (3, 4) and out["iters"][0] < 5000, (kw, out["status"], out["iters"])
+        if "limit" in kw:
+            assert out["status"][0] == 3

@@ -474,6 +474,11 @@ def test_infeasibility_certificate_in_a_batch():
     ok = [b for b in range(8) if b not in (2, 5)]
     assert (status[ok] == 1).all()
     assert opt.last_result.iters[[2, 5]].max() < 5000
+    # the C port carries the same certificate: same statuses on every problem of the batch
+    from oracle import admm_port
+
+    ref = admm_port.solve_batch(opt.last_batch, threads=8, accel_mem=5)
+    assert (ref["status"] == status).all(), (ref["status"], status)
 
 
 # ---- demand_charge / peak (aco.py:387-400): horizon-wide prox of dc * max(max_t power_t, floor) -----
