@@ -463,7 +463,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     // general-shape fallback: state streamed through a global workspace (not graph-capturable: it may allocate)
     const size_t rsz = o->precision == 32 ? 4 : 8;
     const long long n = (long long)h->N * p->t_max, mt = (long long)d->MR * p->t_max;
-    ga.ws_per_problem = 6 * n + 7 * mt + 3LL * p->k_sessions * h->N + 8;
+    ga.ws_per_problem = 7 * n + 8 * mt + 3LL * p->k_sessions * h->N + 8;   // incl. the certificate's dual snapshot
     HIP_TRY(h->work.reserve((size_t)ga.ws_per_problem * p->batch * rsz));
     ga.work = h->work.p;
     ga.pair_stride = o->precision == 32 ? 1 : 4;

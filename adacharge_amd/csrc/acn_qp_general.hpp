@@ -34,6 +34,17 @@ __device__ inline real block_reduce_max(real v, real* red, int tid) {
 }
 
 template <typename real>
+__device__ inline real block_reduce_sum(real v, real* red, int tid) {
+  v = wave_sum<real>(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  real m = red[0];
+  for (int w = 1; w < kGenThreads / 64; ++w) m += red[w];
+  return m;
+}
+
+template <typename real>
 __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const GeneralArgs GA) {
   using M = Mfma<real>;
   const TiledArgs& A = GA.t;
@@ -47,6 +58,8 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   real* mu = zh2 + mt;             // [K*N]
   real* slo = mu + K * N;
   real* shi = slo + K * N;
+  real* y1p = shi + K * N;         // duals at the previous residual check (infeasibility certificate)
+  real* y2p = y1p + n;
   const real* Gm = static_cast<const real*>(A.G);
   const real* Gh = static_cast<const real*>(A.Ghat);
   const real* Qm = static_cast<const real*>(A.Q);
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   real rho = (real)A.rho0;
   int status = 2, it = 0, n_adapt = 0;
   real pri = M::big, dua = M::big;
-  bool done = false;
+  bool done = false, have_prev = false;
   // ---- energy rows: one thread per session, safeguarded Newton on g(m) = sum clip(zh - m); reads zh and the
   // box-clipped z1, overwrites z1 on the session windows.  Used by the start and by every iteration.
   auto project_sessions = [&]() __attribute__((always_inline)) {
@@ -278,7 +291,82 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
       const real npri = block_reduce_max<real>(v2, red, tid);
       const real ndua = fmax(fmax(block_reduce_max<real>(v4, red, tid), block_reduce_max<real>(v5, red, tid)), qnorm);
       if (pri <= (real)A.eps_abs + (real)A.eps_rel * npri && dua <= (real)A.eps_abs + (real)A.eps_rel * ndua) { status = 1; done = true; }
-      else if (it >= A.max_iter) {
+      if (!done && have_prev) {
+        // ---- primal infeasibility certificate (see acn_qp_tiled.hpp): v = y - y(previous check) ------------
+        real vnl = 0, atl = 0;
+        for (int k = tid; k < n; k += kGenThreads) {
+          const int i = k / T, t = k - i * T;
+          const real v1 = y1[k] - y1p[k];
+          real gtv = 0;
+          for (int j = 0; j < MR; ++j) gtv += Gm[(size_t)j * NP + i] * (y2[j * T + t] - y2p[j * T + t]);
+          vnl = fmax(vnl, fabs(v1));
+          atl = fmax(atl, fabs(v1 + gtv));
+        }
+        for (int k = tid; k < mt; k += kGenThreads) vnl = fmax(vnl, fabs(y2[k] - y2p[k]));
+        const real vn = block_reduce_max<real>(vnl, red, tid);
+        const real atv = block_reduce_max<real>(atl, red, tid);
+        const real vtol = (real)1e-4 * vn;
+        if (vn > (real)1e-12 * fmax((real)1, qnorm) && atv <= vtol) {   // block-uniform
+          real ssum = 0, bad = 0;
+          for (int k = tid; k < mt; k += kGenThreads) {
+            const int r = k / T, t = k - r * T;
+            const int ty = A.rowtype[r];
+            const real v2 = y2[k] - y2p[k];
+            if (ty == kRowBox) { ssum += RL[r] * fmax(v2, (real)0); if (v2 < -vtol) bad = 1; }
+            else if (ty == kRowPeak) {
+              const double pv = A.peak ? A.peak[(size_t)b * T + t] : 1e300;
+              if (pv < (double)M::big) ssum += (real)(pv * A.peak_scale) * fmax(v2, (real)0); else if (v2 > vtol) bad = 1;
+              if (v2 < -vtol) bad = 1;
+            } else if (ty == kRowSocRe) {
+              const real vi = y2[(r + GA.pair_stride) * T + t] - y2p[(r + GA.pair_stride) * T + t];
+              ssum += RL[r] * sqrt(v2 * v2 + vi * vi);
+            } else if (ty == kRowSocIm) {
+            } else if (fabs(v2) > vtol) bad = 1;   // free / prox rows admit no ray
+          }
+          // sessions (zh is free at this point: coverage flags of the periods that lie in some window)
+          for (int k = tid; k < n; k += kGenThreads) zh[k] = 0;
+          __syncthreads();
+          for (int s = tid; s < K * N; s += kGenThreads) {
+            const int i = s % N;
+            const size_t sidx = (size_t)b * K * N + s;
+            const int off = A.s_off[sidx];
+            int len = A.s_len[sidx];
+            if (off + len > T) len = T - off;
+            if (len <= 0) continue;
+            real lmin = M::big, lmax = -M::big;
+            for (int t = off; t < off + len; ++t) {
+              const real v1 = y1[i * T + t] - y1p[i * T + t];
+              lmin = fmin(lmin, v1); lmax = fmax(lmax, v1);
+              zh[i * T + t] = 1;
+            }
+            real best = M::big;
+            for (int j = 0; j < 3; ++j) {
+              real l_ = j == 0 ? lmin : (j == 1 ? lmax : (real)0);
+              if (!eq) l_ = fmax(l_, (real)0);
+              real ph = l_ * (real)A.s_cap[sidx];
+              for (int t = off; t < off + len; ++t) {
+                const real dv = (y1[i * T + t] - y1p[i * T + t]) - l_;
+                ph += ub[i * T + t] * fmax(dv, (real)0) + (real)lbg[i * T + t] * fmin(dv, (real)0);
+              }
+              best = fmin(best, ph);
+            }
+            ssum += best;
+          }
+          __syncthreads();
+          for (int k = tid; k < n; k += kGenThreads)
+            if (zh[k] == (real)0) ssum += (real)lbg[k] * (y1[k] - y1p[k]);
+          const real stot = block_reduce_sum<real>(ssum, red, tid);
+          const real anyb = block_reduce_max<real>(bad, red, tid);
+          if (anyb == (real)0 && stot < -vtol) { status = 3; done = true; }
+        }
+      }
+      if (!done) {   // snapshot for the next certificate test
+        for (int k = tid; k < n; k += kGenThreads) y1p[k] = y1[k];
+        for (int k = tid; k < mt; k += kGenThreads) y2p[k] = y2[k];
+        have_prev = true;
+      }
+      if (done) {
+      } else if (it >= A.max_iter) {
         done = true;
         if (pri <= (real)kInaccurate * ((real)A.eps_abs + (real)A.eps_rel * npri) &&
             dua <= (real)kInaccurate * ((real)A.eps_abs + (real)A.eps_rel * ndua)) status = 5;   // solved, inaccurately

@@ -721,3 +721,24 @@ def test_max_iter_with_small_residuals_is_optimal_inaccurate():
     hopeless = AdaptiveChargingOptimization(obj, iface, solver_options=dict(eps_abs=1e-8, eps_rel=1e-8, max_iter=5))
     with pytest.raises(InfeasibilityException, match="max_iter_reached"):
         hopeless.solve(sl, infra)
+
+
+@pytest.mark.parametrize("ct", ["LINEAR", "SOC"])
+def test_general_kernel_certifies_infeasibility(ct):
+    """Horizon 40 takes the general-shape kernel.  Two EVSEs must each receive exactly 13.9 kWh (20 A for 40
+    periods) through a 30 A feeder: no schedule exists, and the kernel says so instead of iterating to max_iter."""
+    k = 208 * 5 / 60 / 1e3
+    sd = session_generator(2, [0, 0], [40, 40], [20 * 40 * k] * 2, [20 * 40 * k] * 2, [32] * 2)
+    iface = TestingInterface({"active_sessions": sd, "infrastructure_info": single_phase_single_constraint(2, 30),
+                              "current_time": 0, "period": 5})
+    opt = AdaptiveChargingOptimization(DEFAULT_OBJECTIVE, iface, constraint_type=ct, enforce_energy_equality=True,
+                                       solver_options=dict(max_iter=20000))
+    with pytest.raises(InfeasibilityException, match="Solve failed with status infeasible"):
+        opt.solve(iface.active_sessions(), iface.infrastructure_info())
+    assert opt.last_result.status[0] == 3 and opt.last_result.iters[0] < 5000
+    # the same problem with a feeder that can carry it is solved
+    iface_ok = TestingInterface({"active_sessions": sd, "infrastructure_info": single_phase_single_constraint(2, 64),
+                                 "current_time": 0, "period": 5})
+    ok = AdaptiveChargingOptimization(DEFAULT_OBJECTIVE, iface_ok, constraint_type=ct, enforce_energy_equality=True)
+    rates = ok.solve(iface_ok.active_sessions(), iface_ok.infrastructure_info())
+    assert np.allclose(rates.sum(axis=1) * k, 20 * 40 * k, rtol=1e-6)
