@@ -463,7 +463,10 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     // general-shape fallback: state streamed through a global workspace (not graph-capturable: it may allocate)
     const size_t rsz = o->precision == 32 ? 4 : 8;
     const long long n = (long long)h->N * p->t_max, mt = (long long)d->MR * p->t_max;
-    ga.ws_per_problem = 7 * n + 8 * mt + 3LL * p->k_sessions * h->N + 8;   // incl. the certificate's dual snapshot
+    const int gm = std::min(a.accel_mem, acnqp::kGenAccelMax);
+    const long long Dn = n + mt;
+    // solver state, the certificate's dual snapshot, the Anderson vectors (u, f: reals; correction and rings: floats)
+    ga.ws_per_problem = 7 * n + 8 * mt + 3LL * p->k_sessions * h->N + 8 + 2 * Dn + ((1 + 2LL * gm) * Dn * 4 + (long long)rsz - 1) / (long long)rsz + 2;
     HIP_TRY(h->work.reserve((size_t)ga.ws_per_problem * p->batch * rsz));
     ga.work = h->work.p;
     ga.pair_stride = o->precision == 32 ? 1 : 4;
@@ -490,7 +493,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
 
 int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, int32_t precision, int32_t requested) {
   if (!h || t_max < 1 || k_sessions < 1 || requested <= 0) return 0;
-  if (!(h->N <= 64 && t_max <= 32)) return 0;   // general-shape kernel: plain ADMM
+  if (!(h->N <= 64 && t_max <= 32)) return std::min(requested, acnqp::kGenAccelMax);   // general-shape kernel: ring in its workspace
   SiteDev* d = &h->dev64;
   if (precision == 32) {
     d = &h->dev32;

@@ -14,6 +14,7 @@
 namespace acnqp {
 
 constexpr int kGenThreads = 256;
+constexpr int kGenAccelMax = 5;   // Anderson ring slots (the tiled kernel's number)
 
 struct GeneralArgs {
   TiledArgs t;          // same site / problem / result / option fields as the tiled kernel
@@ -60,6 +61,17 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   real* shi = slo + K * N;
   real* y1p = shi + K * N;         // duals at the previous residual check (infeasibility certificate)
   real* y2p = y1p + n;
+  // Anderson acceleration (same algorithm as acn_qp_tiled.hpp, state in the workspace): u, f of the previous event,
+  // the correction applied then (float), the dF / dG rings (float)
+  const int D = n + mt;
+  const int aa_m = min(A.accel_mem, kGenAccelMax);
+  real* uprev = y2p + mt;
+  real* fprev = uprev + D;
+  float* cprev = reinterpret_cast<float*>(fprev + D);
+  float* ringF = cprev + D;
+  float* ringG = ringF + (size_t)aa_m * D;
+  __shared__ real aaH[kGenAccelMax * kGenAccelMax + kGenAccelMax];
+  __shared__ real aaG[kGenAccelMax];
   const real* Gm = static_cast<const real*>(A.G);
   const real* Gh = static_cast<const real*>(A.Ghat);
   const real* Qm = static_cast<const real*>(A.Q);
@@ -184,7 +196,17 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
     real acc = 0;
     for (int i = 0; i < N; ++i) acc += Gm[(size_t)r * NP + i] * z1[i * T + t];
     z2[k] = acc; gx[k] = acc; y2[k] = 0; w[k] = rho * acc;
+    if (aa_m > 0) { uprev[n + k] = acc; fprev[n + k] = 0; cprev[n + k] = 0.f; }
   }
+  if (aa_m > 0) {
+    for (int k = tid; k < n; k += kGenThreads) { uprev[k] = z1[k] + y1[k] / rho; fprev[k] = 0; cprev[k] = 0.f; }
+    for (int k = tid; k < 2 * aa_m * D; k += kGenThreads) ringF[k] = 0.f;   // dF and dG rings are contiguous
+    for (int k = tid; k < kGenAccelMax * kGenAccelMax + kGenAccelMax; k += kGenThreads) aaH[k] = 0;
+  }
+  int aa_cnt = 0, aa_head = 0, aa_cool = 0, aa_pen = 1;
+  unsigned aa_valid = 0;
+  bool aa_have_prev = false, aa_was = false;
+  real fn_prev = 0;
   __syncthreads();
   while (!done) {
     ++it;
@@ -220,6 +242,105 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
       zh2[k] = alpha * zt + ((real)1 - alpha) * z2[k] + y2[k] * inv_rho;
     }
     __syncthreads();
+    const bool check = (it % A.check_every == 0) || it >= A.max_iter;
+    // ---- Anderson acceleration event (see acn_qp_tiled.hpp; u = (zh, zh2), block-uniform control flow) --------
+    if (aa_m > 0 && it % kAaPeriod == 0) {
+      auto g_at = [&](int k) -> real& { return k < n ? zh[k] : zh2[k - n]; };
+      const bool col = aa_have_prev;
+      const int slot = aa_head;
+      float* cF = ringF + (size_t)slot * D;
+      float* cG = ringG + (size_t)slot * D;
+      real part[kGenAccelMax + 2];
+      for (int j = 0; j < kGenAccelMax + 2; ++j) part[j] = 0;
+      for (int k = tid; k < D; k += kGenThreads) {
+        const real g_ = g_at(k), f = g_ - uprev[k];
+        part[kGenAccelMax + 1] += f * f;
+        if (col) {   // the new column pair (speculatively: it only counts once marked live)
+          cF[k] = (float)(f - fprev[k]);
+          cG[k] = (float)(g_ - (uprev[k] + (real)cprev[k]));
+        }
+      }
+      const unsigned vnew = aa_valid | (col ? 1u << slot : 0u);
+      if (col) {
+        for (int k = tid; k < D; k += kGenThreads) {
+          const real cf = (real)cF[k];
+          for (int j = 0; j < aa_m; ++j)
+            if ((vnew >> j) & 1u) part[j] += cf * (real)ringF[(size_t)j * D + k];
+          part[kGenAccelMax] += cf * (g_at(k) - uprev[k]);
+        }
+      }
+      real d[kGenAccelMax + 2];
+      for (int j = 0; j < kGenAccelMax + 2; ++j) d[j] = block_reduce_sum<real>(part[j], red, tid);
+      const real fn = sqrt(d[kGenAccelMax + 1]);
+      bool keep = col;
+      if (aa_was && fn > (real)kAaSafe * fn_prev) {   // the accelerated step made things worse: clear, back off
+        aa_cnt = 0; aa_head = 0; aa_valid = 0; keep = false;
+        __syncthreads();
+        for (int k = tid; k < kGenAccelMax * kGenAccelMax + kGenAccelMax; k += kGenThreads) aaH[k] = 0;
+        aa_cool = aa_pen;
+        aa_pen = aa_pen < 64 ? 2 * aa_pen : 64;
+      } else if (aa_cool > 0) --aa_cool;
+      __syncthreads();
+      if (keep) {
+        aa_valid |= 1u << slot;
+        if (tid == 0) {
+          for (int j = 0; j < aa_m; ++j) {
+            if (!((aa_valid >> j) & 1u)) continue;
+            aaH[slot * kGenAccelMax + j] = d[j];
+            aaH[j * kGenAccelMax + slot] = d[j];
+            if (j != slot) aaH[kGenAccelMax * kGenAccelMax + j] += d[j];
+          }
+          aaH[kGenAccelMax * kGenAccelMax + slot] = d[kGenAccelMax];
+        }
+        aa_head = slot + 1 == aa_m ? 0 : slot + 1;
+        aa_cnt = aa_cnt < aa_m ? aa_cnt + 1 : aa_m;
+      }
+      for (int k = tid; k < D; k += kGenThreads) fprev[k] = g_at(k) - uprev[k];
+      aa_have_prev = true; fn_prev = fn; aa_was = false;
+      __syncthreads();
+      real dself = 0;   // |dF_new|^2
+      for (int j = 0; j < kGenAccelMax; ++j) dself = j == slot ? d[j] : dself;
+      // no extrapolation while the map drifts (|dF_new| <= kAaDrift |f|)
+      const bool apply = aa_cnt > 0 && aa_cool == 0 && !check && dself > (real)(kAaDrift * kAaDrift) * d[kGenAccelMax + 1];
+      if (apply) {
+        if (tid == 0) {   // gamma = (H + eta I)^-1 b, Gauss-Jordan in the order of the C port
+          real Aug[kGenAccelMax][kGenAccelMax + 1];
+          real tr = 0;
+          for (int i = 0; i < aa_m; ++i) if ((aa_valid >> i) & 1u) tr += aaH[i * kGenAccelMax + i];
+          const real eta = (real)kAaReg * tr + (real)(sizeof(real) == 8 ? 1e-300 : 1e-37);
+          for (int i = 0; i < aa_m; ++i) {
+            const bool vi = (aa_valid >> i) & 1u;
+            for (int j = 0; j < aa_m; ++j) Aug[i][j] = (vi && ((aa_valid >> j) & 1u)) ? aaH[i * kGenAccelMax + j] : (real)0;
+            Aug[i][i] = vi ? Aug[i][i] + eta : (real)1;
+            Aug[i][aa_m] = vi ? aaH[kGenAccelMax * kGenAccelMax + i] : (real)0;
+          }
+          for (int k = 0; k < aa_m; ++k) {
+            const real inv = (real)1 / Aug[k][k];
+            real rs[kGenAccelMax + 1], ck[kGenAccelMax];
+            for (int j = 0; j <= aa_m; ++j) rs[j] = Aug[k][j] * inv;
+            for (int i = 0; i < aa_m; ++i) ck[i] = Aug[i][k];
+            for (int i = 0; i < aa_m; ++i)
+              for (int j = 0; j <= aa_m; ++j) Aug[i][j] = i == k ? rs[j] : Aug[i][j] - ck[i] * rs[j];
+          }
+          for (int i = 0; i < aa_m; ++i) aaG[i] = Aug[i][aa_m];
+        }
+        __syncthreads();
+      }
+      for (int k = tid; k < D; k += kGenThreads) {
+        real cor = 0;
+        if (apply)
+          for (int j = 0; j < aa_m; ++j)
+            if ((aa_valid >> j) & 1u) cor += aaG[j] * (real)ringG[(size_t)j * D + k];
+        const float c_ = (float)cor;            // kept as float; u = g - c with exactly that c
+        real& g_ = g_at(k);
+        g_ -= (real)c_;
+        uprev[k] = g_;
+        cprev[k] = c_;
+        if (k < n) z1[k] = fmin(fmax(g_, (real)lbg[k]), ub[k]);
+      }
+      aa_was = apply;
+      __syncthreads();
+    }
     project_sessions();
     // ---- site rows: projection (internal row order: a SOC pair is `pair_stride` rows apart) -------
     for (int k = tid; k < mt; k += kGenThreads) {
@@ -268,7 +389,6 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
     __syncthreads();
     for (int k = tid; k < n; k += kGenThreads) y1[k] = rho * (zh[k] - z1[k]);
     // ---- residuals, termination, rho adaptation ------------------------------------------------
-    const bool check = (it % A.check_every == 0) || it >= A.max_iter;
     if (check) {
       real v0 = 0, v1 = 0, v2 = 0, v4 = 0, v5 = 0;
       for (int k = tid; k < n; k += kGenThreads) {
@@ -375,7 +495,17 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
         const real sp = pri / fmax(npri, (real)1e-12), sd = dua / fmax(ndua, (real)1e-12);
         const real ratio = sqrt(sp / fmax(sd, (real)1e-30));
         const real tol_eff = (real)A.adapt_tol * ((real)1 + (real)n_adapt * (real)(1.0 / kAdaptWiden));
-        if (ratio > tol_eff || ratio < (real)1 / tol_eff) { rho = fmin(fmax(rho * ratio, (real)1e-6), (real)1e6); ++n_adapt; }
+        if (ratio > tol_eff || ratio < (real)1 / tol_eff) {
+          rho = fmin(fmax(rho * ratio, (real)1e-6), (real)1e6);
+          ++n_adapt;
+          if (aa_m > 0) {   // the fixed-point map changed: restart the ring from the current (z, y)
+            aa_cnt = 0; aa_head = 0; aa_valid = 0; aa_have_prev = false; aa_was = false;
+            __syncthreads();
+            for (int k = tid; k < kGenAccelMax * kGenAccelMax + kGenAccelMax; k += kGenThreads) aaH[k] = 0;
+            for (int k = tid; k < n; k += kGenThreads) uprev[k] = z1[k] + y1[k] / rho;
+            for (int k = tid; k < mt; k += kGenThreads) uprev[n + k] = z2[k] + y2[k] / rho;
+          }
+        }
       }
     }
     if (!done) {

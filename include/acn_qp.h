@@ -181,7 +181,7 @@ int32_t acnqp_kernel_times(acnqp_handle* h, float* out_ms, int32_t capacity);
 /* Anderson columns the kernels will actually use for problems of this shape
  * (t_max periods, k_sessions slots) at the given precision when `requested`
  * columns are asked for: a function of the shape only, never of the batch
- * size.  0 for shapes that take the general kernel.  No reference equivalent:
+ * size (the general-shape kernel keeps its ring in global memory: 5).  No reference equivalent:
  * test/bench plumbing so that a CPU restatement can run the same algorithm.  */
 int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, int32_t precision,
                             int32_t requested);
