@@ -81,6 +81,8 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device rehearses the N > 1 path on a single-GPU box")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--rehearse-collective", action="store_true",
+                    help="rehearsal only: run the per-step all-gather (and its process group) even with one rank")
     return ap.parse_args()
 
 
@@ -171,6 +173,10 @@ def cpu_baseline_leg(batch, gpu_x, gpu_status, target_seconds, snaps, infra, ifa
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner, Gloo's rank
+    # chatter): keep the real stdout for the JSON line and point file descriptor 1 at stderr for everything else.
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -185,8 +191,12 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    collective = world > 1 or args.rehearse_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29591")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -216,7 +226,7 @@ def main():
         slots.append(dict(
             snaps=sn, batch=bt, handle=SiteHandle(bt.site, local_rank), dbatch=DeviceBatch(bt, dev),
             stream=new_stream(dev) if depth > 1 else torch.cuda.current_stream(),
-            gathered=torch.empty((world * B, bt.N, bt.Tm), dtype=torch.float64, device=gdev) if world > 1 else None,
+            gathered=torch.empty((world * B, bt.N, bt.Tm), dtype=torch.float64, device=gdev) if collective else None,
         ))
     snaps, batch, handle, dbatch = (slots[0][k] for k in ("snaps", "batch", "handle", "dbatch"))
 
@@ -224,7 +234,7 @@ def main():
         sl = slots[i % depth]
         with torch.cuda.stream(sl["stream"]):
             sl["handle"].solve_device(sl["dbatch"], opts, stream=sl["stream"].cuda_stream)
-            if world > 1:   # the one collective of the job: every rank ends up with all schedules
+            if collective:   # the one collective of the job: every rank ends up with all schedules
                 if args.dist_backend == "nccl":
                     dist.all_gather_into_tensor(sl["gathered"], sl["dbatch"].x)
                 else:
@@ -232,7 +242,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -256,7 +266,7 @@ def main():
     for sl in slots:
         kernel_ms += sl["handle"].kernel_times()   # HIP events on the launch streams, read after the fence
     gathered = slots[0]["gathered"]
-    if world > 1:
+    if collective:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -267,7 +277,7 @@ def main():
     used = slots
     solved = int(sum(int((sl["dbatch"].status == 1).sum().item()) for sl in used))
     iters_all = np.concatenate([sl["dbatch"].iters.cpu().numpy() for sl in used])
-    if world > 1:
+    if collective:
         cnt = torch.tensor([solved, B * len(used)], dtype=torch.int64, device=gdev)
         dist.all_reduce(cnt)
         solved_all, total_all = int(cnt[0]), int(cnt[1])
@@ -336,8 +346,8 @@ def main():
                                           accel_mem=handle.accel_columns(batch.Tm, batch.K, opts))
             out["cpu_baseline"] = cb
             out["parity"] = parity
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=json_out, flush=True)
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 
