@@ -750,3 +750,34 @@ def test_general_kernel_certifies_infeasibility(ct):
     ok = AdaptiveChargingOptimization(DEFAULT_OBJECTIVE, iface_ok, constraint_type=ct, enforce_energy_equality=True)
     rates = ok.solve(iface_ok.active_sessions(), iface_ok.infrastructure_info())
     assert np.allclose(rates.sum(axis=1) * k, 20 * 40 * k, rtol=1e-6)
+
+
+def test_certified_infeasible_problems_are_infeasible_for_highs():
+    """Random equality-constrained LINEAR problems (two session slots, horizon 20): a few of 640 cannot be served.
+    Every problem the device certifies infeasible must be infeasible for scipy-HiGHS on the problem the reference
+    states, and problems it solves must be feasible there; the C port flags exactly the same ones."""
+    from adacharge_amd import tou_energy_cost, total_energy
+    from adacharge_amd.acn import Interface
+    from oracle import admm_port
+    from oracle.ipm import solve_lp_highs
+    from oracle.ref_problem import build_reference_problem
+
+    rng = np.random.default_rng(5005)
+    infra = sites.caltech54()
+    iface = Interface({"infrastructure_info": infra, "period": 5, "prices": rng.uniform(0.05, 0.4, size=64)})
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 10.0 ** rng.uniform(-4, -2)),
+           ObjectiveComponent(tou_energy_cost, float(rng.uniform(0, 5))), ObjectiveComponent(total_energy, float(rng.uniform(0, 2)))]
+    snaps = [_random_sessions_general(infra, 20, rng, True, min_rates=False, demand_scale=0.5) for _ in range(640)]
+    batch = build_batch(snaps, infra, iface, obj, "LINEAR", True)
+    h = SiteHandle(batch.site, 0)
+    res = h.solve(batch, default_options(max_iter=30000))
+    assert np.isin(res.status, (1, 3)).all()
+    flagged = np.flatnonzero(res.status == 3)
+    assert 1 <= len(flagged) <= 10
+    ref = admm_port.solve_batch(batch, threads=8, max_iter=30000, accel_mem=h.accel_columns(batch.Tm, batch.K, default_options()))
+    assert (ref["status"] == res.status).all()
+    for b in list(flagged) + [0, 1, 2]:
+        prob = build_reference_problem(snaps[b], infra, iface, [("quick_charge", 1, {})], "LINEAR", enforce_energy_equality=True)
+        lp = solve_lp_highs(prob)
+        assert (lp.status == 2) == (res.status[b] == 3), (b, lp.status, res.status[b])
+    h.close()

@@ -1,0 +1,49 @@
+"""Dev tool: soak the tiled kernel on the randomised problem classes of tests/test_gpu_parity.py (two session slots,
+ragged horizons, peak vectors, equality rows, min rates, two sites) at a larger batch, checking statuses,
+finiteness and the structural invariants of every solved schedule."""
+import sys
+sys.path.insert(0, '.')
+import numpy as np
+from adacharge_amd import ObjectiveComponent, equal_share, quick_charge, sites, tou_energy_cost, total_energy
+from adacharge_amd.acn import Interface
+from adacharge_amd.backend import SiteHandle, default_options
+from adacharge_amd.builder import build_batch
+from tests.test_gpu_parity import _random_sessions_general
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+bad_total = 0
+for case in range(8):
+    rng = np.random.default_rng(5000 + case)
+    T = [12, 16, 24, 30, 12, 20, 9, 32][case]
+    ct = ["SOC", "LINEAR"][case % 2]
+    eq = case in (2, 5); two = case in (1, 3, 5, 7); with_peak = case in (0, 3, 4, 7)
+    infra = sites.caltech54() if case != 6 else sites.jpl52()
+    iface = Interface({"infrastructure_info": infra, "period": 5, "prices": rng.uniform(0.05, 0.4, size=64)})
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 10.0 ** rng.uniform(-4, -2)),
+           ObjectiveComponent(tou_energy_cost, float(rng.uniform(0, 5))), ObjectiveComponent(total_energy, float(rng.uniform(0, 2)))]
+    snaps, peaks = [], []
+    for _ in range(B):
+        snaps.append(_random_sessions_general(infra, T, rng, two, min_rates=not eq, demand_scale=0.5 if eq else 1.5))
+        peaks.append((float(rng.uniform(250, 600)) if rng.random() < 0.5 else rng.uniform(250, 600, size=T)) if with_peak else None)
+    Ts = [max(s.arrival_offset + s.remaining_time for s in sl) for sl in snaps]
+    peaks = [p if (p is None or np.isscalar(p)) else p[:t] for p, t in zip(peaks, Ts)]
+    batch = build_batch(snaps, infra, iface, obj, ct, eq, peak_limits=peaks)
+    h = SiteHandle(batch.site, 0)
+    r = h.solve(batch, default_options(max_iter=30000))
+    ok = np.isin(r.status, (1, 5))
+    finite = np.isfinite(r.x).all()
+    x = r.x[ok]
+    box = (x <= batch.ub[ok] + 1e-9).all() and (x >= batch.lb[ok] - 1e-9).all()
+    ph = np.deg2rad(infra.phases); cm = infra.constraint_matrix
+    if ct == "SOC":
+        mag = np.hypot(np.einsum("mn,bnt->bmt", cm * np.cos(ph), x), np.einsum("mn,bnt->bmt", cm * np.sin(ph), x))
+    else:
+        mag = np.einsum("mn,bnt->bmt", np.abs(cm), x)
+    viol = float((mag - infra.constraint_limits[None, :, None]).max())
+    pk = float((x.sum(axis=1) - batch.peak[ok]).max()) if with_peak else 0.0
+    counts = np.bincount(r.status, minlength=6)[1:]
+    print(f"case {case} {ct} T={T} eq={eq} K={batch.K} peak={with_peak}: status counts(1..5) {counts.tolist()} finite {finite} box {box} "
+          f"max row violation {viol:.2e} max peak violation {pk:.2e} iters mean {r.iters.mean():.0f} max {r.iters.max()} kernel {r.kernel_ms:.1f} ms", flush=True)
+    bad_total += int(not finite) + int(not box) + int(viol > 5e-3) + int(pk > 5e-3)
+    h.close()
+print("anomalies:", bad_total)
