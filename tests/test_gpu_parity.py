@@ -3,6 +3,8 @@
 oracle-certified golden vectors, (iii) size-independent properties at the
 BASELINE.json batch sizes.  Tolerance on rates: 1e-4 relative to the 32 A
 pilot scale (north_star), i.e. 3.2e-3 A absolute."""
+import os
+
 import numpy as np
 import pytest
 
@@ -781,3 +783,57 @@ def test_certified_infeasible_problems_are_infeasible_for_highs():
         lp = solve_lp_highs(prob)
         assert (lp.status == 2) == (res.status[b] == 3), (b, lp.status, res.status[b])
     h.close()
+
+
+# ---- N > 1 with the real library: two ranks share the one GPU of the test box, gloo for the gather -----------------
+def _sharded_rank(rank, world, port, q):
+    import torch.distributed as dist
+
+    from adacharge_amd.distributed import solve_sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    infra, iface = H.caltech_interface()
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    snaps = sites.snapshot_batch(infra, 12, 24, seed=77)
+
+    def solve_local(lo, hi):
+        batch = build_batch(snaps[lo:hi], infra, iface, obj, "SOC")
+        h = SiteHandle(batch.site, 0)
+        res = h.solve(batch, default_options())
+        h.close()
+        x = np.zeros((hi - lo, batch.N, 12))
+        x[:, :, : batch.Tm] = res.x
+        return x, res.status
+
+    x, st = solve_sharded(len(snaps), solve_local, device="cpu")
+    q.put((rank, x, st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_a_batch_and_gather_the_schedules():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_sharded_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    infra, iface = H.caltech_interface()
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    snaps = sites.snapshot_batch(infra, 12, 24, seed=77)
+    batch = build_batch(snaps, infra, iface, obj, "SOC")
+    h = SiteHandle(batch.site, 0)
+    whole = h.solve(batch, default_options())
+    h.close()
+    for rank, x, st in got:
+        assert x.shape == (24, 54, 12) and (st == 1).all()
+        # a problem's result does not depend on what it is batched with: bitwise the single-process answer
+        assert np.array_equal(x[:, :, : batch.Tm], whole.x)
