@@ -479,10 +479,16 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   if (tiled) {
     e = (o->precision == 32) ? launch_any<float>(a, h->NW, st) : launch_any<double>(a, h->NW, st);
   } else {
-    if (o->precision == 32)
-      hipLaunchKernelGGL(acnqp::admm_general_kernel<float>, dim3(a.B), dim3(acnqp::kGenThreads), 0, st, ga);
-    else
-      hipLaunchKernelGGL(acnqp::admm_general_kernel<double>, dim3(a.B), dim3(acnqp::kGenThreads), 0, st, ga);
+    // workgroup size by problem size: the plain loops are latency-bound, more threads per problem hide more of it
+    const long long nvar = (long long)h->N * p->t_max;
+    const int nt = nvar <= 4096 ? 256 : (nvar <= 12288 ? 512 : 1024);
+    auto launch_general = [&](auto real_tag) {
+      using real = decltype(real_tag);
+      if (nt == 256) hipLaunchKernelGGL((acnqp::admm_general_kernel<real, 256>), dim3(a.B), dim3(256), 0, st, ga);
+      else if (nt == 512) hipLaunchKernelGGL((acnqp::admm_general_kernel<real, 512>), dim3(a.B), dim3(512), 0, st, ga);
+      else hipLaunchKernelGGL((acnqp::admm_general_kernel<real, 1024>), dim3(a.B), dim3(1024), 0, st, ga);
+    };
+    if (o->precision == 32) launch_general(float{}); else launch_general(double{});
     e = hipGetLastError();
   }
   if (e != hipSuccess) return fail(ACNQP_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));

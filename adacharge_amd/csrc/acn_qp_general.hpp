@@ -13,7 +13,7 @@
 
 namespace acnqp {
 
-constexpr int kGenThreads = 256;
+constexpr int kGenThreadsMax = 1024;   // workgroup sizes 256 / 512 / 1024, chosen by problem size (acn_qp_api.hip)
 constexpr int kGenAccelMax = 5;   // Anderson ring slots (the tiled kernel's number)
 
 struct GeneralArgs {
@@ -23,7 +23,7 @@ struct GeneralArgs {
   int pair_stride;      // register distance of a SOC pair in the internal row order (4: f64, 1: f32)
 };
 
-template <typename real>
+template <typename real, int kGenThreads>
 __device__ inline real block_reduce_max(real v, real* red, int tid) {
   v = wave_max<real>(v);
   __syncthreads();
@@ -34,7 +34,7 @@ __device__ inline real block_reduce_max(real v, real* red, int tid) {
   return m;
 }
 
-template <typename real>
+template <typename real, int kGenThreads>
 __device__ inline real block_reduce_sum(real v, real* red, int tid) {
   v = wave_sum<real>(v);
   __syncthreads();
@@ -45,11 +45,11 @@ __device__ inline real block_reduce_sum(real v, real* red, int tid) {
   return m;
 }
 
-template <typename real>
+template <typename real, int kGenThreads>
 __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const GeneralArgs GA) {
   using M = Mfma<real>;
   const TiledArgs& A = GA.t;
-  __shared__ real red[8];
+  __shared__ real red[kGenThreads / 64];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int N = A.N, T = A.Tm, NP = A.NP, MR = A.MR, K = A.K;
   const int n = N * T, mt = MR * T;
@@ -114,9 +114,9 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
     }
   }
   __syncthreads();
-  const real qnorm = block_reduce_max<real>(qn, red, tid);
-  const real ubmax = block_reduce_max<real>(um, red, tid);
-  const real anybad = block_reduce_max<real>(bad, red, tid);
+  const real qnorm = block_reduce_max<real, kGenThreads>(qn, red, tid);
+  const real ubmax = block_reduce_max<real, kGenThreads>(um, red, tid);
+  const real anybad = block_reduce_max<real, kGenThreads>(bad, red, tid);
   const real pd_user = (real)A.pdiag[b];
   real pd = pd_user;
   if (ubmax > 0) pd = fmax(pd_user, (real)A.reg_rel * qnorm / (ubmax * (real)max(1, A.horizon[b])));
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
         }
       }
       real d[kGenAccelMax + 2];
-      for (int j = 0; j < kGenAccelMax + 2; ++j) d[j] = block_reduce_sum<real>(part[j], red, tid);
+      for (int j = 0; j < kGenAccelMax + 2; ++j) d[j] = block_reduce_sum<real, kGenThreads>(part[j], red, tid);
       const real fn = sqrt(d[kGenAccelMax + 1]);
       bool keep = col;
       if (aa_was && fn > (real)kAaSafe * fn_prev) {   // the accelerated step made things worse: clear, back off
@@ -406,10 +406,10 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
         v0 = fmax(v0, fabs(gx[k] - z2[k]));
         v2 = fmax(v2, fmax(fabs(gx[k]), fabs(z2[k])));
       }
-      pri = block_reduce_max<real>(v0, red, tid);
-      dua = block_reduce_max<real>(v1, red, tid);
-      const real npri = block_reduce_max<real>(v2, red, tid);
-      const real ndua = fmax(fmax(block_reduce_max<real>(v4, red, tid), block_reduce_max<real>(v5, red, tid)), qnorm);
+      pri = block_reduce_max<real, kGenThreads>(v0, red, tid);
+      dua = block_reduce_max<real, kGenThreads>(v1, red, tid);
+      const real npri = block_reduce_max<real, kGenThreads>(v2, red, tid);
+      const real ndua = fmax(fmax(block_reduce_max<real, kGenThreads>(v4, red, tid), block_reduce_max<real, kGenThreads>(v5, red, tid)), qnorm);
       if (pri <= (real)A.eps_abs + (real)A.eps_rel * npri && dua <= (real)A.eps_abs + (real)A.eps_rel * ndua) { status = 1; done = true; }
       if (!done && have_prev) {
         // ---- primal infeasibility certificate (see acn_qp_tiled.hpp): v = y - y(previous check) ------------
@@ -423,8 +423,8 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
           atl = fmax(atl, fabs(v1 + gtv));
         }
         for (int k = tid; k < mt; k += kGenThreads) vnl = fmax(vnl, fabs(y2[k] - y2p[k]));
-        const real vn = block_reduce_max<real>(vnl, red, tid);
-        const real atv = block_reduce_max<real>(atl, red, tid);
+        const real vn = block_reduce_max<real, kGenThreads>(vnl, red, tid);
+        const real atv = block_reduce_max<real, kGenThreads>(atl, red, tid);
         const real vtol = (real)1e-4 * vn;
         if (vn > (real)1e-12 * fmax((real)1, qnorm) && atv <= vtol) {   // block-uniform
           real ssum = 0, bad = 0;
@@ -475,8 +475,8 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
           __syncthreads();
           for (int k = tid; k < n; k += kGenThreads)
             if (zh[k] == (real)0) ssum += (real)lbg[k] * (y1[k] - y1p[k]);
-          const real stot = block_reduce_sum<real>(ssum, red, tid);
-          const real anyb = block_reduce_max<real>(bad, red, tid);
+          const real stot = block_reduce_sum<real, kGenThreads>(ssum, red, tid);
+          const real anyb = block_reduce_max<real, kGenThreads>(bad, red, tid);
           if (anyb == (real)0 && stot < -vtol) { status = 3; done = true; }
         }
       }
