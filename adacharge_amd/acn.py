@@ -289,16 +289,27 @@ def apply_upper_bound_estimate(ub_estimator, active_sessions):
     return new_sessions
 
 
-def apply_minimum_charging_rate(active_sessions, infrastructure, override=float("inf")):
-    """Give each session (by arrival) the EVSE's minimum pilot in the first
-    period when the network can carry it, else pin it to zero (ada.py:147-150)."""
+def remaining_amp_periods(session, infrastructure, period) -> float:
+    """acnportal.algorithms.utils.remaining_amp_periods [recalled]: A-periods still owed to a session."""
+    i = infrastructure.get_station_index(session.station_id)
+    amp_hours = session.remaining_demand * 1000 / infrastructure.voltages[i]
+    return amp_hours * 60 / period
+
+
+def apply_minimum_charging_rate(active_sessions, infrastructure, period, override=float("inf")):
+    """acnportal.algorithms.preprocessing.apply_minimum_charging_rate [recalled], called at ada.py:147-150 as
+    ``(active_sessions, infrastructure, self.interface.period)``: in arrival order, give each session the EVSE's
+    minimum pilot (capped by ``override``) as ``min_rates[0]`` when it still needs that much charge and the
+    network can carry it on top of the earlier arrivals' minimum pilots; otherwise pin its first period to zero."""
     session_queue = sorted(deepcopy(active_sessions), key=lambda s: s.arrival)
     session_queue = [s for s in session_queue if s.remaining_time > 0]
     rates = np.zeros(len(infrastructure.station_ids))
     for session in session_queue:
         i = infrastructure.get_station_index(session.station_id)
         rates[i] = min(infrastructure.min_pilot[i], override)
-        if infrastructure_constraints_feasible(rates, infrastructure):
+        if remaining_amp_periods(session, infrastructure, period) >= rates[i] and infrastructure_constraints_feasible(
+            rates, infrastructure
+        ):
             session.min_rates[0] = max(rates[i], session.min_rates[0])
             reconcile_max_and_min(session)
         else:

@@ -83,6 +83,7 @@ class _Results(C.Structure):
         ("pri_res", C.c_void_p),
         ("dua_res", C.c_void_p),
         ("obj", C.c_void_p),
+        ("x_dev", C.c_void_p),
     ]
 
 
@@ -117,6 +118,9 @@ EXPORTED_SYMBOLS = (
     "acnqp_last_kernel_ms",
     "acnqp_accel_columns",
     "acnqp_kernel_times",
+    "acnqp_solve_batches",
+    "acnqp_host_alloc",
+    "acnqp_host_free",
 )
 
 _lib = None
@@ -170,6 +174,12 @@ def load_library():
     lib.acnqp_accel_columns.restype = C.c_int32
     lib.acnqp_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int32]
     lib.acnqp_kernel_times.restype = C.c_int32
+    lib.acnqp_solve_batches.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_Problems), C.POINTER(Options), C.POINTER(_Results)]
+    lib.acnqp_solve_batches.restype = C.c_int
+    lib.acnqp_host_alloc.argtypes = [C.c_size_t]
+    lib.acnqp_host_alloc.restype = C.c_void_p
+    lib.acnqp_host_free.argtypes = [C.c_void_p]
+    lib.acnqp_host_free.restype = None
     _lib = lib
     return lib
 
@@ -209,6 +219,39 @@ class BatchResult:
     kernel_ms: float = float("nan")
 
 
+class _PinnedBlock:
+    """Owner of one acnqp_host_alloc block; freed when the last numpy view of it is gone."""
+
+    def __init__(self, nbytes: int):
+        self._lib = load_library()
+        self.nbytes = int(nbytes)
+        self.ptr = self._lib.acnqp_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError(f"acnqp_host_alloc({nbytes}) failed: {self._lib.acnqp_last_error().decode()}")
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.acnqp_host_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float64) -> np.ndarray:
+    """A zero-filled numpy array in pinned host memory (acnqp_host_alloc): the library's H2D / D2H copies of such
+    arrays are direct DMA.  Same call shape as ``np.zeros``; use it as ``alloc=`` of ``builder.build_batch``."""
+    dt = np.dtype(dtype)
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(k) for k in shape)
+    n = int(np.prod(shape)) if shape else 1
+    block = _PinnedBlock(max(n * dt.itemsize, 1))
+    buf = (C.c_char * block.nbytes).from_address(block.ptr)
+    buf._owner = block   # numpy keeps `buf` alive through .base; `buf` keeps the block
+    a = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    a[...] = 0
+    return a
+
+
 class SiteHandle:
     """One ``acnqp_handle``: a site uploaded to one GPU."""
 
@@ -239,13 +282,16 @@ class SiteHandle:
             pass
 
     # -- host buffers -----------------------------------------------------------
-    def solve(self, batch: ProblemBatch, options: Optional[Options] = None) -> BatchResult:
+    def _check_site(self, batch: ProblemBatch):
         if batch.site is not self.site and (
             batch.site.Mg != self.site.Mg or batch.site.N != self.site.N or batch.site.cone != self.site.cone
             or batch.site.has_flat != self.site.has_flat or batch.site.has_max != self.site.has_max
         ):
             raise ValueError("batch was built for a different site than this handle")
-        o = options if options is not None else default_options()
+
+    def _marshal(self, batch: ProblemBatch, pinned: bool, x_dev=None):
+        """ctypes views of one batch: (_Problems, _Results, BatchResult, keep-alive list).  Arrays that already
+        are C-contiguous with the ABI's dtype are passed as they are (e.g. pinned arrays from ``pinned_empty``)."""
         B, N, Tm = batch.B, batch.N, batch.Tm
         arrs = dict(
             horizon=np.ascontiguousarray(batch.T, np.int32),
@@ -265,13 +311,15 @@ class SiteHandle:
         p = _Problems(B, Tm, batch.K, *[_ptr(arrs[k]) for k in
                                        ("horizon", "lb", "ub", "q", "pdiag", "s_off", "s_len", "s_cap", "s_eq")],
                       _ptr(peak), _ptr(lf), _ptr(dc), _ptr(dfl))
+        new = pinned_empty if pinned else (lambda shape, dtype=np.float64: np.zeros(shape, dtype))
         res = BatchResult(
-            np.zeros((B, N, Tm)), np.zeros(B, np.int32), np.zeros(B, np.int32),
-            np.zeros(B), np.zeros(B), np.zeros(B),
+            new((B, N, Tm)), new(B, np.int32), new(B, np.int32), new(B), new(B), new(B),
         )
-        r = _Results(_ptr(res.x), _ptr(res.status), _ptr(res.iters), _ptr(res.pri_res), _ptr(res.dua_res), _ptr(res.obj))
-        _check(self._lib.acnqp_solve_batch(self._h, C.byref(p), C.byref(o), C.byref(r)), "acnqp_solve_batch")
-        res.kernel_ms = float(self._lib.acnqp_last_kernel_ms(self._h))
+        r = _Results(_ptr(res.x), _ptr(res.status), _ptr(res.iters), _ptr(res.pri_res), _ptr(res.dua_res), _ptr(res.obj),
+                     None if x_dev is None else C.c_void_p(int(x_dev)))
+        return p, r, res, (arrs, peak, lf, dc, dfl)
+
+    def _finish(self, batch: ProblemBatch, res: "BatchResult"):
         if self.site.has_flat:   # the kernel's obj covers pdiag and q; add 1/2 lf sum_t (v' x_t)^2
             v = self.site.G[self.site.flat_row]
             res.obj = res.obj + 0.5 * batch.lf * np.einsum("n,bnt->bt", v, res.x).__pow__(2).sum(axis=1)
@@ -282,6 +330,52 @@ class SiteHandle:
         if batch.presolve_status is not None:
             res.status[batch.presolve_status != 0] = STATUS_EMPTY_SET
         return res
+
+    def solve(self, batch: ProblemBatch, options: Optional[Options] = None, pinned_results: bool = False) -> BatchResult:
+        """acnqp_solve_batch: one batch, host buffers in and out, synchronous (pipelined in chunks inside)."""
+        self._check_site(batch)
+        o = options if options is not None else default_options()
+        p, r, res, keep = self._marshal(batch, pinned_results)
+        _check(self._lib.acnqp_solve_batch(self._h, C.byref(p), C.byref(o), C.byref(r)), "acnqp_solve_batch")
+        del keep
+        res.kernel_ms = float(self._lib.acnqp_last_kernel_ms(self._h))
+        return self._finish(batch, res)
+
+    def solve_many(self, batches, options: Optional[Options] = None, pinned_results: bool = True):
+        """acnqp_solve_batches: several independent batches in ONE pipelined pass (shared launches, overlapped
+        copies).  Returns one BatchResult per batch."""
+        o = options if options is not None else default_options()
+        n = len(batches)
+        P, R = (_Problems * n)(), (_Results * n)()
+        results, keep = [], []
+        for g, batch in enumerate(batches):
+            self._check_site(batch)
+            P[g], R[g], res, k = self._marshal(batch, pinned_results)
+            results.append(res)
+            keep.append(k)
+        _check(self._lib.acnqp_solve_batches(self._h, n, P, C.byref(o), R), "acnqp_solve_batches")
+        del keep
+        return [self._finish(b, r) for b, r in zip(batches, results)]
+
+    def prepare_many(self, batches, pinned_results: bool = True, x_dev_ptrs=None):
+        """Marshal once, solve repeatedly (bench.py): returns a callable ``run(options)`` that re-submits the same
+        host buffers through acnqp_solve_batches and the list of BatchResults it fills.  ``x_dev_ptrs[g]``: optional
+        device address that also receives batch g's schedules (acnqp_results.x_dev)."""
+        n = len(batches)
+        P, R = (_Problems * n)(), (_Results * n)()
+        results, keep = [], []
+        for g, batch in enumerate(batches):
+            self._check_site(batch)
+            P[g], R[g], res, k = self._marshal(batch, pinned_results, None if x_dev_ptrs is None else x_dev_ptrs[g])
+            results.append(res)
+            keep.append(k)
+
+        def run(options: Options):
+            _check(self._lib.acnqp_solve_batches(self._h, n, P, C.byref(options), R), "acnqp_solve_batches")
+            return results
+
+        run.keep = keep
+        return run, results
 
     # -- device buffers (torch tensors or any object with data_ptr()) --------------
     def solve_device(self, dev: "DeviceBatch", options: Optional[Options] = None, stream: int = 0) -> None:
@@ -296,7 +390,7 @@ class SiteHandle:
             dev.dfloor.data_ptr() if self.site.has_max else None,
         )
         r = _Results(dev.x.data_ptr(), dev.status.data_ptr(), dev.iters.data_ptr(),
-                     dev.pri_res.data_ptr(), dev.dua_res.data_ptr(), dev.obj.data_ptr())
+                     dev.pri_res.data_ptr(), dev.dua_res.data_ptr(), dev.obj.data_ptr(), None)
         _check(
             self._lib.acnqp_solve_batch_device(self._h, C.byref(p), C.byref(o), C.byref(r), C.c_void_p(stream)),
             "acnqp_solve_batch_device",

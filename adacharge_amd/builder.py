@@ -223,8 +223,13 @@ def build_batch(
     peak_limits: Optional[Sequence] = None,
     prev_peak=0,
     site: Optional[SiteData] = None,
+    alloc=None,
 ) -> ProblemBatch:
-    """One structured QP per entry of ``session_lists`` (all on one site)."""
+    """One structured QP per entry of ``session_lists`` (all on one site).  ``alloc(shape, dtype)`` allocates the
+    arrays the C ABI reads (default ``np.zeros``; ``backend.pinned_empty`` puts them in pinned host memory so the
+    library copies them by DMA without a staging hop)."""
+    if alloc is None:
+        alloc = lambda shape, dtype=np.float64: np.zeros(shape, dtype)
     B = len(session_lists)
     N = len(infrastructure.station_ids)
     if peak_limits is None:
@@ -246,7 +251,8 @@ def build_batch(
         [(station_index[s.station_id], int(s.arrival_offset), int(s.remaining_time), s) for s in sl]
         for sl in session_lists
     ]
-    Ts = np.array([max(o + r for _, o, r, _ in rec) for rec in records], dtype=np.int32)  # aco.py:243-245
+    Ts = alloc(B, np.int32)
+    Ts[:] = [max(o + r for _, o, r, _ in rec) for rec in records]  # aco.py:243-245
     Tm = int(Ts.max())
     volt = np.asarray(infrastructure.voltages, float)
     period = interface.period
@@ -258,19 +264,23 @@ def build_batch(
         cnt = np.bincount([i for i, _, _, _ in rec], minlength=N)
         K = max(K, int(cnt.max()))
 
-    lb = np.zeros((B, N, Tm))
-    ub = np.zeros((B, N, Tm))
-    q = np.zeros((B, N, Tm))
-    pdiag = np.zeros(B)
-    lf = np.zeros(B)
+    lb = alloc((B, N, Tm), np.float64)
+    ub = alloc((B, N, Tm), np.float64)
+    q = alloc((B, N, Tm), np.float64)
+    pdiag = alloc(B, np.float64)
+    lf = alloc(B, np.float64)
     const = np.zeros(B)
-    dc = np.zeros(B)
-    dfloor = np.zeros(B)
-    s_off = np.zeros((B, K, N), dtype=np.int32)
-    s_len = np.zeros((B, K, N), dtype=np.int32)
-    s_cap = np.zeros((B, K, N))
-    s_eq = np.full(B, 1 if enforce_energy_equality else 0, dtype=np.uint8)
-    peak = np.full((B, Tm), np.inf) if site.has_peak else None
+    dc = alloc(B, np.float64)
+    dfloor = alloc(B, np.float64)
+    s_off = alloc((B, K, N), np.int32)
+    s_len = alloc((B, K, N), np.int32)
+    s_cap = alloc((B, K, N), np.float64)
+    s_eq = alloc(B, np.uint8)
+    s_eq[:] = 1 if enforce_energy_equality else 0
+    peak = None
+    if site.has_peak:
+        peak = alloc((B, Tm), np.float64)
+        peak[:] = np.inf
     presolve = np.zeros(B, dtype=np.int32)
     terms_by_horizon = {}   # the objective depends on the problem only through its horizon
 

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -115,9 +116,18 @@ struct acnqp_handle {
   static constexpr int kEvRing = 64;               // event pairs of the most recent launches
   hipEvent_t ev_start[kEvRing] = {}, ev_stop[kEvRing] = {};
   long long launches = 0, reported = 0;           // launches recorded / already handed out by acnqp_kernel_times
-  hipStream_t stream = nullptr;   // used by the host-buffer entry point
-  DevBuf in, out;                 // staging for the host-buffer entry point
-  DevBuf work;                    // workspace of the general-shape kernel
+  // host-buffer entry points: kSlots pipeline slots, each with its own stream and device staging, so that the
+  // H2D copies, the kernel and the D2H copies of successive chunks of a call overlap
+  static constexpr int kSlots = 4;
+  struct Slot { hipStream_t st = nullptr; DevBuf in, out; } slot[kSlots];
+  // workspaces of the general-shape kernel, one per launch stream: launches on different streams never share
+  // (or regrow) each other's state, and a stream's own launches are ordered by the stream
+  std::vector<std::pair<hipStream_t, DevBuf>> work;
+  DevBuf* workspace_for(hipStream_t st) {
+    for (auto& w : work) if (w.first == st) return &w.second;
+    work.emplace_back(st, DevBuf());
+    return &work.back().second;
+  }
 };
 
 namespace {
@@ -374,7 +384,8 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
     e = hipEventCreate(&h->ev_start[k]);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_stop[k]);
   }
-  if (e == hipSuccess) e = hipStreamCreate(&h->stream);
+  for (int k = 0; k < acnqp_handle::kSlots && e == hipSuccess; ++k)
+    e = hipStreamCreateWithFlags(&h->slot[k].st, hipStreamNonBlocking);
   if (e != hipSuccess) {
     std::string msg = std::string("acnqp_create: ") + hipGetErrorString(e);
     acnqp_destroy(h);
@@ -395,11 +406,18 @@ void acnqp_destroy(acnqp_handle* h) {
     if (h->ev_start[k]) (void)hipEventDestroy(h->ev_start[k]);
     if (h->ev_stop[k]) (void)hipEventDestroy(h->ev_stop[k]);
   }
-  if (h->stream) (void)hipStreamDestroy(h->stream);
-  h->in.release();
-  h->out.release();
-  h->work.release();
+  for (auto& sl : h->slot) {
+    if (sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
+    sl.in.release();
+    sl.out.release();
+  }
+  for (auto& w : h->work) w.second.release();
   delete h;
+}
+
+// shapes the register-resident tiled kernel takes; everything else runs through the general-shape kernel
+static bool tiled_shape(const acnqp_handle* h, int t_max, int k_sessions) {
+  return h->N <= 64 && t_max <= 32 && k_sessions <= acnqp::kMaxK;
 }
 
 static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, const acnqp_options* o,
@@ -409,8 +427,8 @@ static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, 
   if (p->batch == 0) return ACNQP_OK;
   if (p->t_max < 1 || p->t_max > 4096)
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: t_max must be in [1, 4096]");
-  if (p->k_sessions < 1 || p->k_sessions > acnqp::kMaxK)
-    return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: k_sessions must be in [1, 4]");
+  if (p->k_sessions < 1 || p->k_sessions > 4096)
+    return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: k_sessions must be in [1, 4096]");
   if (!p->horizon || !p->lb || !p->ub || !p->q || !p->pdiag || !p->s_off || !p->s_len || !p->s_cap || !p->s_eq)
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: null problem array");
   if (h->has_peak && !p->peak) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: site has a peak row but peak is null");
@@ -457,7 +475,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.max_iter = o->max_iter; a.check_every = o->check_every; a.adapt_every = o->adapt_every;
   a.peak_scale = d->peak_scale; a.flat_scale = d->flat_scale; a.max_scale = d->max_scale;
   a.accel_mem = std::max(0, o->accel_mem);
-  const bool tiled = h->N <= 64 && p->t_max <= 32;
+  const bool tiled = tiled_shape(h, p->t_max, p->k_sessions);
   acnqp::GeneralArgs ga;
   if (!tiled) {
     // general-shape fallback: state streamed through a global workspace (not graph-capturable: it may allocate)
@@ -467,12 +485,17 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     const long long Dn = n + mt;
     // solver state, the certificate's dual snapshot, the Anderson vectors (u, f: reals; correction and rings: floats)
     ga.ws_per_problem = 7 * n + 8 * mt + 3LL * p->k_sessions * h->N + 8 + 2 * Dn + ((1 + 2LL * gm) * Dn * 4 + (long long)rsz - 1) / (long long)rsz + 2;
-    HIP_TRY(h->work.reserve((size_t)ga.ws_per_problem * p->batch * rsz));
-    ga.work = h->work.p;
+    DevBuf* wsb = h->workspace_for(st);
+    const size_t need = (size_t)ga.ws_per_problem * p->batch * rsz;
+    if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));   // an earlier launch on this stream may still use the old buffer
+    HIP_TRY(wsb->reserve(need));
+    ga.work = wsb->p;
     ga.pair_stride = o->precision == 32 ? 1 : 4;
     ga.t = a;
   }
   (void)hipGetLastError();   // drop any stale error so the check below reports this launch only
+  // a problem whose workgroup never ran must not look solved (or carry the previous call's status)
+  HIP_TRY(hipMemsetAsync(r->status, 0, (size_t)p->batch * sizeof(int32_t), st));
   const int evk = (int)(h->launches % acnqp_handle::kEvRing);
   HIP_TRY(hipEventRecord(h->ev_start[evk], st));
   hipError_t e = hipSuccess;
@@ -499,7 +522,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
 
 int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, int32_t precision, int32_t requested) {
   if (!h || t_max < 1 || k_sessions < 1 || requested <= 0) return 0;
-  if (!(h->N <= 64 && t_max <= 32)) return std::min(requested, acnqp::kGenAccelMax);   // general-shape kernel: ring in its workspace
+  if (!tiled_shape(h, t_max, k_sessions)) return std::min(requested, acnqp::kGenAccelMax);   // general-shape kernel: ring in its workspace
   SiteDev* d = &h->dev64;
   if (precision == 32) {
     d = &h->dev32;
@@ -534,85 +557,189 @@ int32_t acnqp_kernel_times(acnqp_handle* h, float* out_ms, int32_t capacity) {
   return n;
 }
 
-int acnqp_solve_batch(acnqp_handle* h, const acnqp_problems* p, const acnqp_options* o, acnqp_results* r) {
-  int rc = check_problem_shapes(h, p, o, r);
-  if (rc != ACNQP_OK) return rc;
-  if (p->batch == 0) return ACNQP_OK;
-  HIP_TRY(hipSetDevice(h->device));
-  const size_t B = p->batch, N = h->N, Tm = p->t_max, K = p->k_sessions;
-  const size_t nv = B * N * Tm, ns = B * K * N;
-  // one staging allocation for inputs, one for outputs; 256-byte aligned slices
-  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  size_t off = 0;
-  const size_t o_lb = off; off += al(nv * 8);
-  const size_t o_ub = off; off += al(nv * 8);
-  const size_t o_q = off; off += al(nv * 8);
-  const size_t o_pd = off; off += al(B * 8);
-  const size_t o_hz = off; off += al(B * 4);
-  const size_t o_so = off; off += al(ns * 4);
-  const size_t o_sl = off; off += al(ns * 4);
-  const size_t o_sc = off; off += al(ns * 8);
-  const size_t o_eq = off; off += al(B);
-  const size_t o_pk = off; off += al(p->peak ? B * Tm * 8 : 0);
-  const size_t o_lf = off; off += al(p->lf ? B * 8 : 0);
-  const size_t o_dc = off; off += al(p->dc ? B * 8 : 0);
-  const size_t o_df = off; off += al(p->dfloor ? B * 8 : 0);
-  HIP_TRY(h->in.reserve(off));
-  size_t ooff = 0;
-  const size_t r_x = ooff; ooff += al(nv * 8);
-  const size_t r_st = ooff; ooff += al(B * 4);
-  const size_t r_it = ooff; ooff += al(B * 4);
-  const size_t r_pr = ooff; ooff += al(B * 8);
-  const size_t r_du = ooff; ooff += al(B * 8);
-  const size_t r_ob = ooff; ooff += al(B * 8);
-  HIP_TRY(h->out.reserve(ooff));
-  char* di = static_cast<char*>(h->in.p);
-  char* dout = static_cast<char*>(h->out.p);
-  hipStream_t st = h->stream;
-  HIP_TRY(hipMemcpyAsync(di + o_lb, p->lb, nv * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(di + o_ub, p->ub, nv * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(di + o_q, p->q, nv * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(di + o_pd, p->pdiag, B * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(di + o_hz, p->horizon, B * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(di + o_so, p->s_off, ns * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(di + o_sl, p->s_len, ns * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(di + o_sc, p->s_cap, ns * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(di + o_eq, p->s_eq, B, hipMemcpyHostToDevice, st));
-  if (p->peak) HIP_TRY(hipMemcpyAsync(di + o_pk, p->peak, B * Tm * 8, hipMemcpyHostToDevice, st));
-  if (p->lf) HIP_TRY(hipMemcpyAsync(di + o_lf, p->lf, B * 8, hipMemcpyHostToDevice, st));
-  if (p->dc) HIP_TRY(hipMemcpyAsync(di + o_dc, p->dc, B * 8, hipMemcpyHostToDevice, st));
-  if (p->dfloor) HIP_TRY(hipMemcpyAsync(di + o_df, p->dfloor, B * 8, hipMemcpyHostToDevice, st));
-  acnqp_problems dp = *p;
-  dp.lb = reinterpret_cast<const double*>(di + o_lb);
-  dp.ub = reinterpret_cast<const double*>(di + o_ub);
-  dp.q = reinterpret_cast<const double*>(di + o_q);
-  dp.pdiag = reinterpret_cast<const double*>(di + o_pd);
-  dp.horizon = reinterpret_cast<const int32_t*>(di + o_hz);
-  dp.s_off = reinterpret_cast<const int32_t*>(di + o_so);
-  dp.s_len = reinterpret_cast<const int32_t*>(di + o_sl);
-  dp.s_cap = reinterpret_cast<const double*>(di + o_sc);
-  dp.s_eq = reinterpret_cast<const uint8_t*>(di + o_eq);
-  dp.peak = p->peak ? reinterpret_cast<const double*>(di + o_pk) : nullptr;
-  dp.lf = p->lf ? reinterpret_cast<const double*>(di + o_lf) : nullptr;
-  dp.dc = p->dc ? reinterpret_cast<const double*>(di + o_dc) : nullptr;
-  dp.dfloor = p->dfloor ? reinterpret_cast<const double*>(di + o_df) : nullptr;
-  acnqp_results dr;
-  dr.x = reinterpret_cast<double*>(dout + r_x);
-  dr.status = reinterpret_cast<int32_t*>(dout + r_st);
-  dr.iters = reinterpret_cast<int32_t*>(dout + r_it);
-  dr.pri_res = reinterpret_cast<double*>(dout + r_pr);
-  dr.dua_res = reinterpret_cast<double*>(dout + r_du);
-  dr.obj = reinterpret_cast<double*>(dout + r_ob);
-  rc = acnqp_solve_batch_device(h, &dp, o, &dr, st);
-  if (rc != ACNQP_OK) return rc;
-  HIP_TRY(hipMemcpyAsync(r->x, dr.x, nv * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(r->status, dr.status, B * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(r->iters, dr.iters, B * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(r->pri_res, dr.pri_res, B * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(r->dua_res, dr.dua_res, B * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(r->obj, dr.obj, B * 8, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+// ---- host-buffer entry points ------------------------------------------------------------------------
+namespace {
+
+struct Piece { int g; long long lo, n, pos; };   // problems [lo, lo + n) of batch g sit at [pos, pos + n) of their chunk
+
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// device layout of one chunk of `cn` problems (inputs in slot.in, results in slot.out)
+struct ChunkLayout {
+  size_t lb, ub, q, pd, hz, so, sl, sc, eq, pk, lf, dc, df, in_total;
+  size_t x, st, it, pr, du, ob, out_total;
+  ChunkLayout(size_t cn, size_t N, size_t Tm, size_t K, bool peak, bool flat, bool mx) {
+    size_t o = 0;
+    lb = o; o += al256(cn * N * Tm * 8);
+    ub = o; o += al256(cn * N * Tm * 8);
+    q = o;  o += al256(cn * N * Tm * 8);
+    pd = o; o += al256(cn * 8);
+    hz = o; o += al256(cn * 4);
+    so = o; o += al256(cn * K * N * 4);
+    sl = o; o += al256(cn * K * N * 4);
+    sc = o; o += al256(cn * K * N * 8);
+    eq = o; o += al256(cn);
+    pk = o; o += al256(peak ? cn * Tm * 8 : 0);
+    lf = o; o += al256(flat ? cn * 8 : 0);
+    dc = o; o += al256(mx ? cn * 8 : 0);
+    df = o; o += al256(mx ? cn * 8 : 0);
+    in_total = o;
+    o = 0;
+    x = o;  o += al256(cn * N * Tm * 8);
+    st = o; o += al256(cn * 4);
+    it = o; o += al256(cn * 4);
+    pr = o; o += al256(cn * 8);
+    du = o; o += al256(cn * 8);
+    ob = o; o += al256(cn * 8);
+    out_total = o;
+  }
+};
+
+long long chunk_problems(size_t per_problem_bytes) {
+  long long want = 2048;   // problems per launch: large enough that the launch tail (its slowest problems) is short
+  if (const char* e = std::getenv("ACNQP_CHUNK")) { const long long v = std::atoll(e); if (v > 0) want = v; }
+  const long long by_mem = (long long)((size_t)512 * 1024 * 1024 / std::max<size_t>(per_problem_bytes, 1));
+  return std::max<long long>(1, std::min(want, by_mem));
+}
+
+int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_options* o, acnqp_results* R) {
+  const size_t N = h->N;
+  const bool peak = h->has_peak, flat = h->has_flat, mx = h->has_max;
+  // chunks: consecutive batches of one shape (t_max, k_sessions) share launches of up to chunk_problems() problems
+  std::vector<std::vector<Piece>> chunks;
+  long long fill = 0, cap = 0;
+  int cur_T = -1, cur_K = -1;
+  for (int g = 0; g < nb; ++g) {
+    const long long B = P[g].batch;
+    if (B == 0) continue;
+    const size_t Tm = P[g].t_max, K = P[g].k_sessions;
+    for (long long lo = 0; lo < B;) {
+      if (chunks.empty() || (int)Tm != cur_T || (int)K != cur_K || fill >= cap) {
+        chunks.emplace_back();
+        cur_T = (int)Tm; cur_K = (int)K; fill = 0;
+        cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96);
+      }
+      const long long n = std::min(B - lo, cap - fill);
+      chunks.back().push_back({g, lo, n, fill});
+      fill += n; lo += n;
+    }
+  }
+  for (size_t c = 0; c < chunks.size(); ++c) {
+    acnqp_handle::Slot& S = h->slot[c % acnqp_handle::kSlots];
+    const std::vector<Piece>& pcs = chunks[c];
+    const size_t cn = (size_t)(pcs.back().pos + pcs.back().n);
+    const size_t Tm = P[pcs[0].g].t_max, K = P[pcs[0].g].k_sessions;
+    const ChunkLayout L(cn, N, Tm, K, peak, flat, mx);
+    if (L.in_total > S.in.cap || L.out_total > S.out.cap) HIP_TRY(hipStreamSynchronize(S.st));   // staging still in use
+    HIP_TRY(S.in.reserve(L.in_total));
+    HIP_TRY(S.out.reserve(L.out_total));
+    char* di = static_cast<char*>(S.in.p);
+    char* dq = static_cast<char*>(S.out.p);
+    for (const Piece& pc : pcs) {
+      const acnqp_problems& p = P[pc.g];
+      const size_t lo = (size_t)pc.lo, n = (size_t)pc.n, pos = (size_t)pc.pos;
+      const size_t nv = N * Tm, ns = K * N;
+#define H2D(field, base, elem, per)                                                                             \
+  HIP_TRY(hipMemcpyAsync(di + (base) + pos * (per) * (elem), reinterpret_cast<const char*>(p.field) + lo * (per) * (elem), \
+                         n * (per) * (elem), hipMemcpyHostToDevice, S.st))
+      H2D(lb, L.lb, 8, nv);
+      H2D(ub, L.ub, 8, nv);
+      H2D(q, L.q, 8, nv);
+      H2D(pdiag, L.pd, 8, 1);
+      H2D(horizon, L.hz, 4, 1);
+      H2D(s_off, L.so, 4, ns);
+      H2D(s_len, L.sl, 4, ns);
+      H2D(s_cap, L.sc, 8, ns);
+      H2D(s_eq, L.eq, 1, 1);
+      if (peak) H2D(peak, L.pk, 8, Tm);
+      if (flat) H2D(lf, L.lf, 8, 1);
+      if (mx) { H2D(dc, L.dc, 8, 1); H2D(dfloor, L.df, 8, 1); }
+#undef H2D
+    }
+    acnqp_problems dp;
+    dp.batch = (int32_t)cn; dp.t_max = (int32_t)Tm; dp.k_sessions = (int32_t)K;
+    dp.lb = reinterpret_cast<const double*>(di + L.lb);
+    dp.ub = reinterpret_cast<const double*>(di + L.ub);
+    dp.q = reinterpret_cast<const double*>(di + L.q);
+    dp.pdiag = reinterpret_cast<const double*>(di + L.pd);
+    dp.horizon = reinterpret_cast<const int32_t*>(di + L.hz);
+    dp.s_off = reinterpret_cast<const int32_t*>(di + L.so);
+    dp.s_len = reinterpret_cast<const int32_t*>(di + L.sl);
+    dp.s_cap = reinterpret_cast<const double*>(di + L.sc);
+    dp.s_eq = reinterpret_cast<const uint8_t*>(di + L.eq);
+    dp.peak = peak ? reinterpret_cast<const double*>(di + L.pk) : nullptr;
+    dp.lf = flat ? reinterpret_cast<const double*>(di + L.lf) : nullptr;
+    dp.dc = mx ? reinterpret_cast<const double*>(di + L.dc) : nullptr;
+    dp.dfloor = mx ? reinterpret_cast<const double*>(di + L.df) : nullptr;
+    acnqp_results dr;
+    dr.x = reinterpret_cast<double*>(dq + L.x);
+    dr.status = reinterpret_cast<int32_t*>(dq + L.st);
+    dr.iters = reinterpret_cast<int32_t*>(dq + L.it);
+    dr.pri_res = reinterpret_cast<double*>(dq + L.pr);
+    dr.dua_res = reinterpret_cast<double*>(dq + L.du);
+    dr.obj = reinterpret_cast<double*>(dq + L.ob);
+    dr.x_dev = nullptr;
+    const int rc = acnqp_solve_batch_device(h, &dp, o, &dr, S.st);
+    if (rc != ACNQP_OK) return rc;
+    for (const Piece& pc : pcs) {
+      const acnqp_results& r = R[pc.g];
+      const size_t lo = (size_t)pc.lo, n = (size_t)pc.n, pos = (size_t)pc.pos;
+#define D2H(field, base, elem, per)                                                                          \
+  HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(r.field) + lo * (per) * (elem), dq + (base) + pos * (per) * (elem), \
+                         n * (per) * (elem), hipMemcpyDeviceToHost, S.st))
+      D2H(x, L.x, 8, N * Tm);
+      D2H(status, L.st, 4, 1);
+      D2H(iters, L.it, 4, 1);
+      D2H(pri_res, L.pr, 8, 1);
+      D2H(dua_res, L.du, 8, 1);
+      D2H(obj, L.ob, 8, 1);
+#undef D2H
+      if (r.x_dev)
+        HIP_TRY(hipMemcpyAsync(r.x_dev + lo * N * Tm, dq + L.x + pos * N * Tm * 8, n * N * Tm * 8, hipMemcpyDeviceToDevice, S.st));
+    }
+  }
   return ACNQP_OK;
+}
+
+}  // namespace
+
+int acnqp_solve_batches(acnqp_handle* h, int32_t n_batches, const acnqp_problems* p, const acnqp_options* o, acnqp_results* r) {
+  if (!h || !p || !o || !r || n_batches < 0) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batches: null argument or negative count");
+  for (int g = 0; g < n_batches; ++g) {
+    const int rc = check_problem_shapes(h, p + g, o, r + g);
+    if (rc != ACNQP_OK) return rc;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const int rc = run_pipeline(h, n_batches, p, o, r);
+  // drain every slot before returning, also on failure: nothing may touch the caller's buffers afterwards
+  hipError_t e = hipSuccess;
+  for (auto& sl : h->slot) { const hipError_t e1 = hipStreamSynchronize(sl.st); if (e == hipSuccess) e = e1; }
+  if (rc != ACNQP_OK) return rc;
+  if (e != hipSuccess) return fail(ACNQP_ERR_HIP, std::string("acnqp_solve_batches: ") + hipGetErrorString(e));
+  for (int g = 0; g < n_batches; ++g)
+    for (int b = 0; b < p[g].batch; ++b)
+      if (r[g].status[b] == ACNQP_STATUS_UNSET)
+        return fail(ACNQP_ERR_HIP, "acnqp_solve_batches: batch " + std::to_string(g) + " problem " + std::to_string(b) +
+                                   " was never written by the kernel (status UNSET after synchronisation): the launch did not execute completely");
+  return ACNQP_OK;
+}
+
+int acnqp_solve_batch(acnqp_handle* h, const acnqp_problems* p, const acnqp_options* o, acnqp_results* r) {
+  return acnqp_solve_batches(h, 1, p, o, r);
+}
+
+void* acnqp_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    g_last_error = "acnqp_host_alloc: hipHostMalloc failed";
+    return nullptr;
+  }
+  return p;
+}
+
+void acnqp_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 #ifdef ACNQP_STAMPS

@@ -1,10 +1,10 @@
-// General-shape fallback of the batched MPC QP solver: any horizon, N <= 256, state streamed
+// General-shape fallback of the batched MPC QP solver: any horizon, N <= 1024, state streamed
 // through a per-problem global-memory workspace (L2 resident) instead of registers.
 //
 // Same ADMM as acn_qp_tiled.hpp (see there for the algorithm); this kernel trades speed for
 // generality so that the reference's large scenarios (N = 54, T = 144 stress tests, t_aco.py:286-466,
-// and the offline algorithm, adacharge.py:196-294) run through the same C ABI.  One 256-thread
-// workgroup per problem; plain loops; one thread per session for the water-filling.
+// and the offline algorithm, adacharge.py:196-294) run through the same C ABI.  One workgroup of 256 / 512 /
+// 1024 threads per problem (by size, acn_qp_api.hip); plain loops; one thread per session for the water-filling.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -118,8 +118,9 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   const real ubmax = block_reduce_max<real, kGenThreads>(um, red, tid);
   const real anybad = block_reduce_max<real, kGenThreads>(bad, red, tid);
   const real pd_user = (real)A.pdiag[b];
-  real pd = pd_user;
-  if (ubmax > 0) pd = fmax(pd_user, (real)A.reg_rel * qnorm / (ubmax * (real)max(1, A.horizon[b])));
+  const bool dc_on = A.dc != nullptr && (real)A.dc[b] > (real)0;   // block-uniform
+  const real pd = effective_pdiag<real>(pd_user, (real)A.reg_rel, qnorm, ubmax, A.horizon[b],
+                                        (A.lf != nullptr && (real)A.lf[b] > (real)0) || dc_on);
   if (anybad > 0) {
     for (int k = tid; k < n; k += kGenThreads) A.x[(size_t)b * n + k] = 0;
     if (tid == 0) { A.status[b] = 4; A.iters[b] = 0; A.pri[b] = (double)M::big; A.dua[b] = (double)M::big; A.obj[b] = 0; }
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
     for (int k = tid; k < mt; k += kGenThreads) {
       const int r = k / T, t = k - r * T;
       const int ty = A.rowtype[r];
+      if (ty == kRowMax && dc_on) continue;   // written by wave 0 below, and by nobody else (no write-write race)
       real zn = zh2[k];
       if (ty == kRowBox) zn = fmin(zn, RL[r]);
       else if (ty == kRowQuad) zn = zn * (rho / (rho + (A.lf ? (real)(A.lf[b] / (A.flat_scale * A.flat_scale)) : (real)0)));
@@ -361,25 +363,29 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
       y2[k] = rho * (zh2[k] - zn);
       z2[k] = zn;
     }
-    // demand charge: horizon-wide prox on the "max" row, one thread (the general kernel favours clarity)
-    if (A.dc != nullptr && (real)A.dc[b] > (real)0 && tid == 0) {
+    // demand charge: horizon-wide prox on the "max" row (see acn_qp_tiled.hpp), by wave 0 alone: lanes stride over
+    // the periods, the reductions leave identical values in every lane, so the Newton iteration is wave-uniform.
+    // The strided loop above skips this row, so these are the only writes to its y2 / z2 entries.
+    if (dc_on && tid < 64) {
       for (int r = 0; r < MR; ++r)
         if (A.rowtype[r] == kRowMax) {
           const real cw = (real)(A.dc[b] / A.max_scale) * inv_rho, fl = A.dfloor ? (real)(A.dfloor[b] * A.max_scale) : (real)0;
           const real* zv = zh2 + r * T;
-          real vmax = -M::big;
-          for (int t = 0; t < T; ++t) vmax = fmax(vmax, zv[t]);
+          real vl = -M::big;
+          for (int t = tid; t < T; t += 64) vl = fmax(vl, zv[t]);
+          const real vmax = wave_max<real>(vl);
           real tau = vmax - cw;
           for (int guard = 0; guard < 200; ++guard) {
-            real S = 0, nn = 0;
-            for (int t = 0; t < T; ++t) if (zv[t] > tau) { S += zv[t] - tau; nn += 1; }
+            real Sl = 0, nl = 0;
+            for (int t = tid; t < T; t += 64) if (zv[t] > tau) { Sl += zv[t] - tau; nl += 1; }
+            const real S = wave_sum<real>(Sl), nn = wave_sum<real>(nl);
             const real f = S - cw;
             const real tn = nn > 0 ? tau + f / nn : vmax - cw;
             if (fabs(f) <= M::proj_tol * fmax((real)1, cw) * (real)16 || tn == tau) break;
             tau = tn;
           }
           const real lev = fmax(tau, fl);
-          for (int t = 0; t < T; ++t) {
+          for (int t = tid; t < T; t += 64) {
             const real zn = fmin(zv[t], lev);
             y2[r * T + t] = rho * (zv[t] - zn);
             z2[r * T + t] = zn;

@@ -192,6 +192,17 @@ struct TiledLds {
 
 // Anderson acceleration of the ADMM fixed-point map (restated in oracle/admm_port.c, see there)
 constexpr double kStartGain = 1e5;
+// Tikhonov floor (options.reg_rel) -- applied ONLY to problems whose own objective cannot select a unique point:
+// no prox row in use (load_flattening / demand_charge weights zero) and a quadratic the solver cannot resolve,
+// pdiag * max(ub) <= kRegResolve * |q|_inf (pure LPs; the reference's equal_share * 1e-12).  A strictly convex
+// problem is solved exactly as stated (the reference passes no solver options, aco.py:315-321).
+constexpr double kRegResolve = 1e-6;
+template <typename real>
+__host__ __device__ inline real effective_pdiag(real pd_user, real reg_rel, real qnorm, real ubmax, int horizon, bool has_prox) {
+  if (has_prox || !(ubmax > (real)0) || pd_user * ubmax > (real)kRegResolve * qnorm) return pd_user;
+  const real fl = reg_rel * qnorm / (ubmax * (real)(horizon > 1 ? horizon : 1));
+  return fl > pd_user ? fl : pd_user;
+}
 constexpr double kInaccurate = 100.0;   // max_iter with residuals within this factor of tolerance: SOLVED_INACCURATE
 constexpr double kAdaptWiden = 8.0;   // rho adaptation band: adapt_tol (1 + adaptations / kAdaptWiden): no limit cycles
 constexpr int kAaPeriod = 5;
@@ -343,13 +354,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
       if (sub[c][tt] < slb[c][tt]) sub[c][tt] = slb[c][tt];
     }
   unsigned swm[KS];            // bit (4 c + tt): that period lies in slot k's window
-  bool shas[KS];
-  int smode[KS];               // 0: root-find each iteration, 2: pinned at ub, 3: pinned at lb
+  int smode[KS];               // 0: root-find each iteration, 2: pinned at ub, 3: pinned at lb, 4: no session in this slot
   real scap[KS], mu[KS];
   bool empty_set = false;
 #pragma unroll
   for (int k = 0; k < KS; ++k) {
-    swm[k] = 0; shas[k] = false; smode[k] = 0; scap[k] = 0; mu[k] = 0;
+    swm[k] = 0; smode[k] = 4; scap[k] = 0; mu[k] = 0;
     if (k < A.K) {   // block-uniform
       const size_t sidx = ((size_t)b * A.K + k) * N + (sact ? sev : 0);
       const int off = sact ? A.s_off[sidx] : 0;
@@ -365,8 +375,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
       sl = quarter_sum<real>(sl);
       su = quarter_sum<real>(su);
       scap[k] = sact ? (real)A.s_cap[sidx] : (real)0;
-      shas[k] = len > 0;
-      if (shas[k]) {
+      if (len > 0) {
+        smode[k] = 0;
         const real slack = (real)64 * M::proj_tol * fmax((real)1, fabs(scap[k]));
         if (sl > scap[k] + slack) empty_set = true;
         if (eq && su < scap[k] - slack) empty_set = true;
@@ -395,9 +405,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
       for (int r = 0; r < 4; ++r) { f[1] = fmax(f[1], fabs(qv[c][r])); f[2] = fmax(f[2], ubv[c][r]); }
     block_max<real, 3>(f, Red, lane, wave, NW);
     qnorm = f[1];
-    pd = pd_user;
-    // scale-free Tikhonov floor: reg_rel * |q|_inf / (max(ub) * T_b)
-    if (f[2] > 0) pd = fmax(pd_user, (real)A.reg_rel * qnorm / (f[2] * (real)max(1, A.horizon[b])));
+    // scale-free Tikhonov floor reg_rel * |q|_inf / (max(ub) * T_b), LP-like problems only (effective_pdiag)
+    pd = effective_pdiag<real>(pd_user, (real)A.reg_rel, qnorm, f[2], A.horizon[b], lfb > (real)0 || dcb > (real)0);
     if (f[0] > 0) {   // a session cannot meet its energy row inside its own bounds
 #pragma unroll
       for (int c = 0; c < CT; ++c)
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #if defined(ACNQP_ABL) && ACNQP_ABL == 1
           bool need = false;
 #else
-          bool need = shas[k] && smode[k] == 0;
+          bool need = smode[k] == 0;
 #endif
           real m = mu[k];
           real lo = eq ? -M::big : (real)-1;   // inequality: m >= 0, so (-1, .) brackets m = 0
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           };
           newton_pass();                       // peeled: straight-line with the site-row update above
           while (__any(need)) newton_pass();   // rare: the active set of some session changed
-          if (shas[k] && smode[k] == 0) mu[k] = m;
+          if (smode[k] == 0) mu[k] = m;
 #pragma unroll
           for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -590,7 +599,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
               if ((swm[k] >> (4 * c + tt)) & 1u) {
                 if (smode[k] == 0) sz[c][tt] = fmin(fmax(szh[c][tt] - m, slb[c][tt]), sub[c][tt]);
                 else if (smode[k] == 2) sz[c][tt] = sub[c][tt];
-                else sz[c][tt] = slb[c][tt];
+                else if (smode[k] == 3) sz[c][tt] = slb[c][tt];
               }
         }
       }
@@ -670,6 +679,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   while (!done) {
     ++it;
     real* Pw = Pbuf + (size_t)(it & 1) * NW * MT * CT * 256;
+    // Per-lane constants every predicate of the loop body derives from (row types, session windows, modes) are made
+    // opaque once per iteration: the compiler then evaluates `rtype == kRowBox`, `(swm >> k) & 1` ... where they are
+    // used (one v_cmp each) instead of hoisting dozens of loop-invariant lane masks into SGPR pairs, which it can
+    // only keep by spilling them to VGPR lanes (100-450 SGPR spills per instantiation before this).
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(rtype[m][r]));
+#pragma unroll
+    for (int k = 0; k < KS; ++k) { asm volatile("" : "+v"(swm[k])); asm volatile("" : "+v"(smode[k])); }
     // an offset the compiler cannot see through keeps the fragment loads inside the loop (the base pointers stay
     // kernel arguments, i.e. provably global memory: global_load, not flat_load)
     unsigned frag_off = (unsigned)__builtin_amdgcn_readfirstlane(wave) * (MT * 2 * 4 * 64), zero_off = 0;
@@ -1188,7 +1207,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
                 ph = quarter_sum<real>(ph) + l_ * scap[k];
                 best = fmin(best, ph);
               }
-              if (shas[k] && sh == 0) ssum += best;   // one lane per session
+              if (smode[k] != 4 && sh == 0) ssum += best;   // one lane per session
             }
           }
           // periods outside every window are pinned to lb = ub (= 0): support lb * v
@@ -1270,12 +1289,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 
   // ---- results: the feasible iterate z1 is the schedule ------------------------------------
   real ol = 0;
+  int lane_o = lane;   // opaque copy: the store predicates are evaluated here, not kept alive across the loop
+  asm volatile("" : "+v"(lane_o));
+  const int g_o = lane_o >> 4, t_o = lane_o & 15;
 #pragma unroll
   for (int c = 0; c < CT; ++c)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int tt = 16 * c + t, ev = 16 * wave + M::rowof(g, r);
-      if (evact[r] && tt < Tm) {
+      const int tt = 16 * c + t_o, ev = 16 * wave + M::rowof(g_o, r);
+      if (ev < N && tt < Tm) {
         A.x[((size_t)b * N + ev) * Tm + tt] = (double)z1[c][r];
         ol += ((real)0.5 * pd_user * z1[c][r] + qv[c][r]) * z1[c][r];
       }

@@ -1,81 +1,57 @@
 #!/usr/bin/env python3
-"""Headline benchmark: MPC QP solves/sec, 54 EVSE x horizon 12 (BASELINE.json).
+"""Headline benchmark: MPC QP solves/sec, 54 EVSE x horizon 12 (BASELINE.json), END TO END.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path (acnqp_solve_batch_device: one kernel
-launch) over one batch of 256 independent MPC state snapshots per GPU, inputs
-already resident in HBM.  Workload = BASELINE.json configs[1]: Caltech-shaped
-54-EVSE network, horizon 12, quick_charge (+ equal_share*1e-12, the reference's
-own integration-test objective, t_int.py:67-70), the reference's default SOC
-constraints (aco.py:35), fp64 ADMM, batch 256 per GPU (weak scaling: every rank
-gets its own 256 snapshots; for N > 1 each step ends with one RCCL all-gather of
-the schedules so every rank holds the whole job's result).  `--pipeline D`
-(default 8) keeps D such batches in flight per GPU, each on its own stream: a
-launch lasts as long as its slowest problem, so the next batches' workgroups
-move into the CUs the finished problems have left.
+Workload = BASELINE.json configs[1]: Caltech-shaped 54-EVSE network, horizon 12, quick_charge
+(+ equal_share*1e-12, the reference's own integration-test objective, t_int.py:67-70), the reference's
+default SOC constraints (aco.py:35), fp64 ADMM, batches of 256 independent MPC state snapshots.
 
-Prints ONE JSON line on rank 0 (see the contract in the task statement), with
-`roofline` (HBM algorithmic bytes / measured kernel time) and `cpu_baseline`
-(oracle/admm_port.c, the scalar C port of the same ADMM, on all host cores over
-a bounded sample; N = 1 only).
+One "step" = ONE call of the product entry point `acnqp_solve_batches` over `--batches` (default 64) such
+batches per GPU, i.e. 16,384 problems per GPU per step, from pinned HOST buffers to pinned HOST buffers:
+H2D of every problem array + kernels + D2H of schedules, statuses, iterations, residuals and objectives,
+all inside the timed region (the metric SURVEY.md section 8d defines; `acnqp_create` -- the one-time site
+upload -- is outside).  The library pipelines the call internally (chunks of 2,048 problems rotate over
+four streams with their own device staging), so there is nothing for the bench to overlap by hand and
+`value` is what any caller of the API gets.  Weak scaling: every rank owns its own 64 x 256 snapshots.
+For N > 1 each step leaves the rank's schedules in HBM as well (acnqp_results.x_dev) and ends with the
+job's single collective, one RCCL all-gather of the schedules over xGMI, overlapped with the next step's
+solve; the timed region ends when every gather has landed.
+
+Prints ONE JSON line on rank 0 with `roofline` (algorithmic HBM bytes of one launch / its HIP-event
+duration), `cpu_baseline` (oracle/admm_port.c on the host cores, bounded sample, N = 1 only) and the
+kernel-only rate of the same step (`kernel_only`).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-# Batches are kept in flight on separate HIP streams (--pipeline); the runtime multiplexes streams onto
-# 4 hardware queues by default, and two streams that share a queue run back to back.  Must be set before
-# the HIP runtime initialises (i.e. before torch is imported).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6     # vector fp64 (vendor figure)
+CHUNK_PROBLEMS = 2048        # problems per kernel launch inside acnqp_solve_batches (acn_qp_api.hip, chunk_problems)
 
 
-def new_stream(dev):
-    """A fresh HIP stream (hipStreamCreateWithFlags, non-blocking) wrapped for torch.  torch's own stream
-    pool is created 64 streams at a time and shares the hardware queues among them in an order the caller
-    cannot see; streams created here, one per batch in flight and before that pool exists, each get a
-    hardware queue of their own as long as GPU_MAX_HW_QUEUES allows."""
-    import ctypes
-
-    import torch
-
-    try:
-        hip = ctypes.CDLL("libamdhip64.so")
-        handle = ctypes.c_void_p()
-        rc = hip.hipStreamCreateWithFlags(ctypes.byref(handle), ctypes.c_uint(1))   # hipStreamNonBlocking
-        if rc != 0 or not handle.value:
-            raise RuntimeError(f"hipStreamCreateWithFlags failed ({rc})")
-        return torch.cuda.ExternalStream(handle.value, device=dev)
-    except Exception as exc:   # still correct, possibly less overlap: a stream of torch's pool
-        print(f"[bench] own HIP stream unavailable ({exc}); using a torch pool stream", file=sys.stderr)
-        return torch.cuda.Stream(device=dev)
-
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=256, help="problems per GPU per step")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="problems per batch (BASELINE.json configs[1]: 256)")
+    ap.add_argument("--batches", type=int, default=64, help="batches per GPU per step (one acnqp_solve_batches call)")
     ap.add_argument("--horizon", type=int, default=12)
     ap.add_argument("--constraint-type", default="SOC", choices=["SOC", "LINEAR"])
     ap.add_argument("--precision", type=int, default=64, choices=[64, 32])
-    ap.add_argument("--pipeline", type=int, default=8,
-                    help="batches kept in flight per GPU, one HIP stream each (1 = strictly one launch at a time)")
+    ap.add_argument("--pageable", action="store_true", help="problem / result arrays in pageable host memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -83,13 +59,25 @@ def parse():
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--rehearse-collective", action="store_true",
                     help="rehearsal only: run the per-step all-gather (and its process group) even with one rank")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start one fresh process per GPU (this parent never touches
+    HIP, so no process that has initialised the GPU is replaced or forked) and return the worst exit code."""
+    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    return max(p.wait() for p in procs)
 
 
 def algorithmic_bytes(B, N, Tm, K, site):
-    """HBM bytes one launch must move: per problem read lb, ub, q
-    and write x (4*N*Tm doubles), the session table (K*N * (4+4+8) B), 1 double + 1 int + 1
-    byte of scalars in, 3 doubles + 2 ints out; the site matrices once per launch."""
+    """HBM bytes one launch over B problems must move: per problem read lb, ub, q and write x
+    (4*N*Tm doubles), the session table (K*N * (4+4+8) B), 1 double + 1 int + 1 byte of scalars in, 3 doubles +
+    2 ints out; the site matrices once per launch."""
     per_qp = 8 * 4 * N * Tm + 16 * K * N + (8 + 4 + 1) + (3 * 8 + 2 * 4)
     if site.has_peak:
         per_qp += 8 * Tm
@@ -104,43 +92,34 @@ def flops_per_iteration(N, Tm, site):
 
 
 def cpu_baseline_leg(batch, gpu_x, gpu_status, target_seconds, snaps, infra, iface, accel_mem=0):
-    """The ONLY place bench.py touches oracle/: the scalar C port of the device ADMM timed on
-    the host cores over a bounded sample, which also serves as the parity check of the sample."""
+    """The ONLY place bench.py touches oracle/: the scalar C port of the device ADMM timed on the host cores over a
+    bounded sample, which also serves as the parity check of the sample."""
+    import numpy as np
+
     from oracle import admm_port
-    import copy
 
     cores = min(admm_port.max_threads(), os.cpu_count() or 1)
-
-    def sub(k):
-        sb = copy.copy(batch)
-        sb.B = k
-        for name in ("T", "lb", "ub", "q", "pdiag", "lf", "s_off", "s_len", "s_cap", "s_eq", "const", "presolve_status"):
-            setattr(sb, name, getattr(batch, name)[:k])
-        sb.peak = None if batch.peak is None else batch.peak[:k]
-        return sb
-
-    admm_port.solve_batch(sub(min(cores, batch.B)), threads=cores, accel_mem=accel_mem)  # warm the thread pool / caches
+    admm_port.solve_batch(batch, threads=cores, accel_mem=accel_mem)   # warm the thread pool / caches
     t0 = time.perf_counter()
-    out = admm_port.solve_batch(batch, threads=cores, accel_mem=accel_mem)   # one pass over the whole rank-0 batch: parity sample
+    out = admm_port.solve_batch(batch, threads=cores, accel_mem=accel_mem)   # one pass: the parity sample
     one_pass = max(time.perf_counter() - t0, 1e-4)
     reps = int(max(1, min(200, round(target_seconds / one_pass))))
     t0 = time.perf_counter()
-    for _ in range(reps):   # bounded sample of the same workload: the batch, `reps` times
+    for _ in range(reps):   # bounded sample of the same workload: the first batch, `reps` times
         admm_port.solve_batch(batch, threads=cores, accel_mem=accel_mem)
     dt = time.perf_counter() - t0
     n = batch.B
-    n_timed = n * reps
     ok = (out["status"] == 1) & (gpu_status[:n] == 1)
     dx = float(np.abs(out["x"][ok] - gpu_x[:n][ok]).max()) if ok.any() else float("nan")
     res = {
-        "value": n_timed / dt, "unit": "QP solves/s", "cores": int(cores), "kind": "port",
-        "sample": f"the {batch.B} rank-0 problems x {reps} passes = {n_timed} solves, oracle/admm_port.c (scalar C "
+        "value": n * reps / dt, "unit": "QP solves/s", "cores": int(cores), "kind": "port",
+        "sample": f"the first batch ({batch.B} problems) x {reps} passes = {n * reps} solves, oracle/admm_port.c (scalar C "
                   f"port of the device ADMM, gcc -O3 -fopenmp, one problem per thread), {dt:.1f} s wall",
     }
     parity = {"port_sample": n, "max_abs_rate_diff_gpu_vs_port_A": dx,
               "status_mismatches_vs_port": int((out["status"] != gpu_status[:n]).sum())}
-    # independent solvers on the problem the reference states (pure quick_charge): objective / aggregate
-    # gap against scipy-HiGHS (LINEAR rows) or the certified IPM oracle (SOC rows), first problems only
+    # independent solvers on the problem the reference states (pure quick_charge): objective / aggregate gap
+    # against scipy-HiGHS (LINEAR rows) or the certified IPM oracle (SOC rows), first problems only
     try:
         ctype = "SOC" if batch.site.cone == 1 else "LINEAR"
         from oracle.ipm import solve_lp_highs
@@ -167,21 +146,28 @@ def cpu_baseline_leg(batch, gpu_x, gpu_status, target_seconds, snaps, infra, ifa
         parity["lp_rel_objective_gap_max"] = float(np.max(np.abs(gaps))) if gaps else None
         parity["lp_aggregate_gap_max_A"] = float(np.max(aggs)) if aggs else None
         res["independent_solver_ms_per_solve_1thread"] = 1e3 * float(np.median(th))
-    except Exception as exc:  # the LINEAR-only cross-check is informative, never fatal
-        parity["highs_error"] = repr(exc)
+    except Exception as exc:  # the cross-check is informative, never fatal
+        parity["independent_solver_error"] = repr(exc)
     return res, parity
 
 
 def main():
+    args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))   # before torch / HIP are touched in this process
+    world = int(env_world or "1")
+    if world != args.gpus and not args.one_device:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
+                         f"(torch.distributed.run --nproc-per-node {args.gpus}) or run without a launcher")
     # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL's version banner, Gloo's rank
     # chatter): keep the real stdout for the JSON line and point file descriptor 1 at stderr for everything else.
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -204,105 +190,145 @@ def main():
 
     from adacharge_amd import ObjectiveComponent, equal_share, quick_charge, sites
     from adacharge_amd.acn import Interface
-    from adacharge_amd.backend import DeviceBatch, SiteHandle, default_options
-    from adacharge_amd.builder import build_batch
+    from adacharge_amd.backend import SiteHandle, default_options, pinned_empty
+    from adacharge_amd.builder import build_batch, make_site
 
     infra = sites.caltech54()
     iface = Interface({"infrastructure_info": infra, "period": 5})
-    T, B = args.horizon, args.batch
+    T, B, G = args.horizon, args.batch, args.batches
     objective = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
     opts = default_options(precision=args.precision)
     if args.precision == 32:
         opts.eps_abs = opts.eps_rel = 5e-5
+    alloc = None if args.pageable else pinned_empty
+    site = make_site(infra, args.constraint_type)
+    handle = SiteHandle(site, local_rank)
+    # G batches of B distinct snapshots per rank, every array the ABI reads in (pinned) host memory
+    snaps0 = None
+    batches = []
+    for g in range(G):
+        sn = sites.snapshot_batch(infra, T, B, seed=20240 + 7919 * rank + 104729 * g)
+        if g == 0:
+            snaps0 = sn
+        batches.append(build_batch(sn, infra, iface, objective, args.constraint_type, site=site, alloc=alloc))
+    N, Tm, K = batches[0].N, batches[0].Tm, batches[0].K
+    assert all(b.Tm == Tm and b.K == K for b in batches)
+    per_step = G * B
+
     gdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
-    # `--pipeline` independent batches per GPU, each with its own inputs, result tensors, HIP stream and
-    # gather buffer: a step launches the next batch on the next stream, so that a batch's stragglers
-    # (the launch lasts as long as its slowest problem) overlap with the following batch's solves.
-    depth = max(1, args.pipeline)
-    slots = []
-    for s_ in range(depth):
-        sn = sites.snapshot_batch(infra, T, B, seed=20240 + rank + 1000 * s_)
-        bt = build_batch(sn, infra, iface, objective, args.constraint_type)
-        slots.append(dict(
-            snaps=sn, batch=bt, handle=SiteHandle(bt.site, local_rank), dbatch=DeviceBatch(bt, dev),
-            stream=new_stream(dev) if depth > 1 else torch.cuda.current_stream(),
-            gathered=torch.empty((world * B, bt.N, bt.Tm), dtype=torch.float64, device=gdev) if collective else None,
-        ))
-    snaps, batch, handle, dbatch = (slots[0][k] for k in ("snaps", "batch", "handle", "dbatch"))
+    x_dev = gathered = None
+    x_dev_ptrs = None
+    if collective:   # the rank's schedules also stay in HBM (acnqp_results.x_dev); two gather buffers: the all-gather
+        x_dev = [torch.zeros((per_step, N, Tm), dtype=torch.float64, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world * per_step, N, Tm), dtype=torch.float64, device=gdev) for _ in range(2)]
+    runs = []
+    for k in range(2 if collective else 1):
+        ptrs = None
+        if collective:
+            ptrs = [x_dev[k].data_ptr() + g * B * N * Tm * 8 for g in range(G)]
+        runs.append(handle.prepare_many(batches, pinned_results=not args.pageable, x_dev_ptrs=ptrs))
+    pending = [None, None]
 
     def step(i):
-        sl = slots[i % depth]
-        with torch.cuda.stream(sl["stream"]):
-            sl["handle"].solve_device(sl["dbatch"], opts, stream=sl["stream"].cuda_stream)
-            if collective:   # the one collective of the job: every rank ends up with all schedules
-                if args.dist_backend == "nccl":
-                    dist.all_gather_into_tensor(sl["gathered"], sl["dbatch"].x)
-                else:
-                    dist.all_gather(list(sl["gathered"].chunk(world)), sl["dbatch"].x.cpu())
+        k = i % 2 if collective else 0
+        if collective and pending[k] is not None:   # the gather issued two steps ago used these buffers
+            pending[k].wait()
+            pending[k] = None
+        run, _ = runs[k]
+        run(opts)   # acnqp_solve_batches: H2D + kernels + D2H (+ x_dev), synchronous
+        if collective:   # the one collective of the job, overlapped with the next step's solve
+            if args.dist_backend == "nccl":
+                pending[k] = dist.all_gather_into_tensor(gathered[k], x_dev[k], async_op=True)
+            else:
+                pending[k] = dist.all_gather(list(gathered[k].chunk(world)), x_dev[k].cpu(), async_op=True)
 
     def fence():
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         torch.cuda.synchronize()
         if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(depth):     # setup, not warm-up: every slot's first launch (module load, LDS attribute)
-        step(i)
+    step(0)      # setup, not warm-up: module load, staging allocation, LDS attribute
     fence()
     for i in range(args.warmup):
         step(i)
     fence()
-    for sl in slots:
-        sl["handle"].kernel_times()   # discard the warm-up launches
+    handle.kernel_times()   # discard the warm-up launches
     kernel_ms = []
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-        if (i + 1) % (32 * depth) == 0:   # the event ring holds 64 launches per handle
-            for sl in slots:
-                kernel_ms += sl["handle"].kernel_times()
+        kernel_ms += handle.kernel_times()   # HIP events of this step's launches (the call has synchronised)
     fence()
     elapsed = time.perf_counter() - t0
-    for sl in slots:
-        kernel_ms += sl["handle"].kernel_times()   # HIP events on the launch streams, read after the fence
-    gathered = slots[0]["gathered"]
     if collective:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    x = dbatch.x.cpu().numpy()
-    status = dbatch.status.cpu().numpy()
-    iters = dbatch.iters.cpu().numpy()
-    used = slots
-    solved = int(sum(int((sl["dbatch"].status == 1).sum().item()) for sl in used))
-    iters_all = np.concatenate([sl["dbatch"].iters.cpu().numpy() for sl in used])
+    results = runs[(args.steps - 1) % 2 if collective else 0][1]
+    status_all = np.concatenate([r.status for r in results])
+    iters_all = np.concatenate([r.iters for r in results])
+    solved = int((status_all == 1).sum())
     if collective:
-        cnt = torch.tensor([solved, B * len(used)], dtype=torch.int64, device=gdev)
+        cnt = torch.tensor([solved, per_step], dtype=torch.int64, device=gdev)
         dist.all_reduce(cnt)
         solved_all, total_all = int(cnt[0]), int(cnt[1])
-        if rank == 0:   # the gather really carries every rank's schedules
-            assert torch.equal(gathered[:B].to(dev), dbatch.x)
+        if rank == 0:   # the gather really carries this rank's schedules, and they are what came back to the host
+            k = (args.steps - 1) % 2
+            assert torch.equal(gathered[k][:per_step].to(dev), x_dev[k])
+            assert np.array_equal(x_dev[k][:B].cpu().numpy(), results[0].x)
     else:
-        solved_all, total_all = solved, B * len(used)
+        solved_all, total_all = solved, per_step
 
+    # kernel-only rate of the same step, outside the timed region: the step's problems resident in HBM, ONE launch of
+    # the device-pointer entry, HIP events around it (what `value` would be with free copies)
+    kernel_only = None
     if rank == 0:
+        import copy
+
+        from adacharge_amd.backend import DeviceBatch
+
+        big = copy.copy(batches[0])
+        big.B = per_step
+        for name in ("T", "lb", "ub", "q", "pdiag", "lf", "s_off", "s_len", "s_cap", "s_eq", "dc", "dfloor"):
+            setattr(big, name, np.concatenate([getattr(b, name) for b in batches]))
+        dbig = DeviceBatch(big, dev)
+        ms = []
+        for _ in range(3):
+            handle.solve_device(dbig, opts, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            ms.append(handle.last_kernel_ms())
+        handle.kernel_times()
+        kernel_only = {"value": per_step / (min(ms) * 1e-3), "unit": "QP solves/s per GPU", "launch_ms": min(ms),
+                       "problems_per_launch": per_step,
+                       "note": "device-resident inputs, one launch over the step's problems, HIP events; not the metric"}
+        del dbig
+    if rank == 0:
+        batch = batches[0]
+        launch_b = min(CHUNK_PROBLEMS, per_step)
         k_avg_ms = float(np.mean(kernel_ms))
-        abytes, per_qp, site_bytes = algorithmic_bytes(B, batch.N, batch.Tm, batch.K, batch.site)
+        k_sum_ms = float(np.sum(kernel_ms))
+        abytes, per_qp, site_bytes = algorithmic_bytes(launch_b, N, Tm, K, batch.site)
         achieved = abytes / (k_avg_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):   # committed result of the separate rocprofv3 --pmc passes
+        if os.path.exists(tfile):   # committed result of the separate rocprofv3 --pmc passes (same command)
             try:
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        fl = flops_per_iteration(batch.N, batch.Tm, batch.site)
-        # flops of the iterations actually run (mean over the batches in flight) per second of wall time
-        valu_tf = float(iters_all.mean()) * B * args.steps * fl / elapsed / 1e12
+        fl = flops_per_iteration(N, Tm, batch.site)
+        valu_peak = FP64_VALU_PEAK_TF if args.precision == 64 else 157.3
+        valu_tf = float(iters_all.mean()) * per_step * args.steps * fl / elapsed / 1e12
+        host_bytes = per_step * (per_qp - 0)   # H2D of the inputs + D2H of the results = the algorithmic bytes per QP
         out = {
             "metric": "MPC QP solves/sec whole-node, 54 EVSE x horizon 12; max rate residual vs cvxpy",
-            "value": world * B * args.steps / elapsed,
+            "value": world * per_step * args.steps / elapsed,
             "unit": "QP solves/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -315,35 +341,39 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"caltech54 (Caltech-shaped, 54 EVSE) x horizon {T}, quick_charge + equal_share*1e-12, "
-                            f"{args.constraint_type} constraints, batch {B} independent MPC snapshots per GPU "
-                            f"(BASELINE.json configs[1])",
-                "batch_per_gpu": B, "n_evse": batch.N, "horizon": T, "constraint_type": args.constraint_type,
-                "batches_in_flight_per_gpu": depth,
-                "parallelism": f"dp{world} (one batch shard per GPU" + (", RCCL all-gather of schedules per step)" if world > 1 else ")"),
+                            f"{args.constraint_type} constraints, batches of {B} independent MPC snapshots "
+                            f"(BASELINE.json configs[1]); one step = one acnqp_solve_batches call over {G} such batches "
+                            f"per GPU ({per_step} problems), {'pageable' if args.pageable else 'pinned'} host buffers in, "
+                            f"host buffers out: H2D + kernels + D2H inside the timed region",
+                "batch": B, "batches_per_step_per_gpu": G, "problems_per_step_per_gpu": per_step,
+                "n_evse": N, "horizon": T, "constraint_type": args.constraint_type,
+                "parallelism": f"dp{world} (own snapshots per GPU" + (", one RCCL all-gather of schedules per step)" if world > 1 else ")"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "acnqp::admm_tiled_kernel<%s, 4, 1, 1, 1, 2, 5>" % ("double" if args.precision == 64 else "float"),
-                "kernel_avg_ms": k_avg_ms, "launches_timed": len(kernel_ms), "launches_in_flight": depth,
+                "kernel_avg_ms": k_avg_ms, "launches_timed": len(kernel_ms), "problems_per_launch": launch_b,
                 "algorithmic_bytes_per_launch": abytes, "bytes_per_qp": per_qp,
-                "note": "LDS-resident iterative solver: HBM is touched once per problem, so the HBM fraction is "
-                        "small by construction (SURVEY.md H8); the VALU view is in `valu`",
+                "note": "LDS/register-resident iterative solver: HBM is touched once per problem, so the HBM fraction is "
+                        "small by construction (SURVEY.md H8); launches of successive chunks overlap on the GPU, so a "
+                        "launch's duration includes the share of the CUs it cedes to its neighbours; `valu` is the roof that binds",
             },
             "valu": {
-                "achieved": valu_tf, "peak": FP64_VALU_PEAK_TF if args.precision == 64 else 157.3, "unit": "TFLOP/s",
-                "frac": valu_tf / (FP64_VALU_PEAK_TF if args.precision == 64 else 157.3),
+                "achieved": valu_tf, "peak": valu_peak, "unit": "TFLOP/s", "frac": valu_tf / valu_peak,
                 "flops_per_iteration": fl, "iterations_mean": float(iters_all.mean()), "iterations_max": int(iters_all.max()),
             },
+            "kernel_only": kernel_only,
+            "pcie": {"host_bytes_per_step_per_gpu": int(host_bytes), "achieved_GBs_per_gpu": host_bytes * args.steps / elapsed / 1e9},
             "solver": {
                 "solved": solved_all, "problems": total_all,
                 "eps_abs": opts.eps_abs, "eps_rel": opts.eps_rel, "reg_rel": opts.reg_rel,
-                "anderson_columns": handle.accel_columns(batch.Tm, batch.K, opts),
+                "anderson_columns": handle.accel_columns(Tm, K, opts),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, parity = cpu_baseline_leg(batch, x, status, args.cpu_seconds, snaps, infra, iface,
-                                          accel_mem=handle.accel_columns(batch.Tm, batch.K, opts))
+            cb, parity = cpu_baseline_leg(batch, results[0].x, results[0].status, args.cpu_seconds, snaps0, infra, iface,
+                                          accel_mem=handle.accel_columns(Tm, K, opts))
             out["cpu_baseline"] = cb
             out["parity"] = parity
         print(json.dumps(out), file=json_out, flush=True)

@@ -34,13 +34,14 @@
 #ifndef ACN_QP_H
 #define ACN_QP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define ACNQP_ABI_VERSION 4
+#define ACNQP_ABI_VERSION 5
 
 /* cone of the infrastructure rows (constraint_type at aco.py:35, 151, 165) */
 #define ACNQP_CONE_LINEAR 0
@@ -89,7 +90,9 @@ typedef struct {
 typedef struct {
   int32_t batch;           /* B                                              */
   int32_t t_max;           /* Tm: padded horizon of every array below        */
-  int32_t k_sessions;      /* K: session slots per EVSE (>= 1)               */
+  int32_t k_sessions;      /* K: session slots per EVSE (>= 1; disjoint windows
+                              per EVSE; offline instances, adacharge.py:249-276,
+                              reach tens of sessions per EVSE)                */
   const int32_t* horizon;  /* [B]        own horizon T_b <= Tm (aco.py:243)  */
   const double* lb;        /* [B*N*Tm]   0 outside session windows           */
   const double* ub;        /* [B*N*Tm]   finite                              */
@@ -112,6 +115,10 @@ typedef struct {
   double* pri_res;   /* [B]       |A r - z|_inf at exit                       */
   double* dua_res;   /* [B]       |P r + q + A'y|_inf at exit                 */
   double* obj;       /* [B]       1/2 pdiag |x|^2 + <q, x>                    */
+  double* x_dev;     /* host-buffer entry points only, optional (NULL = not wanted): a DEVICE
+                        pointer [B*N*Tm] on the handle's GPU that also receives the schedules,
+                        so that a collective (the RCCL all-gather of a multi-GPU job) can start
+                        from HBM without re-uploading them.  Ignored by acnqp_solve_batch_device. */
 } acnqp_results;
 
 /* Solver options -- the knobs cvxpy would forward to its solver (the
@@ -145,13 +152,35 @@ typedef struct {
 int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out);
 
 /* acnqp_solve_batch -- host buffers in, host buffers out, synchronous.
- * Replaces cp.Problem(...).solve(...) at aco.py:315-318 for B problems.      */
+ * Replaces cp.Problem(...).solve(...) at aco.py:315-318 for B problems.
+ * Same as acnqp_solve_batches with one batch: a large batch is cut into chunks whose
+ * H2D copies, kernels and D2H copies overlap.                                       */
 int acnqp_solve_batch(acnqp_handle* h, const acnqp_problems* p,
                       const acnqp_options* o, acnqp_results* r);
 
+/* acnqp_solve_batches -- n_batches independent host-buffer batches (p[g] -> r[g]) in
+ * ONE pipelined pass, synchronous.  What a caller with many batches of MPC snapshots
+ * (timesteps, sites, demand scenarios: the reference would loop over aco.py:286-321)
+ * submits at once: consecutive batches of one shape (t_max, k_sessions) share kernel
+ * launches of a few thousand problems, so that a launch does not idle on its slowest
+ * problem; chunks rotate over internal streams with their own device staging, so that
+ * the H2D copies of chunk c+1 and the D2H copies of chunk c-1 overlap chunk c's kernel.
+ * Buffers allocated with acnqp_host_alloc (pinned) are copied by DMA without a staging
+ * hop; pageable buffers work, slower.  Every pointer is a HOST pointer; nothing is
+ * retained after return.  Every problem's status is set (never ACNQP_STATUS_UNSET) or
+ * the call fails with ACNQP_ERR_HIP.                                                 */
+int acnqp_solve_batches(acnqp_handle* h, int32_t n_batches, const acnqp_problems* p,
+                        const acnqp_options* o, acnqp_results* r);
+
+/* Pinned (page-locked) host memory for problem / result arrays; NULL on failure.    */
+void* acnqp_host_alloc(size_t bytes);
+void acnqp_host_free(void* p);
+
 /* acnqp_solve_batch_device -- same, but every pointer in *p and *r is a device
  * pointer on the handle's GPU and the work is enqueued on `hip_stream`
- * (a hipStream_t, NULL = default stream); returns without synchronising.     */
+ * (a hipStream_t, NULL = default stream); returns without synchronising.
+ * r->status is cleared to ACNQP_STATUS_UNSET on the stream before the launch: a
+ * problem still UNSET after synchronisation was never processed.              */
 int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p,
                              const acnqp_options* o, acnqp_results* r,
                              void* hip_stream);

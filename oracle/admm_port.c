@@ -164,7 +164,10 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
     return 4;
   }
   double pd = pdiag_user;
-  if (ubmax > 0) pd = fmax(pd, O->reg_rel * qnorm / (ubmax * (double)(horizon > 1 ? horizon : 1)));
+  /* Tikhonov floor: LP-like problems only (kRegResolve / effective_pdiag in acn_qp_tiled.hpp) */
+  const int has_prox = (S->has_flat && lf > 0) || (S->has_max && dc > 0);
+  if (ubmax > 0 && !has_prox && pdiag_user * ubmax <= 1e-6 * qnorm)
+    pd = fmax(pd, O->reg_rel * qnorm / (ubmax * (double)(horizon > 1 ? horizon : 1)));
   double rho = O->rho;
   int n_adapt = 0;   /* adaptations made so far: the tolerance band widens with each (no limit cycles) */
   const double sigma = O->sigma, alpha = O->alpha;

@@ -196,7 +196,9 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
                     pri_res=np.inf, dua_res=np.inf, obj=np.nan, rho=opts.rho)
     lb, ub, q = batch.lb[b], batch.ub[b], batch.q[b]
     pdiag = float(batch.pdiag[b])
-    if ub.max() > 0:
+    # Tikhonov floor: LP-like problems only (kRegResolve / effective_pdiag in acn_qp_tiled.hpp)
+    has_prox = float(batch.lf[b]) > 0 or (getattr(batch, "dc", None) is not None and float(batch.dc[b]) > 0)
+    if ub.max() > 0 and not has_prox and pdiag * ub.max() <= 1e-6 * np.abs(q).max():
         pdiag = max(pdiag, opts.reg_rel * np.abs(q).max() / (ub.max() * max(1, T)))
     eq = bool(batch.s_eq[b])
     G, Gh, lam, Q, limits = site.G, site.Ghat, site.lam, site.Q, site.limits

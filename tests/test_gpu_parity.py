@@ -162,8 +162,7 @@ def test_golden_strictly_convex_rates():
         sl, meta, exp = H.golden_case(g, key)
         obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, meta["es"])]
         opt = AdaptiveChargingOptimization(obj, iface, constraint_type=meta["ct"],
-                                           enforce_energy_equality=meta["eq"],
-                                           solver_options=dict(reg_rel=0.0))
+                                           enforce_energy_equality=meta["eq"])
         rates = opt.solve(sl, infra)
         d = float(np.abs(rates - exp["rates"]).max())
         worst[key] = d
@@ -254,8 +253,8 @@ def test_fp32_path_reaches_its_tolerance():
     h = SiteHandle(batch.site, 0)
     # same stopping tolerance in both precisions: the fp32 loop must land where the fp64 loop
     # lands (the remaining distance to the optimum is set by eps, not by the arithmetic type)
-    r64 = h.solve(batch, default_options(eps_abs=5e-5, eps_rel=5e-5, reg_rel=0.0))
-    r32 = h.solve(batch, default_options(eps_abs=5e-5, eps_rel=5e-5, reg_rel=0.0, precision=32))
+    r64 = h.solve(batch, default_options(eps_abs=5e-5, eps_rel=5e-5))
+    r32 = h.solve(batch, default_options(eps_abs=5e-5, eps_rel=5e-5, precision=32))
     assert (r64.status == 1).all() and (r32.status == 1).all()
     assert np.abs(r32.x - r64.x).max() <= 2e-2   # 6e-4 relative to the 32 A pilot scale
     assert np.abs(r32.obj - r64.obj).max() <= 1e-4 * np.abs(r64.obj).max()
@@ -279,10 +278,8 @@ def test_large_feasible_single_phase(ct):   # t_aco.py:286-343, KAT-4 aggregate
     check_invariants(rates, sessions, infra)
     agg = rates.sum(axis=0)
     # KAT-4: unique aggregate 576 A for periods 0-53, 49.846 A at 54, 0 after.
-    # Moving charge between periods 53 and 54 costs 1/144 per A, a nearly flat direction of this LP,
-    # so the transition period gets a looser absolute tolerance than the rest.
     assert np.allclose(agg[:54], 576.0, atol=2e-2)
-    assert abs(agg[54] - 49.846153846) < 0.5 and np.allclose(agg[55:], 0, atol=2e-2)
+    assert abs(agg[54] - 49.846153846) < 5e-2 and np.allclose(agg[55:], 0, atol=2e-2)
     lp_obj = -(rates * np.array([(144 - t) / 144 for t in range(144)])[None, :]).sum()
     assert abs(lp_obj - (-25411.153846)) <= 1e-5 * 25411.0
 
@@ -311,7 +308,7 @@ def test_load_flattening_matches_oracle(ct):
     spec = [("load_flattening", 1.0, {"external_signal": ext}), ("total_energy", 1500.0, {}), ("equal_share", 1e-3, {})]
     for seed in (3, 4):
         sl = sites.random_sessions(infra, 12, np.random.default_rng(seed))
-        opt = AdaptiveChargingOptimization(obj, iface, constraint_type=ct, solver_options=dict(reg_rel=0.0))
+        opt = AdaptiveChargingOptimization(obj, iface, constraint_type=ct)
         rates = opt.solve(sl, infra)
         prob = build_reference_problem(sl, infra, iface, spec, ct)
         ref, _, cert = solve_certified(prob)
@@ -503,7 +500,7 @@ def test_demand_charge_matches_oracle(ct, T):
     obj = [ObjectiveComponent(total_energy, 20.0), ObjectiveComponent(demand_charge), ObjectiveComponent(equal_share, 1e-3)]
     spec = [("total_energy", 20.0, {}), ("demand_charge", 1.0, {}), ("equal_share", 1e-3, {})]
     sl = sites.random_sessions(infra, T, np.random.default_rng(3))
-    opt = AdaptiveChargingOptimization(obj, iface, constraint_type=ct, solver_options=dict(reg_rel=0.0))
+    opt = AdaptiveChargingOptimization(obj, iface, constraint_type=ct)
     rates = opt.solve(sl, infra)
     prob = build_reference_problem(sl, infra, iface, spec, ct)
     ref, _, cert = solve_certified(prob)
@@ -541,9 +538,9 @@ def test_config5_shape_synth512_load_flattening():
     batch = build_batch(snaps, infra, iface, obj, "SOC")
     assert batch.N == 512 and batch.Tm == 48 and batch.site.has_flat
     h = SiteHandle(batch.site, 0)
-    res = h.solve(batch, default_options(eps_abs=1e-6, eps_rel=1e-6, reg_rel=0.0, max_iter=20000))
+    res = h.solve(batch, default_options(eps_abs=1e-6, eps_rel=1e-6, max_iter=20000))
     assert (res.status == 1).all()
-    ref = admm_port.solve_batch(batch, threads=2, eps_abs=1e-6, eps_rel=1e-6, reg_rel=0.0,
+    ref = admm_port.solve_batch(batch, threads=2, eps_abs=1e-6, eps_rel=1e-6,
                                 accel_mem=h.accel_columns(batch.Tm, batch.K, default_options()))
     assert (ref["status"] == 1).all()
     assert np.abs(ref["x"] - res.x).max() <= 1e-4
