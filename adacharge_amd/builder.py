@@ -151,6 +151,35 @@ class ProblemBatch:
     def N(self) -> int:
         return self.site.N
 
+    _PER_PROBLEM = ("T", "lb", "ub", "q", "pdiag", "lf", "s_off", "s_len", "s_cap", "s_eq", "peak", "dc", "dfloor",
+                    "const", "presolve_status")
+
+    def subset(self, index) -> "ProblemBatch":
+        """The problems ``index`` (slice or integer array) of this batch as a batch of their own (views when sliced)."""
+        import copy
+
+        out = copy.copy(self)
+        for name in self._PER_PROBLEM:
+            a = getattr(self, name)
+            setattr(out, name, None if a is None else a[index])
+        out.B = len(out.T)
+        return out
+
+    @staticmethod
+    def concatenate(batches: Sequence["ProblemBatch"]) -> "ProblemBatch":
+        """Batches of one site and one shape (Tm, K) as a single batch."""
+        import copy
+
+        first = batches[0]
+        if any(b.Tm != first.Tm or b.K != first.K or b.site is not first.site for b in batches):
+            raise ValueError("concatenate needs batches of one site and one shape")
+        out = copy.copy(first)
+        for name in ProblemBatch._PER_PROBLEM:
+            parts = [getattr(b, name) for b in batches]
+            setattr(out, name, None if parts[0] is None else np.concatenate(parts))
+        out.B = len(out.T)
+        return out
+
 
 def scenario_batch(base: ProblemBatch, demand_factor: np.ndarray, problem: int = 0) -> ProblemBatch:
     """Stochastic-MPC scenarios of ONE problem of ``base`` (BASELINE.json configs[3]): same session windows,

@@ -12,6 +12,7 @@
 #include "acn_qp.h"
 #include "acn_qp_tiled.hpp"
 #include "acn_qp_general.hpp"
+#include "acn_qp_stream.hpp"
 
 namespace {
 
@@ -219,10 +220,10 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
     if (e != hipSuccess) return e;
     return hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(real), hipMemcpyHostToDevice);
   };
-  // MFMA A-operand fragments in the order the tiled kernel reads them (one coalesced 64-lane row per
-  // fragment register): see acn_qp_tiled.hpp.  Only sites the tiled kernel can take (NP = 64).
+  // MFMA A-operand fragments in the order the tiled and the large-site kernel read them (one coalesced
+  // 64-lane row per fragment register): see acn_qp_tiled.hpp / acn_qp_stream.hpp.  NP / 16 EVSE tiles.
   std::vector<double> fragG, fragQ;
-  if (NP == 64) {
+  {
     const int NWv = NP / 16, MT = MR / 16;
     fragG.assign((size_t)NWv * MT * 2 * 4 * 64, 0.0);
     fragQ.assign((size_t)MT * MT * 2 * 4 * 64, 0.0);
@@ -262,20 +263,31 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
 constexpr int kLdsPerCu = 160 * 1024;
 constexpr int kAccelMax1 = 5, kAccelMax2 = 5;   // Anderson columns compiled into the OCC = 1 / OCC = 2 variants
 
-// Anderson columns that fit next to the solver's own LDS for this kernel shape (one workgroup per CU)
+// Anderson columns that fit next to the solver's own LDS for this kernel shape with `occ` workgroups per CU
 template <typename real>
-int accel_capacity(int NW, int MT, int CT, int NP, int K, int occ) {
-  const acnqp::TiledLds base(NW, MT, CT, NP, K, occ == 1 ? kAccelMax1 : kAccelMax2, 1, (int)sizeof(real));
+int accel_capacity(int NW, int MT, int CT, int NP, int K, int occ, int pbuf_single = 0) {
+  const acnqp::TiledLds base(NW, MT, CT, NP, K, occ == 1 ? kAccelMax1 : kAccelMax2, 1, (int)sizeof(real), pbuf_single);
   const int col = acnqp::TiledLds::column_bytes(NW, MT, CT);
   const int fixed = base.total * (int)sizeof(real) - col;
   const int cap = (kLdsPerCu / occ - fixed - 64) / col;
   return std::max(0, std::min(cap, occ == 1 ? kAccelMax1 : kAccelMax2));
 }
 
+// One workgroup per CU: if the double-buffered partial-tile slab leaves fewer than the compiled-in number of ring
+// columns, give one slab up (one more barrier per iteration buys a column: on the congested horizon-24 problems a
+// fourth / fifth column is worth 5x fewer iterations on the slowest instances)
+template <typename real>
+int accel_capacity_best(int NW, int MT, int CT, int NP, int K, int* pbuf_single) {
+  const int two = accel_capacity<real>(NW, MT, CT, NP, K, 1, 0);
+  const int one = accel_capacity<real>(NW, MT, CT, NP, K, 1, 1);
+  *pbuf_single = one > two ? 1 : 0;
+  return std::max(one, two);
+}
+
 template <typename real, int NW, int CT, int MT, int KS, int OCC>
 hipError_t launch_tiled_occ(const acnqp::TiledArgs& a, hipStream_t st) {
   constexpr int AM = OCC == 1 ? kAccelMax1 : kAccelMax2;
-  const acnqp::TiledLds L(NW, MT, CT, a.NP, a.K, AM, std::min(a.accel_mem, AM), (int)sizeof(real));
+  const acnqp::TiledLds L(NW, MT, CT, a.NP, a.K, AM, std::min(a.accel_mem, AM), (int)sizeof(real), a.pbuf_single);
   const size_t lds = (size_t)L.total * sizeof(real);
   auto kern = &acnqp::admm_tiled_kernel<real, NW, CT, MT, KS, OCC, AM>;
   if (lds > 64 * 1024) {
@@ -294,11 +306,15 @@ hipError_t launch_tiled_occ(const acnqp::TiledArgs& a, hipStream_t st) {
 // so that a problem's result does not depend on what it is batched with.
 template <typename real, int NW, int CT, int MT, int KS>
 hipError_t launch_tiled(acnqp::TiledArgs a, int requested_accel, hipStream_t st) {
-  a.accel_mem = std::min(requested_accel, accel_capacity<real>(NW, MT, CT, a.NP, a.K, 1));
+  int single = 0;
+  const int cap1 = accel_capacity_best<real>(NW, MT, CT, a.NP, a.K, &single);
+  a.accel_mem = std::min(requested_accel, cap1);
+  a.pbuf_single = 0;
   if constexpr (CT == 1 && MT <= 2 && KS == 1) {
     if (a.accel_mem <= accel_capacity<real>(NW, MT, CT, a.NP, a.K, 2))
       return launch_tiled_occ<real, NW, CT, MT, KS, 2>(a, st);
   }
+  a.pbuf_single = (a.accel_mem > accel_capacity<real>(NW, MT, CT, a.NP, a.K, 1, 0)) ? single : 0;
   return launch_tiled_occ<real, NW, CT, MT, KS, 1>(a, st);
 }
 
@@ -322,6 +338,44 @@ hipError_t launch_any(const acnqp::TiledArgs& a, int NW, hipStream_t st) {
   const int CT = (a.Tm + 15) / 16;
   (void)NW;   // N <= 64: four waves; wider sites take the general-shape kernel
   return CT == 1 ? launch_mt<real, 4, 1>(a, st) : launch_mt<real, 4, 2>(a, st);
+}
+
+// shapes the register-resident tiled kernel takes; everything else runs through the general-shape kernel
+static bool tiled_shape(const acnqp_handle* h, int t_max, int k_sessions) {
+  return h->N <= 64 && t_max <= 32 && k_sessions <= acnqp::kMaxK;
+}
+
+// shapes the large-site MFMA kernel takes (acn_qp_stream.hpp): wide sites, up to three column tiles, no demand-charge row
+static bool stream_shape(const acnqp_handle* h, int t_max) {
+  return h->N > 64 && t_max <= 48 && !h->has_max;
+}
+
+template <int CT, int MT>
+static hipError_t launch_stream_one(const acnqp::StreamArgs& sa, hipStream_t st) {
+  const acnqp::StreamLds L(MT, CT);
+  const size_t lds = (size_t)L.total * sizeof(double);
+  auto kern = &acnqp::admm_stream_kernel<CT, MT>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(acnqp::kStreamWaves * 64), lds, st, sa);
+  return hipGetLastError();
+}
+
+static hipError_t launch_stream(const acnqp::StreamArgs& sa, hipStream_t st) {
+  const int CT = (sa.t.Tm + 15) / 16, MT = sa.t.MR / 16;
+  switch (CT * 10 + MT) {
+    case 11: return launch_stream_one<1, 1>(sa, st);
+    case 12: return launch_stream_one<1, 2>(sa, st);
+    case 13: return launch_stream_one<1, 3>(sa, st);
+    case 21: return launch_stream_one<2, 1>(sa, st);
+    case 22: return launch_stream_one<2, 2>(sa, st);
+    case 23: return launch_stream_one<2, 3>(sa, st);
+    case 31: return launch_stream_one<3, 1>(sa, st);
+    case 32: return launch_stream_one<3, 2>(sa, st);
+    default: return launch_stream_one<3, 3>(sa, st);
+  }
 }
 
 }  // namespace
@@ -415,11 +469,6 @@ void acnqp_destroy(acnqp_handle* h) {
   delete h;
 }
 
-// shapes the register-resident tiled kernel takes; everything else runs through the general-shape kernel
-static bool tiled_shape(const acnqp_handle* h, int t_max, int k_sessions) {
-  return h->N <= 64 && t_max <= 32 && k_sessions <= acnqp::kMaxK;
-}
-
 static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, const acnqp_options* o,
                                 const acnqp_results* r) {
   if (!h || !p || !o || !r) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: null argument");
@@ -440,8 +489,9 @@ static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, 
       !(o->sigma >= 0) || !(o->alpha > 0 && o->alpha < 2) || !(o->adapt_tol > 1) || !(o->reg_rel >= 0) ||
       o->adapt_every < 0)
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: invalid option value");
-  if (o->precision != 64 && o->precision != 32)
-    return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: precision must be 64 or 32");
+  if (o->precision != 64)
+    return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: precision must be 64 (the fp32 loop was removed: it missed the "
+                                   "1e-4 rate tolerance on weakly convex problems and was not faster; DESIGN.md section 3)");
   return ACNQP_OK;
 }
 
@@ -453,13 +503,6 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   HIP_TRY(hipSetDevice(h->device));
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   SiteDev* d = &h->dev64;
-  if (o->precision == 32) {
-    d = &h->dev32;
-    if (!d->ready) {
-      rc = build_site_dev<float>(h, d);
-      if (rc != ACNQP_OK) return rc;
-    }
-  }
   acnqp::TiledArgs a;
   a.B = p->batch; a.N = h->N; a.Tm = p->t_max; a.K = p->k_sessions; a.NP = h->NP; a.MR = d->MR;
   a.G = d->G; a.Ghat = d->Ghat; a.Q = d->Q; a.lam = d->lam; a.rowlim = d->rowlim; a.rowtype = d->rowtype;
@@ -475,11 +518,25 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.max_iter = o->max_iter; a.check_every = o->check_every; a.adapt_every = o->adapt_every;
   a.peak_scale = d->peak_scale; a.flat_scale = d->flat_scale; a.max_scale = d->max_scale;
   a.accel_mem = std::max(0, o->accel_mem);
+  a.pbuf_single = 0;
   const bool tiled = tiled_shape(h, p->t_max, p->k_sessions);
+  const bool stream = !tiled && stream_shape(h, p->t_max);
   acnqp::GeneralArgs ga;
-  if (!tiled) {
+  acnqp::StreamArgs sa;
+  if (stream) {
+    // large-site kernel: iterates streamed through a per-problem workspace in MFMA fragment order
+    const int CT = (p->t_max + 15) / 16;
+    sa.ws_per_problem = acnqp::stream_workspace(h->NP, CT, p->k_sessions);
+    DevBuf* wsb = h->workspace_for(st);
+    const size_t need = (size_t)sa.ws_per_problem * p->batch * sizeof(double);
+    if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(wsb->reserve(need));
+    sa.work = static_cast<double*>(wsb->p);
+    a.accel_mem = 0;
+    sa.t = a;
+  } else if (!tiled) {
     // general-shape fallback: state streamed through a global workspace (not graph-capturable: it may allocate)
-    const size_t rsz = o->precision == 32 ? 4 : 8;
+    const size_t rsz = 8;
     const long long n = (long long)h->N * p->t_max, mt = (long long)d->MR * p->t_max;
     const int gm = std::min(a.accel_mem, acnqp::kGenAccelMax);
     const long long Dn = n + mt;
@@ -490,7 +547,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));   // an earlier launch on this stream may still use the old buffer
     HIP_TRY(wsb->reserve(need));
     ga.work = wsb->p;
-    ga.pair_stride = o->precision == 32 ? 1 : 4;
+    ga.pair_stride = 4;
     ga.t = a;
   }
   (void)hipGetLastError();   // drop any stale error so the check below reports this launch only
@@ -500,7 +557,9 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   HIP_TRY(hipEventRecord(h->ev_start[evk], st));
   hipError_t e = hipSuccess;
   if (tiled) {
-    e = (o->precision == 32) ? launch_any<float>(a, h->NW, st) : launch_any<double>(a, h->NW, st);
+    e = launch_any<double>(a, h->NW, st);
+  } else if (stream) {
+    e = launch_stream(sa, st);
   } else {
     // workgroup size by problem size: the plain loops are latency-bound, more threads per problem hide more of it
     const long long nvar = (long long)h->N * p->t_max;
@@ -511,7 +570,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
       else if (nt == 512) hipLaunchKernelGGL((acnqp::admm_general_kernel<real, 512>), dim3(a.B), dim3(512), 0, st, ga);
       else hipLaunchKernelGGL((acnqp::admm_general_kernel<real, 1024>), dim3(a.B), dim3(1024), 0, st, ga);
     };
-    if (o->precision == 32) launch_general(float{}); else launch_general(double{});
+    launch_general(double{});
     e = hipGetLastError();
   }
   if (e != hipSuccess) return fail(ACNQP_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
@@ -522,16 +581,15 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
 
 int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, int32_t precision, int32_t requested) {
   if (!h || t_max < 1 || k_sessions < 1 || requested <= 0) return 0;
-  if (!tiled_shape(h, t_max, k_sessions)) return std::min(requested, acnqp::kGenAccelMax);   // general-shape kernel: ring in its workspace
-  SiteDev* d = &h->dev64;
-  if (precision == 32) {
-    d = &h->dev32;
-    if (!d->ready && build_site_dev<float>(h, d) != ACNQP_OK) return 0;
+  if (precision != 64) return 0;
+  if (!tiled_shape(h, t_max, k_sessions)) {
+    if (stream_shape(h, t_max)) return 0;                // large-site kernel: plain ADMM
+    return std::min(requested, acnqp::kGenAccelMax);     // general-shape kernel: ring in its workspace
   }
+  SiteDev* d = &h->dev64;
   const int CT = (t_max + 15) / 16, MT = d->MR / 16;
-  const int cap = precision == 32 ? accel_capacity<float>(4, MT, CT, h->NP, k_sessions, 1)
-                                  : accel_capacity<double>(4, MT, CT, h->NP, k_sessions, 1);
-  return std::min(requested, cap);
+  int single = 0;
+  return std::min(requested, accel_capacity_best<double>(4, MT, CT, h->NP, k_sessions, &single));
 }
 
 static float event_pair_ms(acnqp_handle* h, long long launch) {

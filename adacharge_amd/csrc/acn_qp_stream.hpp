@@ -1,0 +1,567 @@
+// Large-site kernel of the batched MPC QP solver for gfx950: N > 64 EVSEs (up to 1024), horizon <= 48, <= 48 site
+// rows -- BASELINE.json configs[4] (512 EVSE x 48 periods, load_flattening) and the reference's big single instances
+// (aco.py:403-408, adacharge.py:249-276) when they fit that horizon.
+//
+// Same ADMM as acn_qp_tiled.hpp (see there), but an N x T iterate no longer fits the registers / LDS of one
+// workgroup (512 x 48 doubles = 192 KB per array), so the iterates x, z1, y1 and the constants q, lb, ub STREAM
+// through HBM once per iteration, in MFMA fragment order ([EVSE tile][column tile][register][lane]: every wave
+// load is one contiguous 512-byte row), and the two cross-EVSE products are real GEMMs on the matrix cores:
+//
+//   x~ tile   = (r0 + Ghat[:, tile]' e^) / a      N x Mr x T   (Mr = padded site rows)      v_mfma_f64_16x16x4_f64
+//   P         = sum over tiles Ghat[:, tile] r0   Mr x N x T
+//
+// One workgroup of 8 waves per problem; wave w owns EVSE tiles w, w + 8, ...  Per iteration ONE fused pass over the
+// tiles: load (x, z1, y1, q, lb, ub) -> r0 -> x~ (MFMA, e^ from LDS) -> relaxation -> box + energy-row projection
+// (water-filling along the 16-lane DPP row that holds one EVSE's periods, all column tiles in registers) -> y1 ->
+// store (x, z1, y1) -> the NEW r0 feeds the tile's contribution to next iteration's P straight from registers (its
+// C-layout registers are the MFMA B operand, as in the tiled kernel).  Nine N x T arrays cross HBM per iteration:
+// 9 * 8 * NP * TP bytes -- the kernel is HBM-bound by design (the MFMAs take ~1/4 of that time).
+// The 8 partial P sets are reduced through LDS in fixed order (deterministic), the <= 48 x 48 site-row state
+// (z2, y2, G x, e^, h^) lives in LDS and is advanced by the wave that owns each 16 x 16 tile.
+//
+// Not in this kernel (the general-shape kernel keeps them): Anderson acceleration, the infeasibility certificate,
+// the demand-charge row.  acn_qp_api.hip routes accordingly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "acn_qp_tiled.hpp"
+
+namespace acnqp {
+
+constexpr int kStreamWaves = 8;
+
+struct StreamArgs {
+  TiledArgs t;          // same site / problem / result / option fields as the tiled kernel (fragG covers NP / 16 tiles)
+  double* work;         // [B][ws_per_problem]
+  long long ws_per_problem;
+};
+
+// doubles of workspace one problem needs
+__host__ __device__ inline long long stream_workspace(int NP, int CT, int K) {
+  const long long NT = (long long)(NP / 16) * CT * 256;
+  return 6 * NT + (long long)K * NP + 64;
+}
+
+// LDS carve-up (doubles)
+struct StreamLds {
+  int red, g0h, we, z2, y2, gx, scal, total;
+  __host__ __device__ StreamLds(int MT, int CT) {
+    int o = 0;
+    red = o;  o += kStreamWaves * CT * 256;
+    g0h = o;  o += MT * CT * 256;
+    we = o;   o += MT * CT * 256;
+    z2 = o;   o += MT * CT * 256;
+    y2 = o;   o += MT * CT * 256;
+    gx = o;   o += MT * CT * 256;
+    scal = o; o += kStreamWaves * 8 + 8;
+    total = o;
+  }
+};
+
+template <int NV>
+__device__ inline void stream_block_max(double (&v)[NV], double* S, int lane, int wave) {
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const double m = wave_max<double>(v[k]);
+    if (lane == 0) S[wave * 8 + k] = m;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    double m = S[k];
+    for (int wv = 1; wv < kStreamWaves; ++wv) m = fmax(m, S[wv * 8 + k]);
+    v[k] = m;
+  }
+  __syncthreads();
+}
+
+template <int CT, int MT>
+__global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const StreamArgs SA) {
+  using M = Mfma<double>;
+  using vec4 = M::vec4;
+  typedef double real;
+  const TiledArgs& A = SA.t;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  real* sm = reinterpret_cast<real*>(smem_raw);
+  const StreamLds L(MT, CT);
+  real* RED = sm + L.red;
+  real* G0H = sm + L.g0h;
+  real* WE = sm + L.we;
+  real* Z2 = sm + L.z2;
+  real* Y2 = sm + L.y2;
+  real* GX = sm + L.gx;
+  real* SC = sm + L.scal;
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  // wave index as a scalar: tile bases become SGPR addresses (global_load saddr + lane offset) instead of one 64-bit
+  // VGPR address per array, column tile and register
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // lane, g, t are re-derived from an opaque copy at the top of every tile iteration (RELANE): per-lane addresses
+  // (session table, multipliers, site-matrix columns) are then computed where they are used instead of being hoisted
+  // out of the solver loop and held -- or spilled -- across it
+  int lane = tid & 63;
+  int g = lane >> 4, t = lane & 15;
+#define RELANE() do { asm volatile("" : "+v"(lane)); g = lane >> 4; t = lane & 15; } while (0)
+  const int N = A.N, Tm = A.Tm, NP = A.NP, K = A.K;
+  const int NE = NP >> 4;                 // EVSE tiles
+  const long long NT = (long long)NE * CT * 256;
+  real* W0 = SA.work + (size_t)b * SA.ws_per_problem;
+  real *Xs = W0, *Z1s = Xs + NT, *Y1s = Z1s + NT, *Qs = Y1s + NT, *LBs = Qs + NT, *UBs = LBs + NT;
+  real* MU = UBs + NT;                    // [K][NP]
+  const real* FG = static_cast<const real*>(A.fragG);
+  const real* FQ = static_cast<const real*>(A.fragQ);
+  const real* Gm = static_cast<const real*>(A.G);
+  const real* Lm = static_cast<const real*>(A.lam);
+  const real* RL = static_cast<const real*>(A.rowlim);
+  const bool eq = A.s_eq[b] != 0;
+  const real sigma = A.sigma, alpha = A.alpha;
+  const real lfb = A.lf ? A.lf[b] / (A.flat_scale * A.flat_scale) : 0.0;
+
+  auto fidx = [&](int e, int c, int r) -> size_t { return ((size_t)(e * CT + c) * 4 + r) * 64 + lane; };
+
+  // ---- init: inputs -> fragment order; |q|_inf, max ub; a session whose bounds cannot meet its energy row ----------
+  real qn = 0, um = 0, bad = 0;
+#pragma unroll 1
+  for (int e = wave; e < NE; e += kStreamWaves) {
+    RELANE();
+    real lbv[CT][4], ubv[CT][4];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ev = 16 * e + M::rowof(g, r), tt = 16 * c + t;
+        const bool ok = ev < N && tt < Tm;
+        const size_t idx = ((size_t)b * N + (ok ? ev : 0)) * Tm + (ok ? tt : 0);
+        const real l = ok ? A.lb[idx] : 0.0;
+        real u = ok ? A.ub[idx] : 0.0;
+        const real q = ok ? A.q[idx] : 0.0;
+        if (u < l) u = l;
+        lbv[c][r] = l; ubv[c][r] = u;
+        LBs[fidx(e, c, r)] = l; UBs[fidx(e, c, r)] = u; Qs[fidx(e, c, r)] = q;
+        qn = fmax(qn, fabs(q)); um = fmax(um, u);
+      }
+#pragma unroll 1
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ev = 16 * e + M::rowof(g, r);
+        const size_t sidx = ((size_t)b * K + k) * N + (ev < N ? ev : 0);
+        const int off = ev < N ? A.s_off[sidx] : 0, len = ev < N ? A.s_len[sidx] : 0;
+        real sl = 0, su = 0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const int tp = 16 * c + t;
+          const bool inw = tp >= off && tp < off + len && tp < Tm;
+          sl += inw ? lbv[c][r] : 0.0; su += inw ? ubv[c][r] : 0.0;
+        }
+        sl = row_sum<real>(sl); su = row_sum<real>(su);
+        if (len > 0) {
+          const real cap = A.s_cap[sidx];
+          const real slack = 64.0 * M::proj_tol * fmax(1.0, fabs(cap));
+          if (sl > cap + slack || (eq && su < cap - slack)) bad = 1;
+        }
+        if (t == 0 && ev < NP) MU[(size_t)k * NP + ev] = 0;
+      }
+  }
+  real qnorm, pd;
+  const real pd_user = A.pdiag[b];
+  {
+    real f[3] = {qn, um, bad};
+    stream_block_max<3>(f, SC, lane, wave);
+    qnorm = f[0];
+    pd = effective_pdiag<real>(pd_user, A.reg_rel, qnorm, f[1], A.horizon[b], lfb > 0.0);
+    if (f[2] > 0) {
+      for (size_t k = tid; k < (size_t)N * Tm; k += kStreamWaves * 64) A.x[(size_t)b * N * Tm + k] = 0;
+      if (tid == 0) { A.status[b] = 4; A.iters[b] = 0; A.pri[b] = M::big; A.dua[b] = M::big; A.obj[b] = 0; }
+      return;
+    }
+  }
+
+  real rho = A.rho0;
+  vec4 pacc[MT][CT];   // this wave's share of Ghat (r0) -- or of Ghat z1 during the start
+
+  // ---- projection of ONE register row (one EVSE per 16-lane DPP row: EVSE 16 e + rowof(g, r), its periods = the 16
+  // lanes times the CT column registers) onto B = box + energy rows.  Same safeguarded Newton as the general-shape
+  // kernel / the C port.  One row at a time keeps only 3 * CT values live instead of 3 * 4 * CT. -----------------
+  auto project_row = [&](int e, int r, const real (&zh)[CT], const real (&lbv)[CT], const real (&ubv)[CT],
+                         real (&z1)[CT], bool reset_mu) __attribute__((always_inline)) {
+    const int ev = 16 * e + M::rowof(g, r);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) z1[c] = fmin(fmax(zh[c], lbv[c]), ubv[c]);
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+      const size_t sidx = ((size_t)b * K + k) * N + (ev < N ? ev : 0);
+      const int off = ev < N ? A.s_off[sidx] : 0;
+      int len = ev < N ? A.s_len[sidx] : 0;
+      if (off + len > Tm) len = Tm - off;
+      const real cap = ev < N ? A.s_cap[sidx] : 0.0;
+      real s0 = 0, sl = 0, su = 0, lo_l = M::big, hi_l = -M::big;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int tp = 16 * c + t;
+        const bool inw = tp >= off && tp < off + len;
+        s0 += inw ? z1[c] : 0.0;
+        sl += inw ? lbv[c] : 0.0;
+        su += inw ? ubv[c] : 0.0;
+        lo_l = inw ? fmin(lo_l, zh[c] - ubv[c]) : lo_l;
+        hi_l = inw ? fmax(hi_l, zh[c] - lbv[c]) : hi_l;
+      }
+      s0 = row_sum<real>(s0); sl = row_sum<real>(sl); su = row_sum<real>(su);
+      real lo = row_min<real>(lo_l), hi = row_max<real>(hi_l);
+      const real tol = M::proj_tol * fmax(1.0, fabs(cap));
+      const bool act = len > 0 && (eq ? fabs(s0 - cap) > tol : s0 > cap + tol);
+      const int mode = !act ? 4 : ((eq && cap >= su) ? 2 : (cap <= sl ? 3 : 0));   // 0 root-find, 2 at ub, 3 at lb, 4 nothing
+      bool need = mode == 0;
+      if (!eq && lo < 0) lo = 0;
+      const real mu0 = (reset_mu || ev >= N) ? 0.0 : MU[(size_t)k * NP + ev];
+      real m = fmin(fmax(mu0, lo), hi);
+#pragma unroll 1
+      for (int guard = 0; guard <= 100; ++guard) {
+        if (!__any(need)) break;
+        real gl = 0, nl = 0;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const int tp = 16 * c + t;
+          const bool inw = tp >= off && tp < off + len;
+          const real u = zh[c] - m;
+          gl += inw ? fmin(fmax(u, lbv[c]), ubv[c]) : 0.0;
+          nl += (inw && u > lbv[c] && u < ubv[c]) ? 1.0 : 0.0;
+        }
+        const real gs = row_sum<real>(gl), nf = row_sum<real>(nl);
+        const real d = gs - cap;
+        need = need && !(fabs(d) <= tol);
+        lo = (need && d > 0) ? m : lo;
+        hi = (need && !(d > 0)) ? m : hi;
+        real mn = nf > 0 ? m + d / nf : 0.5 * (lo + hi);
+        if (!(mn > lo && mn < hi)) mn = 0.5 * (lo + hi);
+        m = need ? mn : m;
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int tp = 16 * c + t;
+        if (tp >= off && tp < off + len) {
+          if (mode == 0) z1[c] = fmin(fmax(zh[c] - m, lbv[c]), ubv[c]);
+          else if (mode == 2) z1[c] = ubv[c];
+          else if (mode == 3) z1[c] = lbv[c];
+        }
+      }
+      if (t == 0 && ev < N) MU[(size_t)k * NP + ev] = (mode == 0 && !reset_mu) ? m : 0.0;
+    }
+  };
+
+  auto zero_pacc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int c = 0; c < CT; ++c) pacc[m][c] = vec4{0, 0, 0, 0};
+  };
+  // pacc += Ghat[:, tile e] * v   (v in C layout = MFMA B operand)
+  auto accumulate_tile = [&](int e, const real (&v)[4][CT]) __attribute__((always_inline)) {
+    const real* fg = FG + (size_t)e * MT * 2 * 4 * 64;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      real af[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) af[s] = fg[((m * 2 + 0) * 4 + s) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) pacc[m][c] = M::mma(af[s], v[s][c], pacc[m][c]);
+    }
+  };
+  // fixed-order reduction of the 8 waves' pacc into G0H (one row-tile round at a time through RED)
+  auto reduce_pacc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) RED[((wave * CT + c) * 4 + r) * 64 + lane] = pacc[m][c][r];
+      __syncthreads();
+      for (int c = wave; c < CT; c += kStreamWaves)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          real s = 0;
+#pragma unroll
+          for (int wv = 0; wv < kStreamWaves; ++wv) s += RED[((wv * CT + c) * 4 + r) * 64 + lane];
+          G0H[((m * CT + c) * 4 + r) * 64 + lane] = s;
+        }
+      __syncthreads();
+    }
+  };
+  // r0 of every tile from the stored state, pacc = this wave's share of Ghat r0 (start, and after a rho change)
+  auto rebuild_pacc = [&]() __attribute__((always_inline)) {
+    zero_pacc();
+  #pragma unroll 1
+  for (int e = wave; e < NE; e += kStreamWaves) {
+    RELANE();
+      real r0[4][CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t i = fidx(e, c, r);
+          r0[r][c] = sigma * Xs[i] - Qs[i] + rho * Z1s[i] - Y1s[i];
+        }
+      accumulate_tile(e, r0);
+    }
+  };
+
+  // ---- start (see acn_qp_tiled.hpp): z1 = Proj_B(-kStartGain q), x = z1, y1 = -(q + pd z1); z2 = G z1 = Q (Ghat z1) ---
+  zero_pacc();
+#pragma unroll 1
+  for (int e = wave; e < NE; e += kStreamWaves) {
+    RELANE();
+    real z1[4][CT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      real zs[CT], lbv[CT], ubv[CT], qv[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const size_t i = fidx(e, c, r);
+        qv[c] = Qs[i]; lbv[c] = LBs[i]; ubv[c] = UBs[i];
+        zs[c] = -kStartGain * qv[c];
+      }
+      project_row(e, r, zs, lbv, ubv, z1[r], true);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const size_t i = fidx(e, c, r);
+        Xs[i] = z1[r][c]; Z1s[i] = z1[r][c]; Y1s[i] = -(qv[c] + pd * z1[r][c]);
+      }
+    }
+    accumulate_tile(e, z1);
+  }
+  reduce_pacc();
+#pragma unroll 1
+  for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
+      RELANE();
+    const int mo = tl / CT, c = tl - mo * CT;
+    vec4 zt = {0, 0, 0, 0};
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        zt = M::mma(FQ[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane], G0H[((mi * CT + c) * 4 + s) * 64 + lane], zt);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
+      Z2[i] = zt[r]; GX[i] = zt[r]; Y2[i] = 0;
+    }
+  }
+  __syncthreads();
+  rebuild_pacc();
+
+  int status = 2, it = 0, n_adapt = 0;
+  real pri = M::big, dua = M::big;
+  bool done = false;
+#pragma unroll 1
+  while (!done) {
+    ++it;
+    const real a = sigma + pd + rho, inv_a = 1.0 / a, inv_rho = 1.0 / rho;
+    const bool check = (it % A.check_every == 0) || it >= A.max_iter;
+    // an offset the compiler cannot see through keeps the loads of loop-invariant site data (Q fragments, row
+    // constants) inside the loop, where they hit L1 / L2, instead of pinning ~150 registers across it
+    unsigned zoff = 0;
+    asm volatile("" : "+s"(zoff));
+    const real* FQi = FQ + zoff;
+    const real* Lmi = Lm + zoff;
+    const real* RLi = RL + zoff;
+    const int32_t* RTi = A.rowtype + zoff;
+    reduce_pacc();   // G0H = Ghat r0
+    // ---- eigen space, by the wave that owns each 16 x 16 site tile: e^ -> WE, h^ -> G0H --------------------------
+#pragma unroll 1
+    for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
+      RELANE();
+      const int mo = tl / CT, c = tl - mo * CT;
+      vec4 wh = {0, 0, 0, 0};
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int i = ((mi * CT + c) * 4 + s) * 64 + lane;
+          wh = M::mma(FQi[(((mo * MT + mi) * 2 + 0) * 4 + s) * 64 + lane], rho * Z2[i] - Y2[i], wh);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
+        const real lj = Lmi[16 * mo + M::rowof(g, r)];
+        const real g0 = G0H[i];
+        const real e_ = wh[r] - (rho / (a + rho * lj)) * (g0 + lj * wh[r]);
+        WE[i] = e_;
+        G0H[i] = (g0 + lj * e_) * inv_a;
+      }
+    }
+    __syncthreads();
+    // ---- site rows: G x~ = Q h^, relaxation, projection onto C, y2 (owner waves) ---------------------------------
+    real sv0 = 0, sv2 = 0;   // |G x - z2|_inf, max(|G x|, |z2|): the site-row share of the residuals
+#pragma unroll 1
+    for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
+      RELANE();
+      const int mo = tl / CT, c = tl - mo * CT;
+      vec4 zt = {0, 0, 0, 0};
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          zt = M::mma(FQi[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane], G0H[((mi * CT + c) * 4 + s) * 64 + lane], zt);
+      real zhr[4], lim[4];
+      int ty[4];
+      const int tt = 16 * c + t;
+      real pk = M::big;
+      if (A.peak && tt < Tm) { const double pv = A.peak[(size_t)b * Tm + tt]; pk = pv < M::big ? pv * A.peak_scale : M::big; }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
+        const int j = 16 * mo + M::rowof(g, r);
+        ty[r] = RTi[j]; lim[r] = RLi[j];
+        GX[i] = alpha * zt[r] + (1.0 - alpha) * GX[i];
+        zhr[r] = alpha * zt[r] + (1.0 - alpha) * Z2[i] + Y2[i] * inv_rho;
+      }
+      real scl[2] = {1.0, 1.0};
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+        if (ty[2 * pr] == kRowSocRe) {
+          const real re = zhr[2 * pr], im = zhr[2 * pr + 1];
+          const real n2 = re * re + im * im;
+          if (n2 > lim[2 * pr] * lim[2 * pr]) scl[pr] = lim[2 * pr] / sqrt(n2);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
+        real zn = zhr[r];
+        if (ty[r] == kRowBox) zn = fmin(zn, lim[r]);
+        else if (ty[r] == kRowPeak) zn = fmin(zn, pk);
+        else if (ty[r] == kRowQuad) zn = zn * (rho / (rho + lfb));
+        else if (ty[r] == kRowSocRe || ty[r] == kRowSocIm) zn = zn * scl[r >> 1];
+        Y2[i] = rho * (zhr[r] - zn);
+        Z2[i] = zn;
+        sv0 = fmax(sv0, fabs(GX[i] - zn));
+        sv2 = fmax(sv2, fmax(fabs(GX[i]), fabs(zn)));
+      }
+    }
+    __syncthreads();
+    // ---- the fused pass over this wave's EVSE tiles -------------------------------------------------------------
+    real v0 = sv0, v1 = 0, v2 = sv2, v4 = 0, v5 = 0;
+    zero_pacc();
+  #pragma unroll 1
+  for (int e = wave; e < NE; e += kStreamWaves) {
+    RELANE();
+      real zh[4][CT], sq[4][CT];   // sq = sigma x_new - q: all the new r0 still needs of x and q
+      const real* fg = FG + (size_t)e * MT * 2 * 4 * 64;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        real xv[4], z1o[4], y1o[4], qv[4];
+        vec4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t i = fidx(e, c, r);
+          xv[r] = Xs[i]; z1o[r] = Z1s[i]; y1o[r] = Y1s[i]; qv[r] = Qs[i];
+          acc[r] = sigma * xv[r] - qv[r] + rho * z1o[r] - y1o[r];
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            acc = M::mma(fg[((m * 2 + 1) * 4 + s) * 64 + lane], WE[((m * CT + c) * 4 + s) * 64 + lane], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const real xn = acc[r] * inv_a;
+          zh[r][c] = alpha * xn + (1.0 - alpha) * z1o[r] + y1o[r] * inv_rho;
+          const real xnew = alpha * xn + (1.0 - alpha) * xv[r];
+          Xs[fidx(e, c, r)] = xnew;
+          sq[r][c] = sigma * xnew - qv[r];
+        }
+      }
+      real v0t = 0, v2t = 0;   // this tile's |x - z1|, max(|x|, |z1|) (check iterations)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        real lbv[CT], ubv[CT], z1[CT];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) { const size_t i = fidx(e, c, r); lbv[c] = LBs[i]; ubv[c] = UBs[i]; }
+        project_row(e, r, zh[r], lbv, ubv, z1, false);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const size_t i = fidx(e, c, r);
+          const real y1n = rho * (zh[r][c] - z1[c]);
+          Z1s[i] = z1[c]; Y1s[i] = y1n;
+          zh[r][c] = sq[r][c] + rho * z1[c] - y1n;   // the new r0, in zh's registers
+        }
+      }
+      accumulate_tile(e, zh);
+      if (check) {   // residual terms of this tile (state re-read: L2-hot); (G' y2) tile by MFMA with the un-rotated site matrix
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          vec4 gty = {0, 0, 0, 0};
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              gty = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], Y2[((m * CT + c) * 4 + s) * 64 + lane], gty);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const size_t i = fidx(e, c, r);
+            const real xk = Xs[i], qk = Qs[i], yk = Y1s[i], zk = Z1s[i];
+            v0 = fmax(v0, fabs(xk - zk));
+            v1 = fmax(v1, fabs(pd * xk + qk + yk + gty[r]));
+            v2 = fmax(v2, fmax(fabs(xk), fabs(zk)));
+            v4 = fmax(v4, fabs(pd * xk));
+            v5 = fmax(v5, fabs(yk + gty[r]));
+          }
+        }
+      }
+      (void)v0t; (void)v2t;
+    }
+    if (check) {
+      real v[5] = {v0, v1, v2, v4, v5};
+      stream_block_max<5>(v, SC, lane, wave);
+      pri = v[0]; dua = v[1];
+      const real npri = v[2], ndua = fmax(fmax(v[3], v[4]), qnorm);
+      const real eps_p = A.eps_abs + A.eps_rel * npri, eps_d = A.eps_abs + A.eps_rel * ndua;
+      if (pri <= eps_p && dua <= eps_d) { status = 1; done = true; }
+      else if (it >= A.max_iter) {
+        done = true;
+        if (pri <= kInaccurate * eps_p && dua <= kInaccurate * eps_d) status = 5;
+      } else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
+        const real sp = pri / fmax(npri, 1e-12), sd = dua / fmax(ndua, 1e-12);
+        const real ratio = sqrt(sp / fmax(sd, 1e-30));
+        const real tol_eff = A.adapt_tol * (1.0 + (real)n_adapt * (1.0 / kAdaptWiden));
+        if (ratio > tol_eff || ratio < 1.0 / tol_eff) {
+          ++n_adapt;
+          rho = fmin(fmax(rho * ratio, 1e-6), 1e6);
+          __syncthreads();     // every wave's stores of this pass are visible before the state is re-read
+          rebuild_pacc();      // r0 depends on rho: this wave's share of Ghat r0 with the new penalty
+        }
+      }
+    }
+  }
+
+  // ---- results: the feasible iterate z1 is the schedule --------------------------------------------------------
+  __syncthreads();
+  real ol = 0;
+#pragma unroll 1
+  for (int e = wave; e < NE; e += kStreamWaves)
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ev = 16 * e + M::rowof(g, r), tt = 16 * c + t;
+        if (ev < N && tt < Tm) {
+          const size_t i = fidx(e, c, r);
+          const real z = Z1s[i];
+          A.x[((size_t)b * N + ev) * Tm + tt] = z;
+          ol += (0.5 * pd_user * z + Qs[i]) * z;
+        }
+      }
+  ol = wave_sum<real>(ol);
+  if (lane == 0) SC[wave] = ol;
+  __syncthreads();
+  if (tid == 0) {
+    real o = 0;
+    for (int wv = 0; wv < kStreamWaves; ++wv) o += SC[wv];
+    A.status[b] = status; A.iters[b] = it; A.pri[b] = pri; A.dua[b] = dua; A.obj[b] = o;
+  }
+}
+
+#undef RELANE
+}  // namespace acnqp

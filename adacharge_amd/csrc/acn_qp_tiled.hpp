@@ -78,6 +78,7 @@ struct TiledArgs {
   double peak_scale, flat_scale, max_scale;   // host-side row equilibration of the prox rows
   int max_iter, check_every, adapt_every;
   int accel_mem;   // Anderson-acceleration columns actually used (<= the kernel's AM, fits its LDS); 0 = off
+  int pbuf_single; // 1: one partial-tile slab instead of two (one more barrier per iteration, LDS for one more ring column)
 };
 
 template <typename real> struct Mfma;
@@ -171,9 +172,9 @@ constexpr int kXS = 18;   // row stride (reals) of the per-wave 16 x 16 transpos
 struct TiledLds {
   int pbuf, xpose, red, aared, aah, hist, total;   // offsets in reals; hist..total hold floats
   int hist1, hist2;                                // floats per history column: tile part, site-row part
-  __host__ __device__ TiledLds(int NW, int MT, int CT, int NP, int K, int AM, int accel_mem, int real_bytes) {
+  __host__ __device__ TiledLds(int NW, int MT, int CT, int NP, int K, int AM, int accel_mem, int real_bytes, int pbuf_single = 0) {
     int o = 0;
-    pbuf = o;  o += 2 * NW * MT * CT * 4 * 64;   // double-buffered partial tiles
+    pbuf = o;  o += (pbuf_single ? 1 : 2) * NW * MT * CT * 4 * 64;   // partial tiles (double-buffered unless pbuf_single)
     xpose = o; o += NW * CT * 16 * kXS;          // C layout <-> session layout, private to each wave
     red = o;   o += 16 * kNumRed + 8;
     aared = o; o += accel_mem > 0 ? NW * (AM + 2) : 0;          // per-wave partial dot products
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   const int g = lane >> 4, t = lane & 15;
   const int N = A.N, Tm = A.Tm, NP = A.NP, MR = A.MR;
   const int aa_m = AM > 0 ? min(A.accel_mem, AM) : 0;
-  const TiledLds L(NW, MT, CT, NP, A.K, AM, aa_m, (int)sizeof(real));
+  const TiledLds L(NW, MT, CT, NP, A.K, AM, aa_m, (int)sizeof(real), A.pbuf_single);
   real* Pbuf = sm + L.pbuf;
   real* Xw = sm + L.xpose + (size_t)wave * CT * 16 * kXS;   // this wave's transpose scratch
   real* Red = sm + L.red;
@@ -674,11 +675,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         for (int r = 0; r < 4; ++r) { z2[mo][c][r] = zt[r]; gx[mo][c][r] = zt[r]; up2[mo][c][r] = zt[r]; y2[mo][c][r] = 0; }
       }
     }
+    if (A.pbuf_single) __syncthreads();   // the start used the one slab the first iteration writes next
   }
 
   while (!done) {
     ++it;
-    real* Pw = Pbuf + (size_t)(it & 1) * NW * MT * CT * 256;
+    real* Pw = Pbuf + (size_t)(A.pbuf_single ? 0 : (it & 1)) * NW * MT * CT * 256;
     // Per-lane constants every predicate of the loop body derives from (row types, session windows, modes) are made
     // opaque once per iteration: the compiler then evaluates `rtype == kRowBox`, `(swm >> k) & 1` ... where they are
     // used (one v_cmp each) instead of hoisting dozens of loop-invariant lane masks into SGPR pairs, which it can
@@ -740,6 +742,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           eh[m][c][r] = e_;
           hh[m][c][r] = (g0 + lamv[m][r] * e_) * inv_a;
         }
+    if (A.pbuf_single) __syncthreads();   // every wave has read the one slab before the next iteration overwrites it
 
     STAMP(2);   // partial-tile sum, e^, h^
     // ---- x~ tile = (r0 + Ghat_w' e^)/a, relaxation, clip ------------------------------------

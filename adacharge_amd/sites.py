@@ -152,6 +152,53 @@ def random_sessions(
     return sessions
 
 
+def random_sessions_general(infra, horizon, rng, two_per_evse=False, min_rates=False, demand_scale=1.0,
+                            period=5) -> List[SessionInfo]:
+    """A harder snapshot than ``random_sessions``: delayed arrivals, optionally two sessions with disjoint
+    windows on 40 % of the EVSEs (aco.py:62-73 lets later sessions overwrite their own window, t_aco.py:194-208),
+    optionally minimum rates over a prefix of the window (t_aco.py:211-229) and stepped maximum rates."""
+    T = horizon
+    sessions = []
+    n = infra.num_stations
+    for i in rng.choice(n, size=int(rng.integers(n // 3, n + 1)), replace=False):
+        sid = infra.station_ids[int(i)]
+        k = float(infra.voltages[int(i)]) * period / 60 / 1e3
+        if two_per_evse and rng.random() < 0.4 and T >= 8:
+            cut = int(rng.integers(3, T - 3))
+            spans = [(0, cut), (cut + int(rng.integers(0, 2)), T)]
+        else:
+            a = int(rng.integers(0, max(1, T // 3)))
+            spans = [(a, int(rng.integers(a + 1, T + 1)))]
+        for j, (a, d) in enumerate(spans):
+            if d <= a:
+                continue
+            L = d - a
+            mins = np.zeros(L)
+            if min_rates and rng.random() < 0.3:
+                mins[: int(rng.integers(1, L + 1))] = 6.0
+            maxs = np.full(L, 32.0)
+            if rng.random() < 0.2:
+                maxs[int(rng.integers(0, L)):] = 16.0
+            dem = float(rng.uniform(0.2, 1.0) * demand_scale * 32 * L * k)
+            dem = max(dem, mins.sum() * k + 0.01)
+            sessions.append(SessionInfo(sid, f"{sid}-{j}", dem, 0.0, a, d, current_time=0, min_rates=mins, max_rates=maxs))
+    return sessions
+
+
+def eight_sites() -> List[InfrastructureInfo]:
+    """The 8 sites of BASELINE.json configs[3] ("1024 demand scenarios x 8 sites"): the Caltech-shaped and the
+    synthetic 52-EVSE site plus six synthetic three-phase sites of 30-64 EVSEs (all *synthetic*)."""
+    out = [caltech54(), jpl52()]
+    for k, (n, pods, frac) in enumerate([(30, 2, 0.5), (36, 3, 0.4), (42, 3, 0.45), (48, 4, 0.35), (60, 5, 0.4), (64, 4, 0.3)]):
+        out.append(balanced_three_phase(n, pods=pods, load_fraction=frac, name=f"S{k}"))
+    return out
+
+
+def wide128() -> InfrastructureInfo:
+    """Synthetic 128-EVSE three-phase site (general-shape kernel: N > 64)."""
+    return balanced_three_phase(128, pods=6, load_fraction=0.4, name="WD")
+
+
 def snapshot_batch(
     infra: InfrastructureInfo,
     horizon: int,

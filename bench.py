@@ -50,7 +50,7 @@ def parse(argv=None):
     ap.add_argument("--batches", type=int, default=64, help="batches per GPU per step (one acnqp_solve_batches call)")
     ap.add_argument("--horizon", type=int, default=12)
     ap.add_argument("--constraint-type", default="SOC", choices=["SOC", "LINEAR"])
-    ap.add_argument("--precision", type=int, default=64, choices=[64, 32])
+    ap.add_argument("--precision", type=int, default=64, choices=[64])
     ap.add_argument("--pageable", action="store_true", help="problem / result arrays in pageable host memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -289,15 +289,10 @@ def main():
     # the device-pointer entry, HIP events around it (what `value` would be with free copies)
     kernel_only = None
     if rank == 0:
-        import copy
-
         from adacharge_amd.backend import DeviceBatch
+        from adacharge_amd.builder import ProblemBatch
 
-        big = copy.copy(batches[0])
-        big.B = per_step
-        for name in ("T", "lb", "ub", "q", "pdiag", "lf", "s_off", "s_len", "s_cap", "s_eq", "dc", "dfloor"):
-            setattr(big, name, np.concatenate([getattr(b, name) for b in batches]))
-        dbig = DeviceBatch(big, dev)
+        dbig = DeviceBatch(ProblemBatch.concatenate(batches), dev)
         ms = []
         for _ in range(3):
             handle.solve_device(dbig, opts, stream=torch.cuda.current_stream().cuda_stream)

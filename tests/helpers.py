@@ -79,3 +79,33 @@ def infrastructure_violation(rates, infrastructure):
 
 def assert_infrastructure_satisfied(rates, infrastructure, tol=1e-3):
     assert infrastructure_violation(rates, infrastructure) <= tol
+
+
+# ---- second fixture file: kernel variants and constraint families beyond caltech54 / T = 12 / inequality ----------
+WIDE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wide.npz")
+
+
+def load_wide():
+    return np.load(WIDE, allow_pickle=False)
+
+
+def wide_case(g, name):
+    """Rebuild fixture ``name`` of wide.npz (tools/make_golden_wide.py): returns
+    (sessions, infrastructure, interface, meta dict, peak_limit, expected dict)."""
+    infra = getattr(sites, str(g[f"{name}_site"]))()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    st, arr, dep = g[f"{name}_station"], g[f"{name}_arrival"], g[f"{name}_departure"]
+    minr, maxr = g[f"{name}_minr"], g[f"{name}_maxr"]
+    sessions, o = [], 0
+    for k in range(len(st)):
+        L = int(dep[k] - arr[k])
+        sessions.append(SessionInfo(infra.station_ids[int(st[k])], f"s{k}", float(g[f"{name}_demand"][k]), 0.0,
+                                    int(arr[k]), int(dep[k]), current_time=0,
+                                    min_rates=minr[o:o + L].copy(), max_rates=maxr[o:o + L].copy()))
+        o += L
+    m = g[f"{name}_meta"]
+    meta = dict(T=int(m[0]), ct="SOC" if m[1] else "LINEAR", eq=bool(m[2]), es=float(m[3]), seed=int(m[4]))
+    pk = g[f"{name}_peak"]
+    peak = None if np.isnan(pk[0]) else (float(pk[0]) if len(pk) == 1 else pk.copy())
+    exp = dict(rates=g[f"{name}_rates"], obj=float(g[f"{name}_obj"]))
+    return sessions, infra, iface, meta, peak, exp

@@ -31,7 +31,6 @@ for site_name in ("caltech54", "jpl52"):
     infra = getattr(sites, site_name)()
     iface = Interface({"infrastructure_info": infra, "period": 5})
     batch = build_batch(sites.snapshot_batch(infra, 24, 4096, seed=3), infra, iface, qc, "SOC")
-    run(f"cfg3 {site_name} T=24 fp32 eps 5e-5", batch, default_options(precision=32, eps_abs=5e-5, eps_rel=5e-5))
     run(f"cfg3 {site_name} T=24 fp64 eps 1e-8", batch, default_options())
 # configs[3]: 1024 demand scenarios of one site snapshot (one GPU's share of 8 sites x 1024)
 infra = sites.caltech54()
