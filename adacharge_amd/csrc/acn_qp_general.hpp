@@ -487,8 +487,9 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
         }
       }
       if (!done) {   // snapshot for the next certificate test
-        for (int k = tid; k < n; k += kGenThreads) y1p[k] = y1[k];
-        for (int k = tid; k < mt; k += kGenThreads) y2p[k] = y2[k];
+        // rounded to single precision like the tiled kernel's register snapshot (one certificate rule everywhere)
+        for (int k = tid; k < n; k += kGenThreads) y1p[k] = (real)(float)y1[k];
+        for (int k = tid; k < mt; k += kGenThreads) y2p[k] = (real)(float)y2[k];
         have_prev = true;
       }
       if (done) {

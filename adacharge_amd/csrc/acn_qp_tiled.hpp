@@ -170,13 +170,14 @@ __device__ inline double rcp_small(float nf) {
 // LDS carve-up in units of `real`; shared by host (size) and device (offsets)
 constexpr int kXS = 18;   // row stride (reals) of the per-wave 16 x 16 transpose scratch: 16-B aligned quads
 struct TiledLds {
-  int pbuf, xpose, red, aared, aah, hist, total;   // offsets in reals; hist..total hold floats
+  int pbuf, xpose, red, rowc, aared, aah, hist, total;   // offsets in reals; hist..total hold floats
   int hist1, hist2;                                // floats per history column: tile part, site-row part
   __host__ __device__ TiledLds(int NW, int MT, int CT, int NP, int K, int AM, int accel_mem, int real_bytes, int pbuf_single = 0) {
     int o = 0;
     pbuf = o;  o += (pbuf_single ? 1 : 2) * NW * MT * CT * 4 * 64;   // partial tiles (double-buffered unless pbuf_single)
     xpose = o; o += NW * CT * 16 * kXS;          // C layout <-> session layout, private to each wave
     red = o;   o += 16 * kNumRed + 8;
+    rowc = o;  o += 3 * 16 * MT;                 // per site row: eigenvalue, limit, rho / (a + rho lam)
     aared = o; o += accel_mem > 0 ? NW * (AM + 2) : 0;          // per-wave partial dot products
     aah = o;   o += accel_mem > 0 ? NW * (AM * AM + AM) : 0;    // per-wave copy of the Gram matrix and rhs
     o = (o + 1) & ~1;
@@ -299,17 +300,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   //   aQt[mo][mi][s] = Q[16mi + rowof(g,s)][16mo + t']      (w^ = Q' w)
   //   aQ[mo][mi][s]  = Q[16mo + t'][16mi + rowof(g,s)]      (G x~ = Q h^)
   // site-row constants in C layout: row j = 16 m + rowof(g, r)
-  real lamv[MT][4], djv[MT][4], limv[MT][4];
+  // per-row constants (eigenvalue, limit, D = rho / (a + rho lam)) live in a small LDS table, not in 24 registers
+  real* RowLam = sm + L.rowc;
+  real* RowLim = RowLam + 16 * MT;
+  real* RowDj = RowLim + 16 * MT;
   int rtype[MT][4];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = 16 * m + M::rowof(g, r);
-      lamv[m][r] = Lm[j];
-      limv[m][r] = RL[j];
-      rtype[m][r] = A.rowtype[j];
-    }
+    for (int r = 0; r < 4; ++r) rtype[m][r] = A.rowtype[16 * m + M::rowof(g, r)];
+  for (int j = tid; j < 16 * MT; j += NW * 64) { RowLam[j] = Lm[j]; RowLim[j] = RL[j]; }
 
   // ---- problem data -> registers (C layout) --------------------------------------------
   real x[CT][4], z1[CT][4], y1[CT][4], qv[CT][4], lbv[CT][4], ubv[CT][4];
@@ -434,22 +434,23 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
       for (int r = 0; r < 4; ++r) { z2[m][c][r] = 0; y2[m][c][r] = 0; gx[m][c][r] = 0; }
 
   real a = sigma + pd + rho, inv_a = (real)1 / a, inv_rho = (real)1 / rho;
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) djv[m][r] = rho / (a + rho * lamv[m][r]);
+  __syncthreads();
+  for (int j = tid; j < 16 * MT; j += NW * 64) RowDj[j] = rho / (a + rho * RowLam[j]);
+  __syncthreads();
 
   int status = 2, it = 0, n_adapt = 0;
   real pri = M::big, dua = M::big;
   bool done = false, have_prev = false;
-  real y1p[CT][4], y2p[MT][CT][4];   // duals at the previous residual check (infeasibility certificate)
+  // duals at the previous residual check (infeasibility certificate), kept in single precision: the certificate asks
+  // whether v = y - y_prev is a ray (large, A'v ~ 0, negative support); 2^-24 |y| of rounding cannot fake one
+  float y1p[CT][4], y2p[MT][CT][4];
 #pragma unroll
   for (int c = 0; c < CT; ++c)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      y1p[c][r] = 0;
+      y1p[c][r] = 0.f;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) y2p[m][c][r] = 0;
+      for (int m = 0; m < MT; ++m) y2p[m][c][r] = 0.f;
     }
   const real ptol_scale = M::proj_tol;
 
@@ -738,9 +739,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
           for (int wv = 0; wv < NW; ++wv) g0 += Pw[(((wv * MT + m) * CT + c) * 4 + r) * 64 + lane];
           const real w_ = wh[m][c][r];
-          const real e_ = w_ - djv[m][r] * (g0 + lamv[m][r] * w_);
+          const real lam_ = RowLam[16 * m + M::rowof(g, r)];
+          const real e_ = w_ - RowDj[16 * m + M::rowof(g, r)] * (g0 + lam_ * w_);
           eh[m][c][r] = e_;
-          hh[m][c][r] = (g0 + lamv[m][r] * e_) * inv_a;
+          hh[m][c][r] = (g0 + lam_ * e_) * inv_a;
         }
     if (A.pbuf_single) __syncthreads();   // every wave has read the one slab before the next iteration overwrites it
 
@@ -985,7 +987,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
           if (rtype[mo][2 * pr] == kRowSocRe) {
-            const real re = zhr[mo][c][2 * pr], im = zhr[mo][c][2 * pr + 1], lim = limv[mo][2 * pr];
+            const real re = zhr[mo][c][2 * pr], im = zhr[mo][c][2 * pr + 1], lim = RowLim[16 * mo + M::rowof(g, 2 * pr)];
             const real n2 = re * re + im * im;
             if (n2 > lim * lim) scl[pr] = lim * rsqrt_nr(n2);
           }
@@ -995,7 +997,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           const real zh_ = zhr[mo][c][r];
           real zn = zh_;
           const int ty = rtype[mo][r];
-          if (ty == kRowBox) zn = fmin(zh_, limv[mo][r]);
+          if (ty == kRowBox) zn = fmin(zh_, RowLim[16 * mo + M::rowof(g, r)]);
           else if (ty == kRowPeak) zn = fmin(zh_, pk[c]);
           else if (ty == kRowQuad) zn = zh_ * (rho / (rho + lfb));
           // kRowMax: zn = zh_ here; the horizon-wide prox follows the tile loop
@@ -1154,13 +1156,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
                 for (int r = 0; r < 4; ++r) {
                   const real v2 = y2[m][c][r] - y2p[m][c][r];
                   const int ty = rtype[m][r];
-                  if (ty == kRowBox) { ssum += limv[m][r] * fmax(v2, (real)0); if (v2 < -vtol) bad = 1; }
+                  if (ty == kRowBox) { ssum += RowLim[16 * m + M::rowof(g, r)] * fmax(v2, (real)0); if (v2 < -vtol) bad = 1; }
                   else if (ty == kRowPeak) {
                     if (pk[c] < M::big) ssum += pk[c] * fmax(v2, (real)0); else if (v2 > vtol) bad = 1;
                     if (v2 < -vtol) bad = 1;
                   } else if (ty == kRowSocRe) {
                     const real vi = y2[m][c][(r + 1) & 3] - y2p[m][c][(r + 1) & 3];
-                    ssum += limv[m][r] * sqrt(v2 * v2 + vi * vi);
+                    ssum += RowLim[16 * m + M::rowof(g, r)] * sqrt(v2 * v2 + vi * vi);
                   } else if (ty == kRowSocIm) {
                   } else if (fabs(v2) > vtol) bad = 1;   // free / quadratic rows admit no ray
                 }
@@ -1235,13 +1237,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) y1p[c][r] = y1[c][r];
+          for (int r = 0; r < 4; ++r) y1p[c][r] = (float)y1[c][r];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y2p[m][c][r] = y2[m][c][r];
+            for (int r = 0; r < 4; ++r) y2p[m][c][r] = (float)y2[m][c][r];
         have_prev = true;
       }
       if (done) {
@@ -1260,10 +1262,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           a = sigma + pd + rho;
           inv_a = (real)1 / a;
           inv_rho = (real)1 / rho;
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) djv[m][r] = rho / (a + rho * lamv[m][r]);
+          for (int j = tid; j < 16 * MT; j += NW * 64) RowDj[j] = rho / (a + rho * RowLam[j]);
+          __syncthreads();   // block-uniform branch: every wave sees the new D before the next iteration
           if constexpr (AM > 0) {
             if (aa_m > 0) {   // the fixed-point map changed: restart the ring from the current (z, y)
               aa_cnt = 0; aa_head = 0; aa_valid = 0; aa_have_prev = false; aa_was = false;

@@ -421,8 +421,9 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
         }
       }
       if (!done) {
-        memcpy(yprev, y1, sizeof(double) * n);
-        memcpy(yprev + n, y2, sizeof(double) * mt);
+        /* the device keeps this snapshot in single precision (registers): same rounding here */
+        for (int k = 0; k < n; ++k) yprev[k] = (double)(float)y1[k];
+        for (int k = 0; k < mt; ++k) yprev[n + k] = (double)(float)y2[k];
         have_yprev = 1;
       }
       if (done) {

@@ -1,7 +1,8 @@
-"""Turn the rocprofv3 output of tools/profile_r01.sh (gpurun_out/prof_<tag>/) into the committed
-summaries under profiles/: <tag>_kernel_stats.csv, <tag>_pmc_summary.json, hbm_traffic.json.
+"""Turn the rocprofv3 output of tools/profile_r02.sh (gpurun_out/prof_<tag>/) into the committed
+summaries under profiles/: <tag>_kernel_stats.csv, <tag>_pmc_summary.json, <traffic file>.
 
-    python tools/summarise_profile.py r01c
+    python tools/summarise_profile.py r02a_bench admm_tiled_kernel hbm_traffic.json
+    python tools/summarise_profile.py r02a_cfg5 admm_stream_kernel r02a_cfg5_traffic.json
 """
 import csv
 import glob
@@ -11,10 +12,11 @@ import shutil
 import sys
 
 tag = sys.argv[1]
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "admm_tiled_kernel"
+TRAFFIC_FILE = sys.argv[3] if len(sys.argv) > 3 else "hbm_traffic.json"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
-KERNEL = "admm_tiled_kernel"
 
 stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 if stats:   # newest run only (gpurun merges, it does not delete)
@@ -40,8 +42,7 @@ for f in sorted(newest.values()):
         v = list(d.values())
         summary[name] = {"dispatches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
 summary["_kernel"] = meta
-summary["_command"] = ("rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --steps 16 --warmup 8 "
-                       "--no-cpu-baseline (one pass per counter group, tools/profile_r01.sh)")
+summary["_command"] = "rocprofv3 --pmc <counter> --output-format csv -- python3 <program> (one pass per counter group, tools/profile_r02.sh)"
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
 if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
     fk, wk = summary["FETCH_SIZE"]["mean"], summary["WRITE_SIZE"]["mean"]
@@ -52,5 +53,5 @@ if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
                       "streaming read -> doubled; WRITE_SIZE exact; KB = 1024 B",
         "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
         "raw_uncorrected_bytes_per_launch": (fk + wk) * 1024,
-    }, open(os.path.join(dst, "hbm_traffic.json"), "w"), indent=1)
+    }, open(os.path.join(dst, TRAFFIC_FILE), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if not k.startswith("_")}, indent=1)[:3000])
