@@ -151,27 +151,71 @@ class AdaptiveSchedulingAlgorithm(BaseAlgorithm):
             station_id: rates_matrix[i, :] for i, station_id in enumerate(infrastructure.station_ids)
         }
 
-    def schedule_batch(self, session_lists, peak_limits=None):
-        """Batched extension: one schedule dict per state snapshot, all
-        optimisation problems solved by a single kernel launch.  Snapshots whose
-        solve does not end optimal yield ``None``."""
-        infrastructure = self.interface.infrastructure_info()
-        pre = [self._preprocess(sl, infrastructure) if len(sl) else sl for sl in session_lists]
-        if peak_limits is None:
-            peak_limits = [self._trimmed_peak(sl) if len(sl) else None for sl in pre]
-        rates, status = self._optimizer().solve_batch(
-            pre, infrastructure, peak_limits=peak_limits,
-            prev_peak=self.interface.get_prev_peak(), verbose=self.verbose,
+    def schedule_batch(self, session_lists, peak_limits=None, as_arrays=False):
+        """Batched extension: one schedule per state snapshot, every optimisation problem solved by one pipelined
+        pass of the HIP library, and the steps either side of the solve -- the pre-processing of ada.py:141-150 and
+        the post-processing of ada.py:176-189 -- done as array operations over the whole batch
+        (session_table.py, postprocessing.*_batch).  ``session_lists``: a list of SessionInfo lists, or a
+        ``SessionTable`` (no Python objects at all).  Returns one ``{station_id: ndarray}`` dict per snapshot
+        (``{}`` for an empty one, ``None`` where the solve did not end optimal), or, with ``as_arrays=True``,
+        ``(rates (B, N, Tmax), status (B,))``."""
+        from . import session_table as st
+        from .postprocessing import (
+            diff_based_reallocation_batch,
+            project_into_continuous_feasible_pilots_batch,
+            project_into_discrete_feasible_pilots_batch,
         )
-        out = []
-        for sl, r, st in zip(pre, rates, status):
-            if len(sl) == 0:
-                out.append({})
-            elif st not in (1, 5):   # OPTIMAL / OPTIMAL_INACCURATE, as aco.py:319
-                out.append(None)
+
+        infrastructure = self.interface.infrastructure_info()
+        if isinstance(session_lists, st.SessionTable):
+            table, B, nonempty, lists = session_lists, session_lists.B, np.arange(session_lists.B), None
+        else:
+            B = len(session_lists)
+            nonempty = np.array([k for k, sl in enumerate(session_lists) if len(sl) > 0], dtype=np.int64)
+            lists = [session_lists[k] for k in nonempty]
+            table = st.SessionTable.from_sessions(lists, infrastructure) if len(nonempty) else None
+        status = np.full(B, 1, dtype=np.int32)
+        if table is None:
+            return (np.zeros((B, infrastructure.num_stations, 1)), status) if as_arrays else [{} for _ in range(B)]
+        table = st.enforce_pilot_limit(table, infrastructure)                       # ada.py:141
+        if self.estimate_max_rate:                                                  # ada.py:143-146
+            if lists is None:
+                raise ValueError("estimate_max_rate needs SessionInfo lists (the estimator API takes sessions)")
+            table = st.apply_upper_bound_estimate(table, [self.max_rate_estimator.get_maximum_rates(sl) for sl in lists])
+        if self.uninterrupted_charging:                                             # ada.py:147-150
+            table = st.apply_minimum_charging_rate(table, infrastructure, self.interface.period)
+        if peak_limits is None:                                                     # ada.py:160-167
+            if self.peak_limit is None or np.isscalar(self.peak_limit):
+                pl = [self.peak_limit] * table.B
             else:
-                r = self._postprocess(r, sl, infrastructure)
-                out.append({sid: r[i, :] for i, sid in enumerate(infrastructure.station_ids)})
+                end = np.zeros(table.B, dtype=np.int64)
+                np.maximum.at(end, table.prob, table.off + table.rem)
+                t = self.interface.current_time
+                pl = [self.peak_limit[t : t + int(e)] for e in end]
+        else:
+            pl = [peak_limits[k] for k in nonempty]
+        res, batch = self._optimizer().solve_table(table, infrastructure, pl, self.interface.get_prev_peak())
+        if self.quantize:                                                           # ada.py:176-184
+            if self.reallocate:
+                r = diff_based_reallocation_batch(res.x, table, infrastructure, self.interface)
+            else:
+                r = project_into_discrete_feasible_pilots_batch(res.x, infrastructure)
+        else:                                                                       # ada.py:185-188
+            r = project_into_continuous_feasible_pilots_batch(res.x, infrastructure)
+        r = np.maximum(r, 0)                                                        # ada.py:189
+        if as_arrays:
+            rates = np.zeros((B,) + r.shape[1:])
+            rates[nonempty] = r
+            status[nonempty] = res.status
+            return rates, status
+        out = [{} for _ in range(B)]
+        ids = infrastructure.station_ids
+        for j, k in enumerate(nonempty):
+            if res.status[j] not in (1, 5):   # OPTIMAL / OPTIMAL_INACCURATE, as aco.py:319
+                out[k] = None
+            else:
+                rj = r[j, :, : int(batch.T[j])]
+                out[k] = {sid: rj[i] for i, sid in enumerate(ids)}
         return out
 
 

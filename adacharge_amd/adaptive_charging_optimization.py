@@ -331,6 +331,31 @@ class AdaptiveChargingOptimization:
             )
         return rates[0]
 
+    def solve_table(self, table, infrastructure, peak_limits=None, prev_peak=0, _defaults: Optional[dict] = None):
+        """Batched solve of a ``session_table.SessionTable`` (every snapshot non-empty): the array-native entry --
+        no Python loop over sessions anywhere on the path.  Returns ``(backend.BatchResult, ProblemBatch)``."""
+        from . import backend
+        from .builder import _bad_constraint_type, _objective_needs_flat, _objective_needs_max, build_batch_from_table
+
+        if self.constraint_type not in ("SOC", "LINEAR"):
+            _bad_constraint_type(self.constraint_type)
+        pl = [None] * table.B if peak_limits is None else list(peak_limits)
+        site, handle = _site_handle(
+            infrastructure, self.constraint_type, any(p is not None for p in pl), self.device,
+            with_flat=_objective_needs_flat(self.objective_configuration),
+            with_max=_objective_needs_max(self.objective_configuration),
+        )
+        batch = build_batch_from_table(
+            table, infrastructure, self.interface, self.objective_configuration, self.constraint_type,
+            self.enforce_energy_equality, peak_limits=pl, prev_peak=prev_peak, site=site,
+        )
+        opts = dict(_defaults or {})
+        opts.update(self.solver_options)
+        res = handle.solve(batch, backend.default_options(**opts))
+        self.last_result = res
+        self.last_batch = batch   # the structured problems behind last_result (diagnostics, tests)
+        return res, batch
+
     def solve_batch(
         self,
         session_lists: Sequence[Sequence],
@@ -359,24 +384,10 @@ class AdaptiveChargingOptimization:
         if not nonempty:
             return rates, status
         pl = [None] * B if peak_limits is None else list(peak_limits)
-        any_peak = any(pl[k] is not None for k in nonempty)
-        from .builder import _objective_needs_flat, _objective_needs_max
+        from .session_table import SessionTable
 
-        site, handle = _site_handle(
-            infrastructure, self.constraint_type, any_peak, self.device,
-            with_flat=_objective_needs_flat(self.objective_configuration),
-            with_max=_objective_needs_max(self.objective_configuration),
-        )
-        batch = build_batch(
-            [session_lists[k] for k in nonempty], infrastructure, self.interface,
-            self.objective_configuration, self.constraint_type, self.enforce_energy_equality,
-            peak_limits=[pl[k] for k in nonempty], prev_peak=prev_peak, site=site,
-        )
-        opts = dict(_defaults or {})
-        opts.update(self.solver_options)
-        res = handle.solve(batch, backend.default_options(**opts))
-        self.last_result = res
-        self.last_batch = batch   # the structured problems behind last_result (diagnostics, tests)
+        table = SessionTable.from_sessions([session_lists[k] for k in nonempty], infrastructure)
+        res, batch = self.solve_table(table, infrastructure, [pl[k] for k in nonempty], prev_peak, _defaults)
         if verbose:
             for j, k in enumerate(nonempty):
                 print(

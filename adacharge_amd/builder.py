@@ -256,11 +256,33 @@ def build_batch(
 ) -> ProblemBatch:
     """One structured QP per entry of ``session_lists`` (all on one site).  ``alloc(shape, dtype)`` allocates the
     arrays the C ABI reads (default ``np.zeros``; ``backend.pinned_empty`` puts them in pinned host memory so the
-    library copies them by DMA without a staging hop)."""
+    library copies them by DMA without a staging hop).  One pass over the session objects
+    (``SessionTable.from_sessions``), then array work only (``build_batch_from_table``)."""
+    from .session_table import SessionTable
+
+    table = SessionTable.from_sessions(session_lists, infrastructure)
+    return build_batch_from_table(table, infrastructure, interface, objective, constraint_type, enforce_energy_equality,
+                                  peak_limits, prev_peak, site, alloc)
+
+
+def build_batch_from_table(
+    table,
+    infrastructure,
+    interface,
+    objective,
+    constraint_type: str = "SOC",
+    enforce_energy_equality: bool = False,
+    peak_limits: Optional[Sequence] = None,
+    prev_peak=0,
+    site: Optional[SiteData] = None,
+    alloc=None,
+) -> ProblemBatch:
+    """The structured batch of a ``SessionTable`` (every snapshot needs at least one session) with no Python loop
+    over sessions: bounds by ragged scatter (aco.py:61-79), energy rows by group ranking (aco.py:105-123), the
+    objective once per distinct horizon (aco.py:200-218, 243-245)."""
     if alloc is None:
         alloc = lambda shape, dtype=np.float64: np.zeros(shape, dtype)
-    B = len(session_lists)
-    N = len(infrastructure.station_ids)
+    B, N = table.B, len(infrastructure.station_ids)
     if peak_limits is None:
         peak_limits = [None] * B
     any_peak = any(p is not None for p in peak_limits)
@@ -274,24 +296,17 @@ def build_batch(
         raise ValueError("site was built without the aggregate-power row but the objective uses load_flattening")
     elif any_peak and not site.has_peak:
         raise ValueError("site was built without a peak row but a peak_limit was given")
-    station_index = {s: i for i, s in enumerate(infrastructure.station_ids)}
-    # one pass over the session objects: (EVSE index, arrival offset, remaining time, session)
-    records = [
-        [(station_index[s.station_id], int(s.arrival_offset), int(s.remaining_time), s) for s in sl]
-        for sl in session_lists
-    ]
+    S = table.S
+    prob, evse, off, rem = table.prob, table.evse, table.off, table.rem
+    if S == 0 or len(np.unique(prob)) != B:
+        raise ValueError("every snapshot of a batch needs at least one session (aco.py:310-311 handles the empty case)")
     Ts = alloc(B, np.int32)
-    Ts[:] = [max(o + r for _, o, r, _ in rec) for rec in records]  # aco.py:243-245
-    Tm = int(Ts.max())
+    end = np.zeros(B, dtype=np.int64)
+    np.maximum.at(end, prob, off + rem)            # aco.py:243-245
+    Ts[:] = end
+    Tm = int(end.max())
     volt = np.asarray(infrastructure.voltages, float)
-    period = interface.period
-    kwh_per_amp_period = volt * period / 1e3 / 60  # aco.py:114
-
-    # sessions per EVSE
-    K = 1
-    for rec in records:
-        cnt = np.bincount([i for i, _, _, _ in rec], minlength=N)
-        K = max(K, int(cnt.max()))
+    kwh_per_amp_period = volt * interface.period / 1e3 / 60   # aco.py:114
 
     lb = alloc((B, N, Tm), np.float64)
     ub = alloc((B, N, Tm), np.float64)
@@ -301,9 +316,6 @@ def build_batch(
     const = np.zeros(B)
     dc = alloc(B, np.float64)
     dfloor = alloc(B, np.float64)
-    s_off = alloc((B, K, N), np.int32)
-    s_len = alloc((B, K, N), np.int32)
-    s_cap = alloc((B, K, N), np.float64)
     s_eq = alloc(B, np.uint8)
     s_eq[:] = 1 if enforce_energy_equality else 0
     peak = None
@@ -311,44 +323,62 @@ def build_batch(
         peak = alloc((B, Tm), np.float64)
         peak[:] = np.inf
     presolve = np.zeros(B, dtype=np.int32)
-    terms_by_horizon = {}   # the objective depends on the problem only through its horizon
 
-    for b, rec in enumerate(records):
-        T = int(Ts[b])
-        slot = [0] * N
-        windows = {}   # EVSE -> windows already placed (only consulted when an EVSE hosts a second session)
-        lbb, ubb = lb[b], ub[b]
-        for i, o, r, s in rec:  # aco.py:62-73
-            lbb[i, o : o + r] = s.min_rates
-            ubb[i, o : o + r] = s.max_rates
-        np.maximum(ubb, lbb, out=ubb)  # aco.py:75
-        for i, o, r, s in rec:  # aco.py:105-123
-            if r <= 0:
-                # empty window: 0 <= (==) remaining_demand
-                if s.remaining_demand < 0 or (enforce_energy_equality and s.remaining_demand != 0):
-                    presolve[b] = 1
-                continue
-            k = slot[i]
-            if k:
-                if any(o < o2 + r2 and o2 < o + r for o2, r2 in windows[i]):
-                    raise ValueError(
-                        f"sessions on EVSE {s.station_id} overlap in time; the structured "
-                        "builder needs disjoint session windows per EVSE"
-                    )
-                windows[i].append((o, r))
-            else:
-                windows[i] = [(o, r)]
-            slot[i] = k + 1
-            s_off[b, k, i] = o
-            s_len[b, k, i] = r
-            s_cap[b, k, i] = s.remaining_demand / kwh_per_amp_period[i]
-        if T not in terms_by_horizon:
-            terms_by_horizon[T] = objective_terms(objective, infrastructure, interface, N, T, prev_peak)
-        qb, pd, lfc, c0, dcw, dfl = terms_by_horizon[T]
-        q[b, :, :T] = qb
-        pdiag[b], lf[b], const[b], dc[b], dfloor[b] = pd, lfc, c0, dcw, dfl
-        if peak is not None and peak_limits[b] is not None:  # aco.py:196-198
-            peak[b, :T] = np.broadcast_to(np.asarray(peak_limits[b], float), (T,))
+    # ---- bounds (aco.py:62-75): session s writes its rate vectors into [off, off + rem) of its EVSE's row --------
+    rlen = np.diff(table.seg)
+    if np.any(rlen != np.maximum(rem, 0)):
+        raise ValueError("min_rates / max_rates must have one entry per remaining period (aco.py:68, 73)")
+    owner = np.repeat(np.arange(S), rlen)
+    j = np.arange(len(owner)) - np.repeat(table.seg[:-1], rlen)
+    flat = (prob[owner] * N + evse[owner]) * Tm + off[owner] + j
+    lb.reshape(-1)[flat] = table.min_rates
+    ub.reshape(-1)[flat] = table.max_rates
+    np.maximum(ub, lb, out=ub)   # aco.py:75
+
+    # ---- energy rows (aco.py:105-123): slot k = rank of the session among its EVSE's sessions of that snapshot ---
+    live = np.flatnonzero(rem > 0)
+    dead = np.flatnonzero(rem <= 0)
+    if len(dead):   # empty window: 0 <= (==) remaining_demand
+        bad = (table.demand[dead] < 0) | (enforce_energy_equality & (table.demand[dead] != 0))
+        presolve[prob[dead[bad]]] = 1
+    key = prob[live] * N + evse[live]
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    first = np.r_[0, np.flatnonzero(np.diff(ks)) + 1]
+    counts = np.diff(np.r_[first, len(ks)])
+    rank = np.arange(len(ks)) - np.repeat(first, counts)
+    K = int(rank.max()) + 1 if len(ks) else 1
+    if K > 1:   # sessions sharing an EVSE must not overlap in time
+        lo = live[order]
+        o2 = np.lexsort((off[lo], ks))                 # by EVSE group, then window start
+        so, sr, sk = off[lo][o2], rem[lo][o2], ks[o2]
+        clash = (sk[1:] == sk[:-1]) & (so[1:] < so[:-1] + sr[:-1])
+        if clash.any():
+            w = lo[o2][1:][clash][0]
+            raise ValueError(
+                f"sessions on EVSE {infrastructure.station_ids[int(evse[w])]} overlap in time; the structured "
+                "builder needs disjoint session windows per EVSE"
+            )
+    s_off = alloc((B, K, N), np.int32)
+    s_len = alloc((B, K, N), np.int32)
+    s_cap = alloc((B, K, N), np.float64)
+    sl_ = live[order]
+    slot = (prob[sl_] * K + rank) * N + evse[sl_]
+    s_off.reshape(-1)[slot] = off[sl_]
+    s_len.reshape(-1)[slot] = rem[sl_]
+    s_cap.reshape(-1)[slot] = table.demand[sl_] / kwh_per_amp_period[evse[sl_]]
+
+    # ---- objective: depends on the problem only through its horizon ----------------------------------------------
+    for T in np.unique(end):
+        T = int(T)
+        qb, pd, lfc, c0, dcw, dfl = objective_terms(objective, infrastructure, interface, N, T, prev_peak)
+        sel = np.flatnonzero(end == T)
+        q[sel, :, :T] = qb
+        pdiag[sel], lf[sel], const[sel], dc[sel], dfloor[sel] = pd, lfc, c0, dcw, dfl
+    if peak is not None:   # aco.py:196-198
+        for b in range(B):
+            if peak_limits[b] is not None:
+                peak[b, : end[b]] = np.broadcast_to(np.asarray(peak_limits[b], float), (int(end[b]),))
     return ProblemBatch(
         site, B, Tm, K, Ts, lb, ub, q, pdiag, lf, s_off, s_len, s_cap, s_eq, peak, dc, dfloor, const, presolve
     )

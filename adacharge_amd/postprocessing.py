@@ -147,3 +147,100 @@ def diff_based_reallocation(rates, active_sessions, infrastructure, interface):
     _round_robin_increment(col, order, active, ub, infrastructure, peak_limit)
     rounded[:, 0] = col
     return rounded
+
+
+# ---------------------------------------------------------------------------------------------------------------
+#  Whole-batch versions (ada.py:176-189 applied to every snapshot of a batched solve at once).  Same results as
+#  the per-snapshot functions above (tests/test_postprocessing.py), written so that the Python interpreter sees
+#  array operations over the batch instead of a loop over snapshots, EVSEs and increments.
+# ---------------------------------------------------------------------------------------------------------------
+def _pilot_table(infrastructure):
+    """allowable_pilots as one (N, L) array padded with +inf (sets may differ per EVSE)."""
+    sets = [np.asarray(a, float) for a in infrastructure.allowable_pilots]
+    L = max(len(a) for a in sets)
+    tab = np.full((len(sets), L), np.inf)
+    for i, a in enumerate(sets):
+        tab[i, : len(a)] = a
+    return tab
+
+
+def project_into_continuous_feasible_pilots_batch(rates: np.ndarray, infrastructure):
+    """post.py:77-94 for rates (B, N, T)."""
+    cap = np.asarray(infrastructure.max_pilot, float)[None, :, None]
+    return np.maximum(np.minimum(rates, cap), 0)
+
+
+def project_into_discrete_feasible_pilots_batch(rates: np.ndarray, infrastructure):
+    """post.py:97-118 for rates (B, N, T): EVSEs that share an allowable set are floored in one call."""
+    out = np.array(rates, copy=True)
+    groups = {}
+    for i, a in enumerate(infrastructure.allowable_pilots):
+        groups.setdefault(tuple(np.asarray(a, float)), []).append(i)
+    for aset, idx in groups.items():
+        out[:, idx, :] = floor_to_set(rates[:, idx, :], np.array(aset), eps=0.05)
+    return np.maximum(out, 0)
+
+
+def diff_based_reallocation_batch(rates: np.ndarray, table, infrastructure, interface):
+    """post.py:189-258 for every snapshot of a batch: ``rates`` (B, N, T) solved schedules (zero-padded beyond a
+    snapshot's horizon), ``table`` the SessionTable the batch was built from.  The greedy round-robin is sequential
+    inside a snapshot; here every step advances ALL snapshots by one visit (each has its own visiting order and
+    position), so the loop length is the longest snapshot's, not the sum."""
+    B, N = rates.shape[0], rates.shape[1]
+    init = rates[:, :, 0]
+    peak_limit = init.sum(axis=1)
+    rounded = project_into_discrete_feasible_pilots_batch(rates, infrastructure)
+    col = rounded[:, :, 0].copy()
+    # visiting order: a snapshot's sessions sorted by rounding loss, largest first (stable, like sorted())
+    loss = -(init[table.prob, table.evse] - col[table.prob, table.evse])
+    order = np.lexsort((loss, table.prob))
+    cnt = np.bincount(table.prob, minlength=B)
+    start = np.r_[0, np.cumsum(cnt)[:-1]]
+    visit = np.full((B, max(int(cnt.max()), 1)), -1, dtype=np.int64)
+    pos_in = np.arange(len(order)) - np.repeat(start, cnt)
+    visit[table.prob[order], pos_in] = table.evse[order]
+    # first-period caps of the sessions that have arrived (post.py:222-236)
+    active = np.zeros((B, N), dtype=bool)
+    ub = np.zeros((B, N))
+    here = np.flatnonzero((table.off == 0) & (np.diff(table.seg) > 0))
+    volt = np.asarray(infrastructure.voltages, float)
+    amp_periods = table.demand[here] * 1000.0 / volt[table.evse[here]] * 60.0 / interface.period
+    cap = np.minimum(np.minimum(amp_periods, table.max_rates[table.seg[here]]), np.asarray(infrastructure.max_pilot, float)[table.evse[here]])
+    active[table.prob[here], table.evse[here]] = True
+    ub[table.prob[here], table.evse[here]] = cap        # one arrived session per EVSE (a later one overwrites, as the loop does)
+    pilots = _pilot_table(infrastructure)
+    cm = infrastructure.constraint_matrix
+    ph = np.deg2rad(infrastructure.phases)
+    Cre, Cim = (cm * np.cos(ph)).T, (cm * np.sin(ph)).T
+    lim = np.asarray(infrastructure.constraint_limits)[None, :] + 1e-7
+    ptr = np.zeros(B, dtype=np.int64)
+    rows = np.arange(B)
+    n_vis = np.maximum(cnt, 1)
+    while True:
+        run = active.any(axis=1) & (cnt > 0)            # `if not active.any(): break`
+        if not run.any():
+            break
+        i = visit[rows, ptr % n_vis]
+        i = np.where(run, i, 0)
+        ptr += run
+        act = run & active[rows, i]                     # `if not active[i]: continue`
+        cur = col[rows, i]
+        full = act & (cur >= ub[rows, i])               # `if column[i] >= ub[i]: active[i] = False`
+        active[rows[full], i[full]] = False
+        tr = act & ~full
+        if not tr.any():
+            continue
+        r_, i_ = rows[tr], i[tr]
+        nxt_pos = (pilots[i_] > cur[tr][:, None]).argmax(axis=1)          # increment_in_set: next larger value ...
+        has = (pilots[i_] > cur[tr][:, None]).any(axis=1)
+        last = np.isfinite(pilots[i_]).sum(axis=1) - 1
+        nxt = np.where(has, pilots[i_, nxt_pos], pilots[i_, last])        # ... clipped at the end of the set
+        trial = col[r_].copy()
+        trial[np.arange(len(r_)), i_] = nxt
+        ok = (trial.sum(axis=1) <= peak_limit[r_]) & (nxt <= ub[r_, i_])
+        mag = np.hypot(trial @ Cre, trial @ Cim)
+        ok &= np.all(mag <= lim, axis=1)
+        col[r_[ok], i_[ok]] = nxt[ok]
+        active[r_[~ok], i_[~ok]] = False
+    rounded[:, :, 0] = col
+    return rounded

@@ -185,6 +185,33 @@ def random_sessions_general(infra, horizon, rng, two_per_evse=False, min_rates=F
     return sessions
 
 
+def offline_day(infra: InfrastructureInfo, rng: np.random.Generator, horizon: int = 288, n_sessions: int = 150,
+                period: int = 5) -> List[SessionInfo]:
+    """A day-shaped offline instance (adacharge.py:234-276, t_int.py:350-403 shape; synthetic -- the reference's own
+    day comes from the ACN-Data web API): ``n_sessions`` sessions over ``horizon`` periods on the site's EVSEs,
+    arrivals clustered in the morning, stays of 1-9 hours, several consecutive sessions per EVSE, never overlapping
+    on one EVSE, demands a fraction of what the stay could deliver."""
+    n = infra.num_stations
+    free_from = np.zeros(n, dtype=int)           # first period each EVSE is free again
+    sessions = []
+    arrivals = np.sort(np.clip(rng.normal(0.42 * horizon, 0.27 * horizon, size=4 * n_sessions), 0, horizon - 13).astype(int))
+    for a in arrivals:
+        if len(sessions) >= n_sessions:
+            break
+        cand = np.flatnonzero(free_from <= a)
+        if len(cand) == 0:
+            continue
+        i = int(rng.choice(cand))
+        stay = int(rng.integers(12, 97))
+        d = min(horizon, a + stay)
+        k = float(infra.voltages[i]) * period / 60 / 1e3
+        dem = float(rng.uniform(0.15, 0.7) * 32.0 * (d - a) * k)
+        sessions.append(SessionInfo(infra.station_ids[i], f"day-{len(sessions)}", dem, 0.0, int(a), int(d), current_time=0,
+                                    min_rates=0.0, max_rates=32.0))
+        free_from[i] = d + int(rng.integers(1, 6))
+    return sessions
+
+
 def eight_sites() -> List[InfrastructureInfo]:
     """The 8 sites of BASELINE.json configs[3] ("1024 demand scenarios x 8 sites"): the Caltech-shaped and the
     synthetic 52-EVSE site plus six synthetic three-phase sites of 30-64 EVSEs (all *synthetic*)."""
@@ -209,6 +236,31 @@ def snapshot_batch(
     """``batch`` independent snapshots from one SeedSequence spawned B ways."""
     children = np.random.SeedSequence(seed).spawn(batch)
     return [random_sessions(infra, horizon, np.random.default_rng(c), **kw) for c in children]
+
+
+def snapshot_table(infra: InfrastructureInfo, horizon: int, batch: int, seed: int = 20240, min_sessions: int = 10,
+                   max_rate: float = 32.0, demand_range=(0.5, 20.0)):
+    """``batch`` MPC snapshots of the same distribution as ``random_sessions`` as ONE ``SessionTable`` -- arrays from
+    the start, no SessionInfo objects (the array-native input of ``schedule_batch`` / ``solve_table``)."""
+    from .session_table import SessionTable
+
+    rng = np.random.default_rng(seed)
+    n = infra.num_stations
+    cnt = rng.integers(min(min_sessions, n), n + 1, size=batch)
+    # distinct EVSEs per snapshot: the first cnt[b] entries of a random permutation
+    perm = np.argsort(rng.random((batch, n)), axis=1)
+    keep = np.arange(n)[None, :] < cnt[:, None]
+    prob = np.repeat(np.arange(batch), cnt)
+    evse = perm[keep]
+    S = len(prob)
+    rem = rng.integers(1, horizon + 1, size=S)
+    first = np.r_[0, np.cumsum(cnt)[:-1]]
+    rem[first + rng.integers(0, cnt)] = horizon          # one session per snapshot spans the horizon
+    demand = rng.uniform(demand_range[0], demand_range[1], size=S)
+    seg = np.r_[0, np.cumsum(rem)]
+    return SessionTable(batch, n, prob.astype(np.int64), evse.astype(np.int64), np.zeros(S, np.int64), rem.astype(np.int64),
+                        demand, np.zeros(S, np.int64), seg.astype(np.int64), np.zeros(int(seg[-1])), np.full(int(seg[-1]), float(max_rate)),
+                        [f"s{k}" for k in range(S)])
 
 
 def demand_scenarios(

@@ -90,3 +90,35 @@ def test_diff_based_reallocation_returns_first_period_loss():
     nptest.assert_equal(out[:, 0], [17, 16, 17])
     nptest.assert_equal(out[:, 1:], 16)
     assert out[:, 0].sum() <= rates[:, 0].sum()
+
+
+# ---- whole-batch versions (adacharge_amd/postprocessing.py, *_batch) == the per-snapshot functions ----------------
+@pytest.mark.parametrize("site_name,seed", [("caltech54", 5), ("jpl52", 6)])
+def test_batch_postprocessing_equals_per_snapshot(site_name, seed):
+    from adacharge_amd import postprocessing as pp, sites
+    from adacharge_amd.acn import Interface
+    from adacharge_amd.session_table import SessionTable
+
+    infra = getattr(sites, site_name)()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    rng = np.random.default_rng(seed)
+    B, T = 24, 12
+    lists = [sites.random_sessions_general(infra, T, rng, two_per_evse=(b % 2 == 1), min_rates=False, demand_scale=1.0) for b in range(B)]
+    table = SessionTable.from_sessions(lists, infra)
+    rates = np.zeros((B, infra.num_stations, T))
+    for b, sl in enumerate(lists):
+        for s in sl:
+            i = infra.station_ids.index(s.station_id)
+            rates[b, i, s.arrival_offset : s.arrival_offset + s.remaining_time] = rng.uniform(0, 14, size=s.remaining_time)
+    rates[0, :, 0] = 0.03   # within eps of a pilot value: the floor rounds UP (post.py:10-31)
+    d = pp.project_into_discrete_feasible_pilots_batch(rates, infra)
+    c = pp.project_into_continuous_feasible_pilots_batch(rates - 1.0, infra)
+    got = pp.diff_based_reallocation_batch(rates, table, infra, iface)
+    changed = 0
+    for b in range(B):
+        assert np.array_equal(d[b], pp.project_into_discrete_feasible_pilots(rates[b], infra))
+        assert np.array_equal(c[b], pp.project_into_continuous_feasible_pilots(rates[b] - 1.0, infra))
+        want = pp.diff_based_reallocation(rates[b].copy(), lists[b], infra, iface)
+        assert np.array_equal(got[b], want), b
+        changed += int((want[:, 0] != d[b][:, 0]).sum())
+    assert changed > 0   # the reallocation loop did hand rounding loss back somewhere

@@ -36,6 +36,9 @@ CASES = [
     ("t40_two",      "caltech54", 40, "LINEAR", False, True,  False, "vector", 1e-2, 214),
     ("wide128_soc",  "wide128",   12, "SOC",    False, False, False, "none",   1e-3, 215),
     ("wide128_lin",  "wide128",   16, "LINEAR", False, True,  False, "none",   1e-2, 217),
+    # a day-shaped offline instance (adacharge.py:234-276; t_int.py:350-403 solves one with energy equalities):
+    # 288 periods, 150 sessions, up to 6 consecutive sessions per EVSE -- sites.offline_day
+    ("offline_day",  "caltech54", 288, "SOC",   True,  "day", False, "none",   1e-3, 218),
 ]
 
 
@@ -45,7 +48,10 @@ def main():
         infra = getattr(sites, site_name)()
         iface = Interface({"infrastructure_info": infra, "period": 5})
         rng = np.random.default_rng(seed)
-        sl = sites.random_sessions_general(infra, T, rng, two, mins, demand_scale=0.5 if eq else 1.5)
+        if two == "day":
+            sl = sites.offline_day(infra, rng, horizon=T)
+        else:
+            sl = sites.random_sessions_general(infra, T, rng, two, mins, demand_scale=0.5 if eq else 1.5)
         Tb = max(s.arrival_offset + s.remaining_time for s in sl)
         full = 32.0 * len(sl)
         peak = None
