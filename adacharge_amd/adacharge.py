@@ -60,6 +60,7 @@ class AdaptiveSchedulingAlgorithm(BaseAlgorithm):
         verbose=False,
         solver_options=None,
         device=0,
+        warm_start=False,
     ):
         super().__init__()
         self.objective = objective
@@ -67,6 +68,10 @@ class AdaptiveSchedulingAlgorithm(BaseAlgorithm):
         self.enforce_energy_equality = enforce_energy_equality
         self.solver = solver
         self.peak_limit = peak_limit
+        # extension (off by default: the reference rebuilds everything each step and keeps no state, ada.py:152-158):
+        # start each solve from the previous step's schedule and multipliers, shifted by the periods elapsed
+        self.warm_start = warm_start
+        self._warm = None   # (current_time, x (N, T), y (N, T)) of the previous solve
         self.estimate_max_rate = estimate_max_rate
         self.max_rate_estimator = max_rate_estimator
         self.uninterrupted_charging = uninterrupted_charging
@@ -140,12 +145,24 @@ class AdaptiveSchedulingAlgorithm(BaseAlgorithm):
             return {}
         infrastructure = self.interface.infrastructure_info()
         active_sessions = self._preprocess(active_sessions, infrastructure)
-        rates_matrix = self._optimizer().solve(
+        optimizer = self._optimizer()
+        warm = None
+        if self.warm_start and self._warm is not None:
+            t_prev, x_prev, y_prev = self._warm
+            dt = self.interface.current_time - t_prev
+            if 0 <= dt < x_prev.shape[1]:
+                warm = (x_prev[:, dt:], y_prev[:, dt:])
+        rates_matrix = optimizer.solve(
             active_sessions, infrastructure,
             peak_limit=self._trimmed_peak(active_sessions),
             prev_peak=self.interface.get_prev_peak(),
             verbose=self.verbose,
+            warm_start=warm,
         )
+        if self.warm_start:
+            T = rates_matrix.shape[1]
+            self._warm = (self.interface.current_time, rates_matrix.copy(), optimizer.last_multipliers[0][:, :T].copy())
+        self.last_iterations = int(optimizer.last_result.iters[0])
         rates_matrix = self._postprocess(rates_matrix, active_sessions, infrastructure)
         return {
             station_id: rates_matrix[i, :] for i, station_id in enumerate(infrastructure.station_ids)

@@ -314,14 +314,20 @@ class AdaptiveChargingOptimization:
         peak_limit: Union[float, List[float], np.ndarray] = None,
         prev_peak=0,
         verbose: bool = False,
+        warm_start=None,
     ):
         """aco.py:286-321: (N, T) array of charging rates; raises
-        ``InfeasibilityException`` unless the solve ends optimal."""
+        ``InfeasibilityException`` unless the solve ends optimal.
+
+        ``warm_start`` (extension; the reference starts every solve from nothing, adacharge.py:152-158):
+        ``(x0, y0)`` -- a schedule (N, >= T) and the site-row multipliers ``last_multipliers`` (Mg, >= T) of an
+        earlier, similar solve, already shifted to this problem's first period (the site must carry the same rows:
+        same constraint type, peak / load-flattening / demand-charge rows).  Changes the iteration count, not the optimum."""
         if len(active_sessions) == 0:  # aco.py:310-311
             return np.zeros((infrastructure.num_stations, 1))
         rates, status = self.solve_batch(
             [active_sessions], infrastructure, peak_limits=[peak_limit], prev_peak=prev_peak,
-            verbose=verbose, _defaults=self._SINGLE_DEFAULTS,
+            verbose=verbose, _defaults=self._SINGLE_DEFAULTS, warm_start=[warm_start],
         )
         from . import backend
 
@@ -331,7 +337,8 @@ class AdaptiveChargingOptimization:
             )
         return rates[0]
 
-    def solve_table(self, table, infrastructure, peak_limits=None, prev_peak=0, _defaults: Optional[dict] = None):
+    def solve_table(self, table, infrastructure, peak_limits=None, prev_peak=0, _defaults: Optional[dict] = None,
+                    warm_start=None):
         """Batched solve of a ``session_table.SessionTable`` (every snapshot non-empty): the array-native entry --
         no Python loop over sessions anywhere on the path.  Returns ``(backend.BatchResult, ProblemBatch)``."""
         from . import backend
@@ -351,10 +358,27 @@ class AdaptiveChargingOptimization:
         )
         opts = dict(_defaults or {})
         opts.update(self.solver_options)
-        res = handle.solve(batch, backend.default_options(**opts))
+        warm = None
+        if warm_start is not None and any(w is not None for w in warm_start):
+            # per problem (x0, y0) or None; a problem without one starts from its own cold start's point only if all
+            # are None -- mixed batches give the cold problems x0 = y0 = 0 (a valid, if plain, starting point)
+            wx = np.zeros((batch.B, batch.N, batch.Tm))
+            wy = np.zeros((batch.B, site.Mg, batch.Tm))
+            for b, w in enumerate(warm_start):
+                if w is not None:
+                    x0, y0 = np.asarray(w[0], float), np.asarray(w[1], float)
+                    T = min(batch.Tm, x0.shape[1], y0.shape[1])
+                    wx[b, :, :T], wy[b, :, :T] = x0[:, :T], y0[:, :T]
+            warm = (wx, wy)
+        res = handle.solve(batch, backend.default_options(**opts), warm=warm, want_y=True)
         self.last_result = res
         self.last_batch = batch   # the structured problems behind last_result (diagnostics, tests)
         return res, batch
+
+    @property
+    def last_multipliers(self):
+        """(B, Mg, Tm) site-row multipliers of the last solve: the ``y0`` of a later warm start."""
+        return None if self.last_result is None else self.last_result.y
 
     def solve_batch(
         self,
@@ -364,6 +388,7 @@ class AdaptiveChargingOptimization:
         prev_peak=0,
         verbose: bool = False,
         _defaults: Optional[dict] = None,
+        warm_start: Optional[Sequence] = None,
     ):
         """Batched extension (not in the reference): one independent MPC
         problem per entry of ``session_lists`` (state snapshots, sites' days,
@@ -387,7 +412,8 @@ class AdaptiveChargingOptimization:
         from .session_table import SessionTable
 
         table = SessionTable.from_sessions([session_lists[k] for k in nonempty], infrastructure)
-        res, batch = self.solve_table(table, infrastructure, [pl[k] for k in nonempty], prev_peak, _defaults)
+        ws = None if warm_start is None else [warm_start[k] for k in nonempty]
+        res, batch = self.solve_table(table, infrastructure, [pl[k] for k in nonempty], prev_peak, _defaults, ws)
         if verbose:
             for j, k in enumerate(nonempty):
                 print(

@@ -72,6 +72,8 @@ class _Problems(C.Structure):
         ("lf", C.c_void_p),
         ("dc", C.c_void_p),
         ("dfloor", C.c_void_p),
+        ("warm_x", C.c_void_p),
+        ("warm_y", C.c_void_p),
     ]
 
 
@@ -83,6 +85,7 @@ class _Results(C.Structure):
         ("pri_res", C.c_void_p),
         ("dua_res", C.c_void_p),
         ("obj", C.c_void_p),
+        ("y", C.c_void_p),
         ("x_dev", C.c_void_p),
     ]
 
@@ -217,6 +220,7 @@ class BatchResult:
     dua_res: np.ndarray
     obj: np.ndarray
     kernel_ms: float = float("nan")
+    y: Optional[np.ndarray] = None   # (B, Mg, Tm) multipliers of the site rows (when asked for): warm_y of a later solve
 
 
 class _PinnedBlock:
@@ -289,7 +293,7 @@ class SiteHandle:
         ):
             raise ValueError("batch was built for a different site than this handle")
 
-    def _marshal(self, batch: ProblemBatch, pinned: bool, x_dev=None):
+    def _marshal(self, batch: ProblemBatch, pinned: bool, x_dev=None, warm=None, want_y=False):
         """ctypes views of one batch: (_Problems, _Results, BatchResult, keep-alive list).  Arrays that already
         are C-contiguous with the ABI's dtype are passed as they are (e.g. pinned arrays from ``pinned_empty``)."""
         B, N, Tm = batch.B, batch.N, batch.Tm
@@ -308,16 +312,24 @@ class SiteHandle:
         lf = np.ascontiguousarray(batch.lf, np.float64) if self.site.has_flat else None
         dc = np.ascontiguousarray(batch.dc, np.float64) if self.site.has_max else None
         dfl = np.ascontiguousarray(batch.dfloor, np.float64) if self.site.has_max else None
+        wx = wy = None
+        if warm is not None:
+            wx = np.ascontiguousarray(warm[0], np.float64)
+            wy = np.ascontiguousarray(warm[1], np.float64)
+            if wx.shape != (B, N, Tm) or wy.shape != (B, self.site.Mg, Tm):
+                raise ValueError(f"warm start arrays must have shapes {(B, N, Tm)} and {(B, self.site.Mg, Tm)}")
         p = _Problems(B, Tm, batch.K, *[_ptr(arrs[k]) for k in
                                        ("horizon", "lb", "ub", "q", "pdiag", "s_off", "s_len", "s_cap", "s_eq")],
-                      _ptr(peak), _ptr(lf), _ptr(dc), _ptr(dfl))
+                      _ptr(peak), _ptr(lf), _ptr(dc), _ptr(dfl), _ptr(wx), _ptr(wy))
         new = pinned_empty if pinned else (lambda shape, dtype=np.float64: np.zeros(shape, dtype))
         res = BatchResult(
             new((B, N, Tm)), new(B, np.int32), new(B, np.int32), new(B), new(B), new(B),
         )
+        if want_y:
+            res.y = new((B, self.site.Mg, Tm))
         r = _Results(_ptr(res.x), _ptr(res.status), _ptr(res.iters), _ptr(res.pri_res), _ptr(res.dua_res), _ptr(res.obj),
-                     None if x_dev is None else C.c_void_p(int(x_dev)))
-        return p, r, res, (arrs, peak, lf, dc, dfl)
+                     _ptr(res.y), None if x_dev is None else C.c_void_p(int(x_dev)))
+        return p, r, res, (arrs, peak, lf, dc, dfl, wx, wy)
 
     def _finish(self, batch: ProblemBatch, res: "BatchResult"):
         if self.site.has_flat:   # the kernel's obj covers pdiag and q; add 1/2 lf sum_t (v' x_t)^2
@@ -331,11 +343,14 @@ class SiteHandle:
             res.status[batch.presolve_status != 0] = STATUS_EMPTY_SET
         return res
 
-    def solve(self, batch: ProblemBatch, options: Optional[Options] = None, pinned_results: bool = False) -> BatchResult:
-        """acnqp_solve_batch: one batch, host buffers in and out, synchronous (pipelined in chunks inside)."""
+    def solve(self, batch: ProblemBatch, options: Optional[Options] = None, pinned_results: bool = False,
+              warm=None, want_y: bool = False) -> BatchResult:
+        """acnqp_solve_batch: one batch, host buffers in and out, synchronous (pipelined in chunks inside).
+        ``warm = (x0, y0)``: optional warm start (an earlier schedule (B, N, Tm) and its ``BatchResult.y`` (B, Mg, Tm),
+        shifted by the caller); ``want_y``: also return the site-row multipliers ``y`` for a later warm start."""
         self._check_site(batch)
         o = options if options is not None else default_options()
-        p, r, res, keep = self._marshal(batch, pinned_results)
+        p, r, res, keep = self._marshal(batch, pinned_results, warm=warm, want_y=want_y)
         _check(self._lib.acnqp_solve_batch(self._h, C.byref(p), C.byref(o), C.byref(r)), "acnqp_solve_batch")
         del keep
         res.kernel_ms = float(self._lib.acnqp_last_kernel_ms(self._h))
@@ -388,9 +403,10 @@ class SiteHandle:
             dev.lf.data_ptr() if self.site.has_flat else None,
             dev.dc.data_ptr() if self.site.has_max else None,
             dev.dfloor.data_ptr() if self.site.has_max else None,
+            None, None,
         )
         r = _Results(dev.x.data_ptr(), dev.status.data_ptr(), dev.iters.data_ptr(),
-                     dev.pri_res.data_ptr(), dev.dua_res.data_ptr(), dev.obj.data_ptr(), None)
+                     dev.pri_res.data_ptr(), dev.dua_res.data_ptr(), dev.obj.data_ptr(), None, None)
         _check(
             self._lib.acnqp_solve_batch_device(self._h, C.byref(p), C.byref(o), C.byref(r), C.c_void_p(stream)),
             "acnqp_solve_batch_device",

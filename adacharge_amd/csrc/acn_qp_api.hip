@@ -100,10 +100,13 @@ struct SiteDev {
   void *G = nullptr, *Ghat = nullptr, *Q = nullptr, *lam = nullptr, *rowlim = nullptr;
   void *fragG = nullptr, *fragQ = nullptr;   // Ghat / Q in MFMA A-operand fragment order (tiled kernel)
   int32_t* rowtype = nullptr;
+  int32_t* rowabi = nullptr;     // internal row -> row of acnqp_site.G (-1: padding)
+  void* rowscale = nullptr;      // equilibration factor of each internal row
   void release() {
-    for (void** p : {&G, &Ghat, &Q, &lam, &rowlim, &fragG, &fragQ}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    for (void** p : {&G, &Ghat, &Q, &lam, &rowlim, &fragG, &fragQ, &rowscale}) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (rowtype) (void)hipFree(rowtype);
-    rowtype = nullptr;
+    if (rowabi) (void)hipFree(rowabi);
+    rowtype = nullptr; rowabi = nullptr;
     ready = false;
   }
 };
@@ -148,9 +151,10 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
   const int MR = 16 * ((raw + 15) / 16 > 0 ? (raw + 15) / 16 : 1);
   if (MR > 48) return fail(ACNQP_ERR_INVALID, "site has too many rows for the tiled kernel (> 48 after padding)");
   std::vector<double> Gi((size_t)MR * NP, 0.0), lim(MR, 0.0);
-  std::vector<int32_t> ty(MR, acnqp::kRowFree);
+  std::vector<int32_t> ty(MR, acnqp::kRowFree), abi(MR, -1);
   auto put = [&](int slot, int src_row, int type, double limit) {
     for (int i = 0; i < N; ++i) Gi[(size_t)slot * NP + i] = h->G[(size_t)src_row * N + i];
+    abi[slot] = src_row;
     ty[slot] = type;
     lim[slot] = limit;
   };
@@ -251,8 +255,11 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
   if (e == hipSuccess) e = up(&d->Q, Q);
   if (e == hipSuccess) e = up(&d->lam, lam);
   if (e == hipSuccess) e = up(&d->rowlim, lim);
+  if (e == hipSuccess) e = up(&d->rowscale, rs);
   if (e == hipSuccess) e = hipMalloc((void**)&d->rowtype, MR * sizeof(int32_t));
   if (e == hipSuccess) e = hipMemcpy(d->rowtype, ty.data(), MR * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&d->rowabi, MR * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpy(d->rowabi, abi.data(), MR * sizeof(int32_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) { d->release(); return fail(ACNQP_ERR_HIP, std::string("site upload: ") + hipGetErrorString(e)); }
   d->MR = MR;
   d->ready = true;
@@ -483,6 +490,8 @@ static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, 
   if (h->has_peak && !p->peak) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: site has a peak row but peak is null");
   if (h->has_flat && !p->lf) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: site has a flat row but lf is null");
   if (h->has_max && (!p->dc || !p->dfloor)) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: site has a max row but dc/dfloor is null");
+  if ((p->warm_x == nullptr) != (p->warm_y == nullptr))
+    return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: warm_x and warm_y must be given together");
   if (!r->x || !r->status || !r->iters || !r->pri_res || !r->dua_res || !r->obj)
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: null result array");
   if (!(o->eps_abs >= 0) || !(o->eps_rel >= 0) || o->max_iter < 1 || o->check_every < 1 || !(o->rho > 0) ||
@@ -512,6 +521,10 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.lf = h->has_flat ? p->lf : nullptr;
   a.dc = h->has_max ? p->dc : nullptr;
   a.dfloor = h->has_max ? p->dfloor : nullptr;
+  a.warm_x = (p->warm_x && p->warm_y) ? p->warm_x : nullptr;
+  a.warm_y = (p->warm_x && p->warm_y) ? p->warm_y : nullptr;
+  a.y_out = r->y;
+  a.rowabi = d->rowabi; a.rowscale = d->rowscale; a.Mg = h->Mg;
   a.x = r->x; a.status = r->status; a.iters = r->iters; a.pri = r->pri_res; a.dua = r->dua_res; a.obj = r->obj;
   a.eps_abs = o->eps_abs; a.eps_rel = o->eps_rel; a.rho0 = o->rho; a.sigma = o->sigma; a.alpha = o->alpha;
   a.adapt_tol = o->adapt_tol; a.reg_rel = o->reg_rel;
@@ -624,9 +637,9 @@ inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // device layout of one chunk of `cn` problems (inputs in slot.in, results in slot.out)
 struct ChunkLayout {
-  size_t lb, ub, q, pd, hz, so, sl, sc, eq, pk, lf, dc, df, in_total;
-  size_t x, st, it, pr, du, ob, out_total;
-  ChunkLayout(size_t cn, size_t N, size_t Tm, size_t K, bool peak, bool flat, bool mx) {
+  size_t lb, ub, q, pd, hz, so, sl, sc, eq, pk, lf, dc, df, wx, wy, in_total;
+  size_t x, st, it, pr, du, ob, y, out_total;
+  ChunkLayout(size_t cn, size_t N, size_t Tm, size_t K, size_t Mg, bool peak, bool flat, bool mx, bool warm, bool want_y) {
     size_t o = 0;
     lb = o; o += al256(cn * N * Tm * 8);
     ub = o; o += al256(cn * N * Tm * 8);
@@ -641,6 +654,8 @@ struct ChunkLayout {
     lf = o; o += al256(flat ? cn * 8 : 0);
     dc = o; o += al256(mx ? cn * 8 : 0);
     df = o; o += al256(mx ? cn * 8 : 0);
+    wx = o; o += al256(warm ? cn * N * Tm * 8 : 0);
+    wy = o; o += al256(warm ? cn * Mg * Tm * 8 : 0);
     in_total = o;
     o = 0;
     x = o;  o += al256(cn * N * Tm * 8);
@@ -649,6 +664,7 @@ struct ChunkLayout {
     pr = o; o += al256(cn * 8);
     du = o; o += al256(cn * 8);
     ob = o; o += al256(cn * 8);
+    y = o;  o += al256(want_y ? cn * Mg * Tm * 8 : 0);
     out_total = o;
   }
 };
@@ -666,15 +682,16 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
   // chunks: consecutive batches of one shape (t_max, k_sessions) share launches of up to chunk_problems() problems
   std::vector<std::vector<Piece>> chunks;
   long long fill = 0, cap = 0;
-  int cur_T = -1, cur_K = -1;
+  int cur_T = -1, cur_K = -1, cur_opt = -1;
   for (int g = 0; g < nb; ++g) {
     const long long B = P[g].batch;
     if (B == 0) continue;
     const size_t Tm = P[g].t_max, K = P[g].k_sessions;
+    const int opt = (P[g].warm_x ? 1 : 0) | (R[g].y ? 2 : 0);   // chunks are uniform in warm start / multiplier output
     for (long long lo = 0; lo < B;) {
-      if (chunks.empty() || (int)Tm != cur_T || (int)K != cur_K || fill >= cap) {
+      if (chunks.empty() || (int)Tm != cur_T || (int)K != cur_K || opt != cur_opt || fill >= cap) {
         chunks.emplace_back();
-        cur_T = (int)Tm; cur_K = (int)K; fill = 0;
+        cur_T = (int)Tm; cur_K = (int)K; cur_opt = opt; fill = 0;
         cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96);
       }
       const long long n = std::min(B - lo, cap - fill);
@@ -687,7 +704,9 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
     const std::vector<Piece>& pcs = chunks[c];
     const size_t cn = (size_t)(pcs.back().pos + pcs.back().n);
     const size_t Tm = P[pcs[0].g].t_max, K = P[pcs[0].g].k_sessions;
-    const ChunkLayout L(cn, N, Tm, K, peak, flat, mx);
+    const bool warm = P[pcs[0].g].warm_x != nullptr, want_y = R[pcs[0].g].y != nullptr;
+    const size_t Mg = (size_t)h->Mg;
+    const ChunkLayout L(cn, N, Tm, K, Mg, peak, flat, mx, warm, want_y);
     if (L.in_total > S.in.cap || L.out_total > S.out.cap) HIP_TRY(hipStreamSynchronize(S.st));   // staging still in use
     HIP_TRY(S.in.reserve(L.in_total));
     HIP_TRY(S.out.reserve(L.out_total));
@@ -712,6 +731,7 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
       if (peak) H2D(peak, L.pk, 8, Tm);
       if (flat) H2D(lf, L.lf, 8, 1);
       if (mx) { H2D(dc, L.dc, 8, 1); H2D(dfloor, L.df, 8, 1); }
+      if (warm) { H2D(warm_x, L.wx, 8, nv); H2D(warm_y, L.wy, 8, Mg * Tm); }
 #undef H2D
     }
     acnqp_problems dp;
@@ -729,6 +749,8 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
     dp.lf = flat ? reinterpret_cast<const double*>(di + L.lf) : nullptr;
     dp.dc = mx ? reinterpret_cast<const double*>(di + L.dc) : nullptr;
     dp.dfloor = mx ? reinterpret_cast<const double*>(di + L.df) : nullptr;
+    dp.warm_x = warm ? reinterpret_cast<const double*>(di + L.wx) : nullptr;
+    dp.warm_y = warm ? reinterpret_cast<const double*>(di + L.wy) : nullptr;
     acnqp_results dr;
     dr.x = reinterpret_cast<double*>(dq + L.x);
     dr.status = reinterpret_cast<int32_t*>(dq + L.st);
@@ -737,6 +759,7 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
     dr.dua_res = reinterpret_cast<double*>(dq + L.du);
     dr.obj = reinterpret_cast<double*>(dq + L.ob);
     dr.x_dev = nullptr;
+    dr.y = want_y ? reinterpret_cast<double*>(dq + L.y) : nullptr;
     const int rc = acnqp_solve_batch_device(h, &dp, o, &dr, S.st);
     if (rc != ACNQP_OK) return rc;
     for (const Piece& pc : pcs) {
@@ -751,6 +774,7 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
       D2H(pri_res, L.pr, 8, 1);
       D2H(dua_res, L.du, 8, 1);
       D2H(obj, L.ob, 8, 1);
+      if (want_y) D2H(y, L.y, 8, Mg * Tm);
 #undef D2H
       if (r.x_dev)
         HIP_TRY(hipMemcpyAsync(r.x_dev + lo * N * Tm, dq + L.x + pos * N * Tm * 8, n * N * Tm * 8, hipMemcpyDeviceToDevice, S.st));

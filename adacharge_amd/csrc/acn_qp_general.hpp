@@ -179,25 +179,38 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   };
   // ---- start: the schedule that ignores the site rows (see acn_qp_tiled.hpp): z1 = Proj_B(-kStartGain q),
   // y1 = -(q + pd z1), z2 = G z1, y2 = 0
+  // Warm start (optional; see acn_qp_tiled.hpp): z1 = Proj_B(warm_x), y2 = warm_y (caller's row order and units),
+  // y1 = -(q + pd z1 + G' y2)
+  const bool warm = A.warm_x != nullptr && A.warm_y != nullptr;
   for (int k = tid; k < n; k += kGenThreads) {
-    zh[k] = -(real)kStartGain * (real)qg[k];
+    zh[k] = warm ? (real)A.warm_x[(size_t)b * n + k] : -(real)kStartGain * (real)qg[k];
     z1[k] = fmin(fmax(zh[k], (real)lbg[k]), ub[k]);
   }
   __syncthreads();
   project_sessions();
   __syncthreads();
   for (int s = tid; s < K * N; s += kGenThreads) mu[s] = 0;
-  for (int k = tid; k < n; k += kGenThreads) {
-    x[k] = z1[k];
-    y1[k] = -((real)qg[k] + pd * z1[k]);
-    r0[k] = sigma * x[k] - (real)qg[k] + rho * z1[k] - y1[k];
-  }
   for (int k = tid; k < mt; k += kGenThreads) {
     const int r = k / T, t = k - r * T;
     real acc = 0;
     for (int i = 0; i < N; ++i) acc += Gm[(size_t)r * NP + i] * z1[i * T + t];
-    z2[k] = acc; gx[k] = acc; y2[k] = 0; w[k] = rho * acc;
-    if (aa_m > 0) { uprev[n + k] = acc; fprev[n + k] = 0; cprev[n + k] = 0.f; }
+    real yv = 0;
+    if (warm) {
+      const int ja = A.rowabi[r];
+      if (ja >= 0) yv = (real)A.warm_y[((size_t)b * A.Mg + ja) * T + t] / static_cast<const real*>(A.rowscale)[r];
+    }
+    z2[k] = acc; gx[k] = acc; y2[k] = yv; w[k] = rho * acc - yv;
+    if (aa_m > 0) { uprev[n + k] = acc + yv / rho; fprev[n + k] = 0; cprev[n + k] = 0.f; }
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += kGenThreads) {
+    const int i = k / T, t = k - i * T;
+    real gty = 0;
+    if (warm)
+      for (int j = 0; j < MR; ++j) gty += Gm[(size_t)j * NP + i] * y2[j * T + t];
+    x[k] = z1[k];
+    y1[k] = -((real)qg[k] + pd * z1[k] + gty);
+    r0[k] = sigma * x[k] - (real)qg[k] + rho * z1[k] - y1[k];
   }
   if (aa_m > 0) {
     for (int k = tid; k < n; k += kGenThreads) { uprev[k] = z1[k] + y1[k] / rho; fprev[k] = 0; cprev[k] = 0.f; }
@@ -527,6 +540,12 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
     A.x[(size_t)b * n + k] = (double)z1[k];
     ol += ((real)0.5 * pd_user * z1[k] + (real)qg[k]) * z1[k];
   }
+  if (A.y_out)   // site-row multipliers in the caller's row order and units
+    for (int k = tid; k < mt; k += kGenThreads) {
+      const int r = k / T, t = k - r * T;
+      const int ja = A.rowabi[r];
+      if (ja >= 0) A.y_out[((size_t)b * A.Mg + ja) * T + t] = (double)(y2[k] * static_cast<const real*>(A.rowscale)[r]);
+    }
   ol = wave_sum<real>(ol);
   __syncthreads();
   if ((tid & 63) == 0) red[tid >> 6] = ol;

@@ -308,7 +308,9 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
     }
   };
 
-  // ---- start (see acn_qp_tiled.hpp): z1 = Proj_B(-kStartGain q), x = z1, y1 = -(q + pd z1); z2 = G z1 = Q (Ghat z1) ---
+  // ---- start (see acn_qp_tiled.hpp): z1 = Proj_B(-kStartGain q), x = z1, y1 = -(q + pd z1); z2 = G z1 = Q (Ghat z1);
+  // warm (optional): z1 = Proj_B(warm_x), y2 = warm_y, y1 = -(q + pd z1 + G' y2) -------------------------------------
+  const bool warm = A.warm_x != nullptr && A.warm_y != nullptr;
   zero_pacc();
 #pragma unroll 1
   for (int e = wave; e < NE; e += kStreamWaves) {
@@ -322,6 +324,11 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
         const size_t i = fidx(e, c, r);
         qv[c] = Qs[i]; lbv[c] = LBs[i]; ubv[c] = UBs[i];
         zs[c] = -kStartGain * qv[c];
+        if (warm) {
+          const int ev = 16 * e + M::rowof(g, r), tt = 16 * c + t;
+          const bool ok = ev < N && tt < Tm;
+          zs[c] = ok ? A.warm_x[((size_t)b * N + (ok ? ev : 0)) * Tm + (ok ? tt : 0)] : 0.0;
+        }
       }
       project_row(e, r, zs, lbv, ubv, z1[r], true);
 #pragma unroll
@@ -346,10 +353,33 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
-      Z2[i] = zt[r]; GX[i] = zt[r]; Y2[i] = 0;
+      real yv = 0;
+      if (warm) {
+        const int j = 16 * mo + M::rowof(g, r), tt = 16 * c + t;
+        const int ja = A.rowabi[j];
+        if (ja >= 0 && tt < Tm) yv = A.warm_y[((size_t)b * A.Mg + ja) * Tm + tt] / static_cast<const real*>(A.rowscale)[j];
+      }
+      Z2[i] = zt[r]; GX[i] = zt[r]; Y2[i] = yv;
     }
   }
   __syncthreads();
+  if (warm) {   // y1 = -(q + pd z1 + G' y2): the cold start stored the G' y2 = 0 version
+#pragma unroll 1
+    for (int e = wave; e < NE; e += kStreamWaves) {
+      RELANE();
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        vec4 gty = {0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            gty = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], Y2[((m * CT + c) * 4 + s) * 64 + lane], gty);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Y1s[fidx(e, c, r)] -= gty[r];
+      }
+    }
+  }
   rebuild_pacc();
 
   int status = 2, it = 0, n_adapt = 0;
@@ -553,6 +583,19 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
           ol += (0.5 * pd_user * z + Qs[i]) * z;
         }
       }
+  if (A.y_out) {   // site-row multipliers in the caller's row order and units, by the waves that own the tiles
+#pragma unroll 1
+    for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
+      const int mo = tl / CT, c = tl - mo * CT;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * mo + M::rowof(g, r), tt = 16 * c + t;
+        const int ja = A.rowabi[j];
+        if (ja >= 0 && tt < Tm)
+          A.y_out[((size_t)b * A.Mg + ja) * Tm + tt] = Y2[((mo * CT + c) * 4 + r) * 64 + lane] * static_cast<const real*>(A.rowscale)[j];
+      }
+    }
+  }
   ol = wave_sum<real>(ol);
   if (lane == 0) SC[wave] = ol;
   __syncthreads();

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define ACNQP_ABI_VERSION 5
+#define ACNQP_ABI_VERSION 6
 
 /* cone of the infrastructure rows (constraint_type at aco.py:35, 151, 165) */
 #define ACNQP_CONE_LINEAR 0
@@ -106,6 +106,13 @@ typedef struct {
   const double* lf;        /* [B] or NULL: weight of 1/2 lf (v' r_t)^2 (2 * load_flattening coefficient) */
   const double* dc;        /* [B] or NULL: weight (>= 0) of max(max_t v' r_t, dfloor)  [$ per kW]     */
   const double* dfloor;    /* [B] or NULL: previous / baseline peak in kW (aco.py:390-394)           */
+  /* Optional warm start (both or neither; NULL = cold, which is what the reference does: nothing survives a
+   * schedule() call, adacharge.py:152-158).  A closed-loop caller passes the previous step's schedule and
+   * site-row multipliers (results.y), both shifted by the periods that have elapsed.  The solve then starts from
+   * z = Proj(warm_x), y2 = warm_y and the multipliers of the box / energy set that make the pair stationary,
+   * y1 = -(P z + q + G' y2).  The optimum does not depend on it; the iteration count does.                       */
+  const double* warm_x;    /* [B*N*Tm] or NULL                                                        */
+  const double* warm_y;    /* [B*n_rows*Tm] or NULL: multipliers of the rows of acnqp_site.G, per period */
 } acnqp_problems;
 
 typedef struct {
@@ -115,6 +122,9 @@ typedef struct {
   double* pri_res;   /* [B]       |A r - z|_inf at exit                       */
   double* dua_res;   /* [B]       |P r + q + A'y|_inf at exit                 */
   double* obj;       /* [B]       1/2 pdiag |x|^2 + <q, x>                    */
+  double* y;         /* [B*n_rows*Tm] or NULL (not wanted): multipliers of the rows of acnqp_site.G at exit
+                        (row order and units of G; a SOC pair's two rows carry the pair's two components)
+                        -- the warm_y of a later, similar problem                                 */
   double* x_dev;     /* host-buffer entry points only, optional (NULL = not wanted): a DEVICE
                         pointer [B*N*Tm] on the handle's GPU that also receives the schedules,
                         so that a collective (the RCCL all-gather of a multi-GPU job) can start

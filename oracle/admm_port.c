@@ -119,7 +119,7 @@ static void aa_solve(int m, const double* H, const double* bvec, unsigned valid,
 static int solve_one(const port_site* S, const port_opts* O, int horizon, const double* lb, const double* ub_in, const double* q,
                      double pdiag_user, double lf, double dc, double dfloor, const int32_t* s_off, const int32_t* s_len, const double* s_cap, int eq,
                      const double* peak, double* xout, int* iters_out, double* pri_out, double* dua_out,
-                     double* obj_out) {
+                     double* obj_out, const double* warm_x, const double* warm_y, double* y_out) {
   const int N = S->N, T = S->Tm, Mg = S->Mg, M = S->M, K = S->K;
   const int n = N * T, mt = Mg * T;
   const int D = n + mt, MM = O->accel_mem > AA_MAX ? AA_MAX : (O->accel_mem > 0 ? O->accel_mem : 0);
@@ -174,7 +174,10 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
   /* Start: the schedule that ignores the site rows, z1 = Proj_B(-kStartGain q) (every session served as its
    * cost vector prefers, inside its bounds and energy row), with the multiplier that makes it stationary,
    * y1 = -(q + pd z1); site rows at z2 = G z1, y2 = 0.  Exact when no site row binds. */
-  for (int k = 0; k < n; ++k) { zh[k] = -kStartGain * q[k]; z1[k] = clip(zh[k], lb[k], ub[k]); }
+  /* Warm start (optional; acn_qp_tiled.hpp): z1 = Proj_B(warm_x), y2 = warm_y (already in this solver's row scaling),
+   * y1 = -(q + pd z1 + G' y2) */
+  const int warm = warm_x != 0 && warm_y != 0;
+  for (int k = 0; k < n; ++k) { zh[k] = warm ? warm_x[k] : -kStartGain * q[k]; z1[k] = clip(zh[k], lb[k], ub[k]); }
   for (int k = 0; k < K; ++k)
     for (int i = 0; i < N; ++i) {
       const int L = s_len[k * N + i], o = s_off[k * N + i];
@@ -184,12 +187,20 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
                        shi[k * N + i], &m0, z1 + i * T + o);
       }
     }
-  for (int k = 0; k < n; ++k) { x[k] = z1[k]; y1[k] = -(q[k] + pd * z1[k]); uprev[k] = z1[k] + y1[k] / rho; }
+  if (warm) memcpy(y2, warm_y, sizeof(double) * mt);
+  for (int i = 0; i < N; ++i)
+    for (int t = 0; t < T; ++t) {
+      const int k = i * T + t;
+      double g = 0;
+      if (warm) for (int j = 0; j < Mg; ++j) g += S->G[j * N + i] * y2[j * T + t];
+      x[k] = z1[k]; y1[k] = -(q[k] + pd * z1[k] + g); uprev[k] = z1[k] + y1[k] / rho;
+    }
   for (int t = 0; t < T; ++t)
     for (int r = 0; r < Mg; ++r) {
       double a2 = 0;
       for (int i = 0; i < N; ++i) a2 += S->G[r * N + i] * z1[i * T + t];
-      gx[r * T + t] = z2[r * T + t] = uprev[n + r * T + t] = a2;
+      gx[r * T + t] = z2[r * T + t] = a2;
+      uprev[n + r * T + t] = a2 + y2[r * T + t] / rho;
     }
   for (int k = 0; k < n; ++k) r0[k] = sigma * x[k] - q[k] + rho * z1[k] - y1[k];
   for (int k = 0; k < mt; ++k) w[k] = rho * z2[k] - y2[k];
@@ -454,6 +465,7 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
   if (it > O->max_iter) it = O->max_iter;
   double obj = 0;
   for (int k = 0; k < n; ++k) { xout[k] = z1[k]; obj += (0.5 * pdiag_user * z1[k] + q[k]) * z1[k]; }
+  if (y_out) memcpy(y_out, y2, sizeof(double) * mt);
   *iters_out = it; *pri_out = pri; *dua_out = dua; *obj_out = obj;
   free(buf); free(hist); free(yprev);
   return status;
@@ -463,7 +475,8 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
 int admm_port_solve_batch(const port_site* S, const port_opts* O, int B, const int32_t* horizon, const double* lb, const double* ub,
                           const double* q, const double* pdiag, const double* lf, const double* dc, const double* dfloor, const int32_t* s_off, const int32_t* s_len,
                           const double* s_cap, const uint8_t* s_eq, const double* peak, double* x, int32_t* status,
-                          int32_t* iters, double* pri, double* dua, double* obj, int threads) {
+                          int32_t* iters, double* pri, double* dua, double* obj, int threads,
+                          const double* warm_x, const double* warm_y, double* y_out) {
   const size_t nv = (size_t)S->N * S->Tm, ns = (size_t)S->K * S->N;
 #ifdef _OPENMP
   if (threads > 0) omp_set_num_threads(threads);
@@ -473,7 +486,8 @@ int admm_port_solve_batch(const port_site* S, const port_opts* O, int B, const i
     int it = 0;
     status[b] = solve_one(S, O, horizon[b], lb + b * nv, ub + b * nv, q + b * nv, pdiag[b], lf ? lf[b] : 0.0, dc ? dc[b] : 0.0, dfloor ? dfloor[b] : 0.0, s_off + b * ns, s_len + b * ns,
                           s_cap + b * ns, s_eq[b] != 0, peak ? peak + (size_t)b * S->Tm : 0, x + b * nv, &it,
-                          pri + b, dua + b, obj + b);
+                          pri + b, dua + b, obj + b, warm_x ? warm_x + b * nv : 0,
+                          warm_y ? warm_y + (size_t)b * S->Mg * S->Tm : 0, y_out ? y_out + (size_t)b * S->Mg * S->Tm : 0);
     iters[b] = it;
   }
   return 0;

@@ -67,11 +67,12 @@ def equilibrated(site):
     pk = scale[nrows - 1] if site.has_peak else 1.0
     mx = scale[nrows - 1 - int(site.has_peak)] if getattr(site, "has_max", False) else 1.0
     fl = scale[nrows - 1 - int(site.has_peak) - int(getattr(site, "has_max", False))] if getattr(site, "has_flat", False) else 1.0
+    equilibrated.last_scale = scale   # per row: y (caller's units) = scale * y (this solver's units)
     return G, np.ascontiguousarray(Gh), np.ascontiguousarray(Q), lam, lim, pk, fl, mx
 
 
 def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.02, sigma=1e-6, alpha=1.4, adapt_tol=3.0,
-                reg_rel=0.06, max_iter=20000, check_every=20, adapt_every=20, accel_mem=0):
+                reg_rel=0.06, max_iter=20000, check_every=20, adapt_every=20, accel_mem=0, warm_x=None, warm_y=None):
     """Solve a builder.ProblemBatch-like object on the CPU; same defaults as
     acnqp_default_options.  Returns dict of arrays."""
     lib = _load()
@@ -91,9 +92,13 @@ def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.02, sigma=1e
             np.ascontiguousarray(batch.s_cap, np.float64), np.ascontiguousarray(batch.s_eq, np.uint8)]
     peak = None if batch.peak is None else np.ascontiguousarray(batch.peak * pk_s, np.float64)
     x = np.zeros((B, N, Tm)); status = np.zeros(B, np.int32); iters = np.zeros(B, np.int32)
-    pri = np.zeros(B); dua = np.zeros(B); obj = np.zeros(B)
+    pri = np.zeros(B); dua = np.zeros(B); obj = np.zeros(B); y = np.zeros((B, site.Mg, Tm))
+    scale = equilibrated.last_scale
+    wx = None if warm_x is None else np.ascontiguousarray(warm_x, np.float64)
+    wy = None if warm_y is None else np.ascontiguousarray(np.asarray(warm_y, float) / scale[None, :, None], np.float64)
     lib.admm_port_solve_batch(
         C.byref(S), C.byref(O), C.c_int(B), *[p(a) for a in arrs], None if peak is None else p(peak),
         p(x), p(status), p(iters), p(pri), p(dua), p(obj), C.c_int(int(threads)),
+        None if wx is None else p(wx), None if wy is None else p(wy), p(y),
     )
-    return dict(x=x, status=status, iters=iters, pri_res=pri, dua_res=dua, obj=obj)
+    return dict(x=x, status=status, iters=iters, pri_res=pri, dua_res=dua, obj=obj, y=y * scale[None, :, None])

@@ -109,3 +109,32 @@ def wide_case(g, name):
     peak = None if np.isnan(pk[0]) else (float(pk[0]) if len(pk) == 1 else pk.copy())
     exp = dict(rates=g[f"{name}_rates"], obj=float(g[f"{name}_obj"]))
     return sessions, infra, iface, meta, peak, exp
+
+
+# ---- a minimal closed-loop plant (shape of the reference's integration tests, t_int.py:16-48, without acnsim) --------
+def closed_loop_fleet(infra, rng, n_evs=45, t_span=24, stay=(8, 13), fill=(0.5, 0.95), period=5):
+    """EV records for a congested closed loop: arrivals over ``t_span`` periods, stays of ``stay`` periods, requests a
+    ``fill`` fraction of what the stay could deliver at 32 A."""
+    evs = []
+    k = infra.voltages[0] * period / 1e3 / 60
+    for n, i in enumerate(rng.choice(infra.num_stations, size=n_evs, replace=False)):
+        arr = int(rng.integers(0, t_span))
+        dur = int(rng.integers(stay[0], stay[1]))
+        evs.append(dict(station=infra.station_ids[int(i)], sid=f"ev{n}", arrival=arr, departure=arr + dur,
+                        requested=float(rng.uniform(*fill) * 32 * dur * k), delivered=0.0))
+    return evs
+
+
+def closed_loop_sessions(evs, t):
+    """SessionInfo list of the EVs plugged in at period ``t`` that still need energy."""
+    return [SessionInfo(e["station"], e["sid"], e["requested"], e["delivered"], e["arrival"], e["departure"],
+                        current_time=t, max_rates=32.0)
+            for e in evs if e["arrival"] <= t < e["departure"] and e["requested"] - e["delivered"] > 1e-9]
+
+
+def closed_loop_apply(evs, t, first_period_rates, infra, period=5):
+    k = infra.voltages[0] * period / 1e3 / 60
+    for e in evs:
+        if e["arrival"] <= t < e["departure"]:
+            r = float(first_period_rates[infra.get_station_index(e["station"])])
+            e["delivered"] = min(e["requested"], e["delivered"] + r * k)

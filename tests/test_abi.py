@@ -26,7 +26,7 @@ def test_header_symbols_all_exported(hip_library):
 
 
 def test_abi_version_and_defaults(hip_library):
-    assert hip_library.acnqp_abi_version() == 5
+    assert hip_library.acnqp_abi_version() == 6
     o = backend.default_options()
     assert o.precision == 64 and 0 < o.alpha < 2 and o.max_iter > 0 and o.eps_abs > 0
     o2 = backend.default_options(eps_abs=1e-9, max_iter=5)

@@ -10,14 +10,15 @@ infra, iface = H.caltech_interface()
 obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
 names = ["r0+P+wh(8mfma)","barrier","psum+eh+hh","xt mfma+clip","xpose back+y1","siterows","check","xpose fwd","newton-other","anderson event","aa:dots+reduce","aa:solve"]
 for ct in ("SOC","LINEAR"):
-    snaps = sites.snapshot_batch(infra, 12, 256, seed=20240)
+    NB = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    snaps = sites.snapshot_batch(infra, 12, NB, seed=20240)
     batch = build_batch(snaps, infra, iface, obj, ct)
     h = SiteHandle(batch.site, 0)
     res = h.solve(batch, default_options())
     lib = load_library()
-    buf = (C.c_ulonglong * (256*16*12))()
-    lib.acnqp_debug_read_stamps(buf, 256*16*12)
-    st = np.array(buf, dtype=np.float64).reshape(256,16,12)[:, :4]
+    buf = (C.c_ulonglong * (1024*16*12))()
+    lib.acnqp_debug_read_stamps(buf, 1024*16*12)
+    st = np.array(buf, dtype=np.float64).reshape(1024,16,12)[:NB, :4]
     per_iter = st / res.iters[:,None,None]
     print(ct, "kernel_ms %.2f"%res.kernel_ms, "iters max", res.iters.max())
     tot = per_iter.sum(-1).mean()
