@@ -357,17 +357,24 @@ static bool stream_shape(const acnqp_handle* h, int t_max) {
   return h->N > 64 && t_max <= 48 && !h->has_max;
 }
 
-template <int CT, int MT>
-static hipError_t launch_stream_one(const acnqp::StreamArgs& sa, hipStream_t st) {
-  const acnqp::StreamLds L(MT, CT);
+template <int CT, int MT, int NWV>
+static hipError_t launch_stream_nwv(const acnqp::StreamArgs& sa, hipStream_t st) {
+  const acnqp::StreamLds L(MT, CT, NWV);
   const size_t lds = (size_t)L.total * sizeof(double);
-  auto kern = &acnqp::admm_stream_kernel<CT, MT>;
+  auto kern = &acnqp::admm_stream_kernel<CT, MT, NWV>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(acnqp::kStreamWaves * 64), lds, st, sa);
+  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
   return hipGetLastError();
+}
+
+// 4 waves per problem and two problems per CU when the batch can fill the chip twice over (throughput), 8 waves per
+// problem otherwise (latency); same bits either way (acn_qp_stream.hpp)
+template <int CT, int MT>
+static hipError_t launch_stream_one(const acnqp::StreamArgs& sa, hipStream_t st) {
+  return sa.t.B >= 384 ? launch_stream_nwv<CT, MT, 4>(sa, st) : launch_stream_nwv<CT, MT, 8>(sa, st);
 }
 
 static hipError_t launch_stream(const acnqp::StreamArgs& sa, hipStream_t st) {
@@ -539,7 +546,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   if (stream) {
     // large-site kernel: iterates streamed through a per-problem workspace in MFMA fragment order
     const int CT = (p->t_max + 15) / 16;
-    sa.ws_per_problem = acnqp::stream_workspace(h->NP, CT, p->k_sessions);
+    sa.ws_per_problem = acnqp::stream_workspace(h->NP, CT, p->k_sessions, d->MR / 16);
     DevBuf* wsb = h->workspace_for(st);
     const size_t need = (size_t)sa.ws_per_problem * p->batch * sizeof(double);
     if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));
@@ -672,8 +679,10 @@ struct ChunkLayout {
 long long chunk_problems(size_t per_problem_bytes) {
   long long want = 2048;   // problems per launch: large enough that the launch tail (its slowest problems) is short
   if (const char* e = std::getenv("ACNQP_CHUNK")) { const long long v = std::atoll(e); if (v > 0) want = v; }
-  const long long by_mem = (long long)((size_t)512 * 1024 * 1024 / std::max<size_t>(per_problem_bytes, 1));
-  return std::max<long long>(1, std::min(want, by_mem));
+  const long long by_mem = (long long)((size_t)1024 * 1024 * 1024 / std::max<size_t>(per_problem_bytes, 1));
+  long long n = std::max<long long>(1, std::min(want, by_mem));
+  if (n >= 512) n -= n % 512;   // whole rounds of the chip's 512 workgroup slots (2 per CU): no thin last round
+  return n;
 }
 
 int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_options* o, acnqp_results* R) {

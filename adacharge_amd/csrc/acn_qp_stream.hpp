@@ -13,11 +13,13 @@
 // One workgroup of 8 waves per problem; wave w owns EVSE tiles w, w + 8, ...  Per iteration ONE fused pass over the
 // tiles: load (x, z1, y1, q, lb, ub) -> r0 -> x~ (MFMA, e^ from LDS) -> relaxation -> box + energy-row projection
 // (water-filling along the 16-lane DPP row that holds one EVSE's periods, all column tiles in registers) -> y1 ->
-// store (x, z1, y1) -> the NEW r0 feeds the tile's contribution to next iteration's P straight from registers (its
-// C-layout registers are the MFMA B operand, as in the tiled kernel).  Nine N x T arrays cross HBM per iteration:
-// 9 * 8 * NP * TP bytes -- the kernel is HBM-bound by design (the MFMAs take ~1/4 of that time).
-// The 8 partial P sets are reduced through LDS in fixed order (deterministic), the <= 48 x 48 site-row state
-// (z2, y2, G x, e^, h^) lives in LDS and is advanced by the wave that owns each 16 x 16 tile.
+// store (x, z1, y1) -> the NEW r0 of the tile.  Nine N x T arrays cross HBM per iteration (9 * 8 * NP * TP bytes,
+// non-temporal: they must not evict the shared site fragments from L2): the kernel is HBM-bound by design.
+// P = Ghat r0 is formed in ROUNDS of 8 tiles: every wave parks its tile's new r0 in an LDS slab (it is the MFMA B
+// operand as it stands), and the wave that OWNS an output tile (m, c) of P accumulates the 8 staged tiles into its
+// one or two accumulators -- 8-16 registers instead of the 72 a per-wave partial P would pin, no cross-wave
+// reduction, and a fixed summation order (deterministic).  The <= 48 x 48 site-row state (z2, y2, G x, e^, h^)
+// lives in LDS and is advanced by the same owner waves.
 //
 // Not in this kernel (the general-shape kernel keeps them): Anderson acceleration, the infeasibility certificate,
 // the demand-charge row.  acn_qp_api.hip routes accordingly.
@@ -29,7 +31,9 @@
 
 namespace acnqp {
 
-constexpr int kStreamWaves = 8;
+// Waves per workgroup is a template parameter NWV: 4 (two workgroups = two problems share a CU and fill each other's
+// memory phases: best throughput on large batches) or 8 (one workgroup per CU: a single problem finishes sooner).
+// The summation order of every reduction is the same for both, so the choice never changes a result bit.
 
 struct StreamArgs {
   TiledArgs t;          // same site / problem / result / option fields as the tiled kernel (fragG covers NP / 16 tiles)
@@ -38,28 +42,25 @@ struct StreamArgs {
 };
 
 // doubles of workspace one problem needs
-__host__ __device__ inline long long stream_workspace(int NP, int CT, int K) {
+__host__ __device__ inline long long stream_workspace(int NP, int CT, int K, int MT) {
   const long long NT = (long long)(NP / 16) * CT * 256;
-  return 6 * NT + (long long)K * NP + 64;
+  return 6 * NT + (long long)K * NP + 3LL * MT * CT * 256 + 64;
 }
 
 // LDS carve-up (doubles)
 struct StreamLds {
-  int red, g0h, we, z2, y2, gx, scal, total;
-  __host__ __device__ StreamLds(int MT, int CT) {
+  int red, g0h, we, scal, total;
+  __host__ __device__ StreamLds(int MT, int CT, int NWV) {
     int o = 0;
-    red = o;  o += kStreamWaves * CT * 256;
-    g0h = o;  o += MT * CT * 256;
-    we = o;   o += MT * CT * 256;
-    z2 = o;   o += MT * CT * 256;
-    y2 = o;   o += MT * CT * 256;
-    gx = o;   o += MT * CT * 256;
-    scal = o; o += kStreamWaves * 8 + 8;
+    red = o;  o += NWV * CT * 256;            // the round's staged tiles
+    g0h = o;  o += MT * CT * 256;             // Ghat z1 (start) / h^
+    we = o;   o += MT * CT * 256;             // e^: B operand of every tile's x~ product
+    scal = o; o += NWV * 8 + 8;
     total = o;
   }
 };
 
-template <int NV>
+template <int NV, int NWV>
 __device__ inline void stream_block_max(double (&v)[NV], double* S, int lane, int wave) {
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
@@ -70,27 +71,25 @@ __device__ inline void stream_block_max(double (&v)[NV], double* S, int lane, in
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     double m = S[k];
-    for (int wv = 1; wv < kStreamWaves; ++wv) m = fmax(m, S[wv * 8 + k]);
+    for (int wv = 1; wv < NWV; ++wv) m = fmax(m, S[wv * 8 + k]);
     v[k] = m;
   }
   __syncthreads();
 }
 
-template <int CT, int MT>
-__global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const StreamArgs SA) {
+template <int CT, int MT, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel(const StreamArgs SA) {
+  constexpr int kStreamWaves = NWV;
   using M = Mfma<double>;
   using vec4 = M::vec4;
   typedef double real;
   const TiledArgs& A = SA.t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   real* sm = reinterpret_cast<real*>(smem_raw);
-  const StreamLds L(MT, CT);
+  const StreamLds L(MT, CT, NWV);
   real* RED = sm + L.red;
   real* G0H = sm + L.g0h;
   real* WE = sm + L.we;
-  real* Z2 = sm + L.z2;
-  real* Y2 = sm + L.y2;
-  real* GX = sm + L.gx;
   real* SC = sm + L.scal;
 
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -109,6 +108,10 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
   real* W0 = SA.work + (size_t)b * SA.ws_per_problem;
   real *Xs = W0, *Z1s = Xs + NT, *Y1s = Z1s + NT, *Qs = Y1s + NT, *LBs = Qs + NT, *UBs = LBs + NT;
   real* MU = UBs + NT;                    // [K][NP]
+  // site-row state (z2, y2, G x) in tile-fragment order: touched by the owner waves once per iteration, L2-resident
+  real* Z2 = MU + (size_t)K * NP;
+  real* Y2 = Z2 + MT * CT * 256;
+  real* GX = Y2 + MT * CT * 256;
   const real* FG = static_cast<const real*>(A.fragG);
   const real* FQ = static_cast<const real*>(A.fragQ);
   const real* Gm = static_cast<const real*>(A.G);
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
   const real pd_user = A.pdiag[b];
   {
     real f[3] = {qn, um, bad};
-    stream_block_max<3>(f, SC, lane, wave);
+    stream_block_max<3, NWV>(f, SC, lane, wave);
     qnorm = f[0];
     pd = effective_pdiag<real>(pd_user, A.reg_rel, qnorm, f[1], A.horizon[b], lfb > 0.0);
     if (f[2] > 0) {
@@ -179,7 +182,13 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
   }
 
   real rho = A.rho0;
-  vec4 pacc[MT][CT];   // this wave's share of Ghat (r0) -- or of Ghat z1 during the start
+  // P = Ghat r0 (or Ghat z1 during the start): this wave's accumulators for the output tiles (m, c) it owns
+  // wave m (< MT) owns the output tiles (m, c) of all column tiles c: a Ghat fragment is then fetched once per
+  // iteration and row tile, not once per column tile as well (the fragments are the only re-read data of the kernel)
+  static_assert(MT <= kStreamWaves, "one owner wave per row tile");
+  constexpr int NOWN = CT;
+  vec4 pown[NOWN];
+  const int n_rounds = (NE + kStreamWaves - 1) / kStreamWaves;
 
   // ---- projection of ONE register row (one EVSE per 16-lane DPP row: EVSE 16 e + rowof(g, r), its periods = the 16
   // lanes times the CT column registers) onto B = box + energy rows.  Same safeguarded Newton as the general-shape
@@ -250,96 +259,106 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
     }
   };
 
-  auto zero_pacc = [&]() __attribute__((always_inline)) {
+  auto zero_pown = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int c = 0; c < CT; ++c) pacc[m][c] = vec4{0, 0, 0, 0};
+    for (int k = 0; k < NOWN; ++k) pown[k] = vec4{0, 0, 0, 0};
   };
-  // pacc += Ghat[:, tile e] * v   (v in C layout = MFMA B operand)
-  auto accumulate_tile = [&](int e, const real (&v)[4][CT]) __attribute__((always_inline)) {
-    const real* fg = FG + (size_t)e * MT * 2 * 4 * 64;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      real af[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) af[s] = fg[((m * 2 + 0) * 4 + s) * 64 + lane];
+  // One round of P: this wave's tile vector v (C layout = MFMA B operand; `have` = the wave has a tile this round)
+  // goes into the slab; after the barrier the owner of each output tile (m, c) adds Ghat[m, e] v_e[c] for the tiles
+  // e of the round, in tile order.  Two barriers per round; RED is the slab.
+  auto p_round = [&](int rd, bool have, const real (&v)[4][CT]) __attribute__((always_inline)) {
+    if (have) {
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) pacc[m][c] = M::mma(af[s], v[s][c], pacc[m][c]);
+        for (int s = 0; s < 4; ++s) RED[((wave * CT + c) * 4 + s) * 64 + lane] = v[s][c];
     }
-  };
-  // fixed-order reduction of the 8 waves' pacc into G0H (one row-tile round at a time through RED)
-  auto reduce_pacc = [&]() __attribute__((always_inline)) {
+    __syncthreads();
+    const int ne = min(kStreamWaves, NE - rd * kStreamWaves);
+    if (wave < MT) {
+      const real* fg = FG + ((size_t)(rd * kStreamWaves) * MT + wave) * 2 * 4 * 64 + lane;
+      // all fragments of the round are requested up front (<= 4 tiles x 4 k-steps), then the MFMA chains run
+      real af[kStreamWaves][4];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+      for (int w = 0; w < kStreamWaves; ++w)
 #pragma unroll
-      for (int c = 0; c < CT; ++c)
+        for (int s = 0; s < 4; ++s) af[w][s] = fg[(size_t)(w < ne ? w : 0) * MT * 2 * 4 * 64 + s * 64];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) RED[((wave * CT + c) * 4 + r) * 64 + lane] = pacc[m][c][r];
-      __syncthreads();
-      for (int c = wave; c < CT; c += kStreamWaves)
+      for (int w = 0; w < kStreamWaves; ++w)
+        if (w < ne) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          real s = 0;
+          for (int c = 0; c < CT; ++c)
 #pragma unroll
-          for (int wv = 0; wv < kStreamWaves; ++wv) s += RED[((wv * CT + c) * 4 + r) * 64 + lane];
-          G0H[((m * CT + c) * 4 + r) * 64 + lane] = s;
+            for (int s = 0; s < 4; ++s) pown[c] = M::mma(af[w][s], RED[((w * CT + c) * 4 + s) * 64 + lane], pown[c]);
         }
-      __syncthreads();
     }
+    __syncthreads();
   };
-  // r0 of every tile from the stored state, pacc = this wave's share of Ghat r0 (start, and after a rho change)
-  auto rebuild_pacc = [&]() __attribute__((always_inline)) {
-    zero_pacc();
-  #pragma unroll 1
-  for (int e = wave; e < NE; e += kStreamWaves) {
-    RELANE();
+  // r0 of every tile from the stored state -> P (start, and after a rho change)
+  auto rebuild_p = [&]() __attribute__((always_inline)) {
+    zero_pown();
+#pragma unroll 1
+    for (int rd = 0; rd < n_rounds; ++rd) {
+      RELANE();
+      const int e = rd * kStreamWaves + wave;
+      const bool have = e < NE;
       real r0[4][CT];
+      if (have) {
 #pragma unroll
-      for (int c = 0; c < CT; ++c)
+        for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const size_t i = fidx(e, c, r);
-          r0[r][c] = sigma * Xs[i] - Qs[i] + rho * Z1s[i] - Y1s[i];
-        }
-      accumulate_tile(e, r0);
+          for (int r = 0; r < 4; ++r) {
+            const size_t i = fidx(e, c, r);
+            r0[r][c] = sigma * Xs[i] - Qs[i] + rho * Z1s[i] - Y1s[i];
+          }
+      }
+      p_round(rd, have, r0);
     }
   };
 
   // ---- start (see acn_qp_tiled.hpp): z1 = Proj_B(-kStartGain q), x = z1, y1 = -(q + pd z1); z2 = G z1 = Q (Ghat z1);
   // warm (optional): z1 = Proj_B(warm_x), y2 = warm_y, y1 = -(q + pd z1 + G' y2) -------------------------------------
   const bool warm = A.warm_x != nullptr && A.warm_y != nullptr;
-  zero_pacc();
+  zero_pown();
 #pragma unroll 1
-  for (int e = wave; e < NE; e += kStreamWaves) {
+  for (int rd = 0; rd < n_rounds; ++rd) {
     RELANE();
+    const int e = rd * kStreamWaves + wave;
+    const bool have = e < NE;
     real z1[4][CT];
+    if (have) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      real zs[CT], lbv[CT], ubv[CT], qv[CT];
+      for (int r = 0; r < 4; ++r) {
+        real zs[CT], lbv[CT], ubv[CT], qv[CT];
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        const size_t i = fidx(e, c, r);
-        qv[c] = Qs[i]; lbv[c] = LBs[i]; ubv[c] = UBs[i];
-        zs[c] = -kStartGain * qv[c];
-        if (warm) {
-          const int ev = 16 * e + M::rowof(g, r), tt = 16 * c + t;
-          const bool ok = ev < N && tt < Tm;
-          zs[c] = ok ? A.warm_x[((size_t)b * N + (ok ? ev : 0)) * Tm + (ok ? tt : 0)] : 0.0;
+        for (int c = 0; c < CT; ++c) {
+          const size_t i = fidx(e, c, r);
+          qv[c] = Qs[i]; lbv[c] = LBs[i]; ubv[c] = UBs[i];
+          zs[c] = -kStartGain * qv[c];
+          if (warm) {
+            const int ev = 16 * e + M::rowof(g, r), tt = 16 * c + t;
+            const bool ok = ev < N && tt < Tm;
+            zs[c] = ok ? A.warm_x[((size_t)b * N + (ok ? ev : 0)) * Tm + (ok ? tt : 0)] : 0.0;
+          }
+        }
+        project_row(e, r, zs, lbv, ubv, z1[r], true);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const size_t i = fidx(e, c, r);
+          Xs[i] = z1[r][c]; Z1s[i] = z1[r][c]; Y1s[i] = -(qv[c] + pd * z1[r][c]);
         }
       }
-      project_row(e, r, zs, lbv, ubv, z1[r], true);
-#pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        const size_t i = fidx(e, c, r);
-        Xs[i] = z1[r][c]; Z1s[i] = z1[r][c]; Y1s[i] = -(qv[c] + pd * z1[r][c]);
-      }
     }
-    accumulate_tile(e, z1);
+    p_round(rd, have, z1);
   }
-  reduce_pacc();
+  // Ghat z1 sits with the owners: hand it to the site-row update below through G0H
+  if (wave < MT) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) G0H[((wave * CT + c) * 4 + r) * 64 + lane] = pown[c][r];
+  }
+  __syncthreads();
 #pragma unroll 1
   for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
       RELANE();
@@ -380,11 +399,15 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
       }
     }
   }
-  rebuild_pacc();
+  rebuild_p();
 
   int status = 2, it = 0, n_adapt = 0;
   real pri = M::big, dua = M::big;
   bool done = false;
+#ifdef ACNQP_STAMPS
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
 #pragma unroll 1
   while (!done) {
     ++it;
@@ -398,12 +421,13 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
     const real* Lmi = Lm + zoff;
     const real* RLi = RL + zoff;
     const int32_t* RTi = A.rowtype + zoff;
-    reduce_pacc();   // G0H = Ghat r0
-    // ---- eigen space, by the wave that owns each 16 x 16 site tile: e^ -> WE, h^ -> G0H --------------------------
-#pragma unroll 1
-    for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
+    // ---- eigen space, by the wave that owns each 16 x 16 site tile (its accumulator holds Ghat r0 for that tile):
+    // e^ -> WE, h^ -> G0H ---------------------------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < NOWN; ++k) {
+      if (wave >= MT) continue;
       RELANE();
-      const int mo = tl / CT, c = tl - mo * CT;
+      const int mo = wave, c = k;
       vec4 wh = {0, 0, 0, 0};
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
@@ -416,13 +440,14 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
       for (int r = 0; r < 4; ++r) {
         const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
         const real lj = Lmi[16 * mo + M::rowof(g, r)];
-        const real g0 = G0H[i];
+        const real g0 = pown[k][r];
         const real e_ = wh[r] - (rho / (a + rho * lj)) * (g0 + lj * wh[r]);
         WE[i] = e_;
         G0H[i] = (g0 + lj * e_) * inv_a;
       }
     }
     __syncthreads();
+    STAMP(1);   // eigen step A + barrier
     // ---- site rows: G x~ = Q h^, relaxation, projection onto C, y2 (owner waves) ---------------------------------
     real sv0 = 0, sv2 = 0;   // |G x - z2|_inf, max(|G x|, |z2|): the site-row share of the residuals
 #pragma unroll 1
@@ -471,14 +496,23 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
       }
     }
     __syncthreads();
+    STAMP(2);   // site rows + barrier
     // ---- the fused pass over this wave's EVSE tiles -------------------------------------------------------------
     real v0 = sv0, v1 = 0, v2 = sv2, v4 = 0, v5 = 0;
-    zero_pacc();
-  #pragma unroll 1
-  for (int e = wave; e < NE; e += kStreamWaves) {
-    RELANE();
+    zero_pown();
+#pragma unroll 1
+    for (int rd = 0; rd < n_rounds; ++rd) {
+      RELANE();
+      const int e = rd * kStreamWaves + wave;
+      const bool have = e < NE;
       real zh[4][CT], sq[4][CT];   // sq = sigma x_new - q: all the new r0 still needs of x and q
+      if (have) {
       const real* fg = FG + (size_t)e * MT * 2 * 4 * 64;
+      real fx[MT][4];              // A fragments of the x~ product: requested with the state, used after it arrived
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) fx[m][s] = fg[((m * 2 + 1) * 4 + s) * 64 + lane];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         real xv[4], z1o[4], y1o[4], qv[4];
@@ -486,39 +520,39 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const size_t i = fidx(e, c, r);
-          xv[r] = Xs[i]; z1o[r] = Z1s[i]; y1o[r] = Y1s[i]; qv[r] = Qs[i];
+          xv[r] = __builtin_nontemporal_load(&Xs[i]); z1o[r] = __builtin_nontemporal_load(&Z1s[i]); y1o[r] = __builtin_nontemporal_load(&Y1s[i]); qv[r] = __builtin_nontemporal_load(&Qs[i]);
           acc[r] = sigma * xv[r] - qv[r] + rho * z1o[r] - y1o[r];
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int s = 0; s < 4; ++s)
-            acc = M::mma(fg[((m * 2 + 1) * 4 + s) * 64 + lane], WE[((m * CT + c) * 4 + s) * 64 + lane], acc);
+            acc = M::mma(fx[m][s], WE[((m * CT + c) * 4 + s) * 64 + lane], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const real xn = acc[r] * inv_a;
           zh[r][c] = alpha * xn + (1.0 - alpha) * z1o[r] + y1o[r] * inv_rho;
           const real xnew = alpha * xn + (1.0 - alpha) * xv[r];
-          Xs[fidx(e, c, r)] = xnew;
+          __builtin_nontemporal_store(xnew, &Xs[fidx(e, c, r)]);
           sq[r][c] = sigma * xnew - qv[r];
         }
       }
-      real v0t = 0, v2t = 0;   // this tile's |x - z1|, max(|x|, |z1|) (check iterations)
+      STAMP(3);   // loads + x~ MFMA + relaxation
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         real lbv[CT], ubv[CT], z1[CT];
 #pragma unroll
-        for (int c = 0; c < CT; ++c) { const size_t i = fidx(e, c, r); lbv[c] = LBs[i]; ubv[c] = UBs[i]; }
+        for (int c = 0; c < CT; ++c) { const size_t i = fidx(e, c, r); lbv[c] = __builtin_nontemporal_load(&LBs[i]); ubv[c] = __builtin_nontemporal_load(&UBs[i]); }
         project_row(e, r, zh[r], lbv, ubv, z1, false);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
           const size_t i = fidx(e, c, r);
           const real y1n = rho * (zh[r][c] - z1[c]);
-          Z1s[i] = z1[c]; Y1s[i] = y1n;
+          __builtin_nontemporal_store(z1[c], &Z1s[i]); __builtin_nontemporal_store(y1n, &Y1s[i]);
           zh[r][c] = sq[r][c] + rho * z1[c] - y1n;   // the new r0, in zh's registers
         }
       }
-      accumulate_tile(e, zh);
+      STAMP(4);   // projection rows + stores
       if (check) {   // residual terms of this tile (state re-read: L2-hot); (G' y2) tile by MFMA with the un-rotated site matrix
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
@@ -540,11 +574,14 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
           }
         }
       }
-      (void)v0t; (void)v2t;
+      }   // have
+      p_round(rd, have, zh);   // the tile's new r0 joins next iteration's P
+      STAMP(5);   // P round
     }
+    STAMP(6);   // check terms
     if (check) {
       real v[5] = {v0, v1, v2, v4, v5};
-      stream_block_max<5>(v, SC, lane, wave);
+      stream_block_max<5, NWV>(v, SC, lane, wave);
       pri = v[0]; dua = v[1];
       const real npri = v[2], ndua = fmax(fmax(v[3], v[4]), qnorm);
       const real eps_p = A.eps_abs + A.eps_rel * npri, eps_d = A.eps_abs + A.eps_rel * ndua;
@@ -560,12 +597,16 @@ __global__ __launch_bounds__(kStreamWaves * 64, 1) void admm_stream_kernel(const
           ++n_adapt;
           rho = fmin(fmax(rho * ratio, 1e-6), 1e6);
           __syncthreads();     // every wave's stores of this pass are visible before the state is re-read
-          rebuild_pacc();      // r0 depends on rho: this wave's share of Ghat r0 with the new penalty
+          rebuild_p();         // r0 depends on rho: P with the new penalty
         }
       }
     }
   }
 
+#ifdef ACNQP_STAMPS
+  if (lane == 0 && b < 1024)
+    for (int k = 0; k < 12; ++k) g_stamps[(b * 16 + wave) * 12 + k] = st_acc[k];
+#endif
   // ---- results: the feasible iterate z1 is the schedule --------------------------------------------------------
   __syncthreads();
   real ol = 0;
