@@ -404,10 +404,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   int status = 2, it = 0, n_adapt = 0;
   real pri = M::big, dua = M::big;
   bool done = false;
-#ifdef ACNQP_STAMPS
-  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
-#endif
 #pragma unroll 1
   while (!done) {
     ++it;
@@ -447,7 +443,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       }
     }
     __syncthreads();
-    STAMP(1);   // eigen step A + barrier
     // ---- site rows: G x~ = Q h^, relaxation, projection onto C, y2 (owner waves) ---------------------------------
     real sv0 = 0, sv2 = 0;   // |G x - z2|_inf, max(|G x|, |z2|): the site-row share of the residuals
 #pragma unroll 1
@@ -496,7 +491,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       }
     }
     __syncthreads();
-    STAMP(2);   // site rows + barrier
     // ---- the fused pass over this wave's EVSE tiles -------------------------------------------------------------
     real v0 = sv0, v1 = 0, v2 = sv2, v4 = 0, v5 = 0;
     zero_pown();
@@ -537,7 +531,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
           sq[r][c] = sigma * xnew - qv[r];
         }
       }
-      STAMP(3);   // loads + x~ MFMA + relaxation
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         real lbv[CT], ubv[CT], z1[CT];
@@ -552,7 +545,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
           zh[r][c] = sq[r][c] + rho * z1[c] - y1n;   // the new r0, in zh's registers
         }
       }
-      STAMP(4);   // projection rows + stores
       if (check) {   // residual terms of this tile (state re-read: L2-hot); (G' y2) tile by MFMA with the un-rotated site matrix
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
@@ -576,9 +568,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       }
       }   // have
       p_round(rd, have, zh);   // the tile's new r0 joins next iteration's P
-      STAMP(5);   // P round
     }
-    STAMP(6);   // check terms
     if (check) {
       real v[5] = {v0, v1, v2, v4, v5};
       stream_block_max<5, NWV>(v, SC, lane, wave);
@@ -603,10 +593,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
     }
   }
 
-#ifdef ACNQP_STAMPS
-  if (lane == 0 && b < 1024)
-    for (int k = 0; k < 12; ++k) g_stamps[(b * 16 + wave) * 12 + k] = st_acc[k];
-#endif
   // ---- results: the feasible iterate z1 is the schedule --------------------------------------------------------
   __syncthreads();
   real ol = 0;

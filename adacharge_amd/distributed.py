@@ -35,19 +35,23 @@ def solve_sharded(
 
     if not dist.is_initialized():
         x, st = solve_local(0, n_problems)
-        return np.asarray(x), np.asarray(st)
+        to_np = lambda a: a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+        return to_np(x), to_np(st)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_range(n_problems, rank, world)
     x, st = solve_local(lo, hi)
-    x = np.asarray(x, dtype=np.float64)
-    st = np.asarray(st, dtype=np.int32)
     cap = max(shard_range(n_problems, r, world)[1] - shard_range(n_problems, r, world)[0] for r in range(world))
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
-    xs = torch.zeros((cap,) + x.shape[1:], dtype=torch.float64, device=device)
+    # a shard that is already a tensor on the collective's device (DeviceBatch.x after solve_device, or the x_dev sink
+    # of acnqp_solve_batches) enters the all-gather from HBM; numpy shards are uploaded once
+    as_tensor = lambda a, dt: (a.to(device=device, dtype=dt) if torch.is_tensor(a)
+                               else torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt))
+    x, st = as_tensor(x, torch.float64), as_tensor(st, torch.int32)
+    xs = torch.zeros((cap,) + tuple(x.shape[1:]), dtype=torch.float64, device=device)
     ss = torch.zeros((cap,), dtype=torch.int32, device=device)
-    xs[: hi - lo] = torch.from_numpy(x).to(device)
-    ss[: hi - lo] = torch.from_numpy(st).to(device)
+    xs[: hi - lo] = x
+    ss[: hi - lo] = st
     xg = torch.empty((world * cap,) + x.shape[1:], dtype=torch.float64, device=device)
     sg = torch.empty((world * cap,), dtype=torch.int32, device=device)
     dist.all_gather_into_tensor(xg, xs, group=group)

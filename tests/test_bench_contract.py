@@ -1,5 +1,5 @@
 """The JSON line bench.py prints is a contract with the driver: check the committed record of the last GPU run
-(profiles/r01c_bench.json, written by `python bench.py` on an MI355X) and the bookkeeping helpers, on the CPU."""
+(profiles/r02_bench.json, written by `python bench.py` on an MI355X) and the bookkeeping helpers, on the CPU."""
 import json
 import os
 
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01c_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -29,9 +29,27 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1
-    # value = problems of all timed steps / wall time
-    assert abs(d["value"] - d["n_gpus"] * d["config"]["batch_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    # value = problems of all timed steps / wall time; a step = one acnqp_solve_batches call over batches x batch problems
+    cfg = d["config"]
+    assert cfg["problems_per_step_per_gpu"] == cfg["batch"] * cfg["batches_per_step_per_gpu"] and cfg["batch"] == 256
+    assert abs(d["value"] - d["n_gpus"] * cfg["problems_per_step_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["ms_per_step"] * d["steps"] >= 500.0          # the timed region is long enough for the driver's clock
+    assert "H2D" in cfg["workload"] and "D2H" in cfg["workload"]   # the metric SURVEY.md section 8d defines
     assert d["solver"]["solved"] == d["solver"]["problems"]
+    # roofline of the dominant kernel: algorithmic bytes of one launch / its HIP-event duration
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_avg_ms"] * 1e-3) / 1e9) <= 1e-9 * r["achieved"]
+
+
+def test_bench_gpus_flag_needs_matching_world_size(monkeypatch):
+    """`--gpus N` with a WORLD_SIZE that disagrees is refused before torch / HIP are touched."""
+    import pytest
+    import sys
+
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert "WORLD_SIZE" in str(exc.value)
 
 
 def test_algorithmic_bytes_and_flops_bookkeeping():
