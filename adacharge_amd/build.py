@@ -16,7 +16,7 @@ CSRC = os.path.join(ROOT, "adacharge_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "adacharge_amd", "lib")
 LIB = os.path.join(LIBDIR, "libacn_qp_hip.so")
 SOURCES = [os.path.join(CSRC, "acn_qp_api.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, "acn_qp_tiled.hpp"), os.path.join(CSRC, "acn_qp_general.hpp"), os.path.join(ROOT, "include", "acn_qp.h")]
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("acn_qp_tiled.hpp", "acn_qp_general.hpp", "acn_qp_stream.hpp", "acn_qp_long.hpp")] + [os.path.join(ROOT, "include", "acn_qp.h")]
 
 
 def hipcc_path() -> str:

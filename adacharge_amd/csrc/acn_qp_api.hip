@@ -13,6 +13,7 @@
 #include "acn_qp_tiled.hpp"
 #include "acn_qp_general.hpp"
 #include "acn_qp_stream.hpp"
+#include "acn_qp_long.hpp"
 
 namespace {
 
@@ -392,6 +393,42 @@ static hipError_t launch_stream(const acnqp::StreamArgs& sa, hipStream_t st) {
   }
 }
 
+// shapes the long-horizon MFMA kernel takes (acn_qp_long.hpp): what the two kernels above leave, up to 288 periods
+// and two row tiles, no demand-charge row
+static int long_tiles(int t_max) { return t_max <= 96 ? 6 : (t_max <= 144 ? 9 : (t_max <= 192 ? 12 : 18)); }
+static bool long_shape(const acnqp_handle* h, int t_max, int k_sessions) {
+  if (std::getenv("ACNQP_NO_LONG")) return false;   // diagnostic: the general-shape kernel instead
+  return !tiled_shape(h, t_max, k_sessions) && !stream_shape(h, t_max) && !h->has_max && t_max <= 288 &&
+         h->dev64.MR <= 32;
+}
+
+template <int CTL, int MT>
+static hipError_t launch_long_one(const acnqp::StreamArgs& sa, hipStream_t st) {
+  const acnqp::LongLds L(MT);
+  const size_t lds = (size_t)L.total * sizeof(double);
+  auto kern = &acnqp::admm_long_kernel<CTL, MT>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(acnqp::kLongWaves * 64), lds, st, sa);
+  return hipGetLastError();
+}
+
+static hipError_t launch_long(const acnqp::StreamArgs& sa, hipStream_t st) {
+  const int CTL = long_tiles(sa.t.Tm), MT = sa.t.MR / 16;
+  switch (CTL * 10 + MT) {
+    case 61: return launch_long_one<6, 1>(sa, st);
+    case 62: return launch_long_one<6, 2>(sa, st);
+    case 91: return launch_long_one<9, 1>(sa, st);
+    case 92: return launch_long_one<9, 2>(sa, st);
+    case 121: return launch_long_one<12, 1>(sa, st);
+    case 122: return launch_long_one<12, 2>(sa, st);
+    case 181: return launch_long_one<18, 1>(sa, st);
+    default: return launch_long_one<18, 2>(sa, st);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -541,12 +578,23 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.pbuf_single = 0;
   const bool tiled = tiled_shape(h, p->t_max, p->k_sessions);
   const bool stream = !tiled && stream_shape(h, p->t_max);
+  const bool lng = long_shape(h, p->t_max, p->k_sessions);
   acnqp::GeneralArgs ga;
   acnqp::StreamArgs sa;
   if (stream) {
     // large-site kernel: iterates streamed through a per-problem workspace in MFMA fragment order
     const int CT = (p->t_max + 15) / 16;
     sa.ws_per_problem = acnqp::stream_workspace(h->NP, CT, p->k_sessions, d->MR / 16);
+    DevBuf* wsb = h->workspace_for(st);
+    const size_t need = (size_t)sa.ws_per_problem * p->batch * sizeof(double);
+    if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(wsb->reserve(need));
+    sa.work = static_cast<double*>(wsb->p);
+    a.accel_mem = 0;
+    sa.t = a;
+  } else if (lng) {
+    // long-horizon kernel: same workspace idea, one more array (r0 / zh)
+    sa.ws_per_problem = acnqp::long_workspace(h->NP, long_tiles(p->t_max), p->k_sessions, d->MR / 16);
     DevBuf* wsb = h->workspace_for(st);
     const size_t need = (size_t)sa.ws_per_problem * p->batch * sizeof(double);
     if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));
@@ -580,6 +628,8 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     e = launch_any<double>(a, h->NW, st);
   } else if (stream) {
     e = launch_stream(sa, st);
+  } else if (lng) {
+    e = launch_long(sa, st);
   } else {
     // workgroup size by problem size: the plain loops are latency-bound, more threads per problem hide more of it
     const long long nvar = (long long)h->N * p->t_max;
@@ -604,6 +654,7 @@ int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, 
   if (precision != 64) return 0;
   if (!tiled_shape(h, t_max, k_sessions)) {
     if (stream_shape(h, t_max)) return 0;                // large-site kernel: plain ADMM
+    if (long_shape(h, t_max, k_sessions)) return 0;      // long-horizon kernel: plain ADMM
     return std::min(requested, acnqp::kGenAccelMax);     // general-shape kernel: ring in its workspace
   }
   SiteDev* d = &h->dev64;
