@@ -404,14 +404,7 @@ static bool long_shape(const acnqp_handle* h, int t_max, int k_sessions) {
 
 template <int CTL, int MT>
 static hipError_t launch_long_one(const acnqp::StreamArgs& sa, hipStream_t st) {
-  const acnqp::LongLds L(MT);
-  const size_t lds = (size_t)L.total * sizeof(double);
-  auto kern = &acnqp::admm_long_kernel<CTL, MT>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(acnqp::kLongWaves * 64), lds, st, sa);
+  hipLaunchKernelGGL((acnqp::admm_long_kernel<CTL, MT, 8>), dim3(sa.t.B), dim3(8 * 64), 0, st, sa);
   return hipGetLastError();
 }
 
@@ -594,13 +587,13 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     sa.t = a;
   } else if (lng) {
     // long-horizon kernel: same workspace idea, one more array (r0 / zh)
-    sa.ws_per_problem = acnqp::long_workspace(h->NP, long_tiles(p->t_max), p->k_sessions, d->MR / 16);
+    a.accel_mem = std::min(a.accel_mem, acnqp::kLongAccelMax);
+    sa.ws_per_problem = acnqp::long_workspace(h->NP, long_tiles(p->t_max), p->k_sessions, d->MR / 16, a.accel_mem);
     DevBuf* wsb = h->workspace_for(st);
     const size_t need = (size_t)sa.ws_per_problem * p->batch * sizeof(double);
     if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(wsb->reserve(need));
     sa.work = static_cast<double*>(wsb->p);
-    a.accel_mem = 0;
     sa.t = a;
   } else if (!tiled) {
     // general-shape fallback: state streamed through a global workspace (not graph-capturable: it may allocate)
@@ -654,7 +647,7 @@ int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, 
   if (precision != 64) return 0;
   if (!tiled_shape(h, t_max, k_sessions)) {
     if (stream_shape(h, t_max)) return 0;                // large-site kernel: plain ADMM
-    if (long_shape(h, t_max, k_sessions)) return 0;      // long-horizon kernel: plain ADMM
+    if (long_shape(h, t_max, k_sessions)) return std::min(requested, acnqp::kLongAccelMax);   // ring in its workspace
     return std::min(requested, acnqp::kGenAccelMax);     // general-shape kernel: ring in its workspace
   }
   SiteDev* d = &h->dev64;
