@@ -404,7 +404,16 @@ static bool long_shape(const acnqp_handle* h, int t_max, int k_sessions) {
 
 template <int CTL, int MT>
 static hipError_t launch_long_one(const acnqp::StreamArgs& sa, hipStream_t st) {
-  hipLaunchKernelGGL((acnqp::admm_long_kernel<CTL, MT, 8>), dim3(sa.t.B), dim3(8 * 64), 0, st, sa);
+  // 8 waves per problem: 256 registers per lane hold a row item of any supported horizon without scratch (16 waves
+  // at 128 registers spilled ~230 of them and ran slower)
+  constexpr int NWV = 8;
+  const size_t lds = (size_t)2 * MT * CTL * 256 * sizeof(double);   // e^, h^
+  auto kern = &acnqp::admm_long_kernel<CTL, MT, NWV>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
   return hipGetLastError();
 }
 

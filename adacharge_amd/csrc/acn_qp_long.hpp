@@ -6,30 +6,53 @@
 // Same ADMM as acn_qp_tiled.hpp / acn_qp_stream.hpp.  What changes is who owns what.  Only ONE step of the iteration
 // couples the periods of an EVSE: the projection onto its energy rows (water-filling over the session window).
 // Everything else -- P = Ghat r0, the eigen-space step, the site-row projection, x~ = (r0 + Ghat' e^) / a -- is
-// independent per period.  So an iteration is two phases over two kinds of work item, one wave per item:
+// independent per period.  An iteration is three phases over small work items, dealt round-robin to the 8 waves
+// of the problem's workgroup, with the state streaming through a per-problem workspace in MFMA fragment order
+// (L2 / MALL resident at these sizes: 54 x 144 is 74 KB per array):
 //
-//   phase 1, item = one COLUMN TILE (16 periods, every EVSE tile and every site-row tile of it):
-//     P[:, c] = sum_e Ghat[:, e] r0[e, c]  ->  e^, h^  ->  G x~ = Q h^, relaxation, projection onto C, y2
-//     ->  x~[e, c] = (r0[e, c] + Ghat[:, e]' e^) / a for every e, relaxation, zh[e, c] -> workspace.
-//     The whole chain runs in the wave's registers: an MFMA accumulator tile IS the B operand of the next product
-//     (the site fragments are stored pre-permuted for that), so no LDS and no barrier inside the phase.
-//   phase 2, item = one REGISTER ROW of an EVSE tile (4 EVSEs x the WHOLE horizon, CTL column registers per lane):
-//     zh, lb, ub -> water-filling (safeguarded Newton along the 16-lane DPP rows) -> z1, y1, the new r0 -> workspace.
+//   1a  item = one 16 x 16 SITE tile (row tile m, column tile c):
+//         P = sum_e Ghat[m, e] r0[e, c],  w^ = Q[:, m]' (rho z2 - y2)[:, c]   (MFMA)  ->  e^, h^ of the tile -> LDS
+//   1b  item = one site tile:  G x~ = Q h^ (MFMA, h^ from LDS), relaxation, projection onto C, y2
+//       item = one EVSE tile (e, c):  x~ = (r0 + Ghat[:, e]' e^) / a (MFMA, e^ from LDS), relaxation, zh -> workspace
+//   2   item = one REGISTER ROW of an EVSE tile (4 EVSEs x the WHOLE horizon, CTL column registers per lane):
+//         zh, lb, ub -> water-filling (safeguarded Newton along the 16-lane DPP rows) -> z1, y1, the new r0
 //
-// Two barriers per iteration, whatever the horizon.  With 16 waves per problem a 54 x 144 problem has 9 column items
-// and 16 row items: every phase is one step deep, and the latency of an iteration is a handful of dependent L2
-// round trips.  State streams through a per-problem workspace in MFMA fragment order (L2 / MALL resident at these
-// sizes: 54 x 144 is 74 KB per array); the site-row state of a column is only ever touched by the wave that owns it.
-//
-// Anderson acceleration as in the other kernels (the ring lives in the workspace); the infeasibility certificate of
-// acn_qp_tiled.hpp.  Not in this kernel (the general-shape kernel keeps it): the demand-charge row.
+// Three barriers per iteration whatever the horizon; e^ and h^ (the only data every tile of a column needs) stay in
+// LDS.  A 54 x 144 problem has 9-18 items in 1a, 45-54 in 1b, 16 in phase 2: every phase keeps all four SIMDs busy.
+// What bounds an iteration is the CU's vector-memory issue rate: a 64-lane 8-byte access costs ~16 cycles of the
+// texture addresser whoever issues it (tools/micro/rt_latency.hip), and an iteration makes ~2,800 of them.
+// Anderson acceleration as in the other kernels (the ring lives in the workspace; its passes run over the tile items
+// of 1b); the infeasibility certificate of acn_qp_tiled.hpp.  Not in this kernel (the general-shape kernel keeps it):
+// the demand-charge row, whose prox couples the periods of a SITE row.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "acn_qp_stream.hpp"
 
 namespace acnqp {
+
+// The per-problem workspace is addressed as ONE buffer resource: a 128-bit descriptor in scalar registers, the lane's
+// byte offset in one vector register shared by every access, and the array / tile offset as a 32-bit scalar operand
+// of the instruction.  With ~20 arrays, plain pointers cost a 64-bit per-lane address per array (the compiler forms
+// base + lane once and keeps -- or spills -- all of them); this costs nothing per access.
+typedef unsigned ws_v2u __attribute__((ext_vector_type(2)));
+struct WsArr64 { unsigned off; };   // byte offset of an array of doubles inside the problem's workspace
+struct WsArr32 { unsigned off; };   // ... of floats
+__device__ inline WsArr32 operator+(WsArr32 a, size_t n) { return WsArr32{a.off + (unsigned)n * 4u}; }
+struct WsRef64 {
+  __amdgpu_buffer_rsrc_t rs; unsigned vo, so;
+  __device__ inline operator double() const { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, vo, so, 0)); }
+  __device__ inline void operator=(double v) const { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ws_v2u, v), rs, vo, so, 0); }
+  __device__ inline void operator-=(double v) const { *this = (double)*this - v; }
+};
+struct WsRef32 {
+  __amdgpu_buffer_rsrc_t rs; unsigned vo, so;
+  __device__ inline operator float() const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0)); }
+  __device__ inline void operator=(float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, so, 0); }
+};
 
 constexpr int kLongAccelMax = 5;   // Anderson columns (the ring lives in the workspace: any shape takes all five)
 
@@ -41,8 +64,7 @@ __host__ __device__ inline long long long_workspace(int NP, int CTL, int K, int 
   return w;
 }
 
-// CTL: column registers of a row item (>= ceil(Tm / 16)); NWV: waves per problem (16: 128 registers per lane, rows of
-// up to 9 column tiles; 8: 256 registers, rows of up to 18)
+// CTL: column registers of a row item (>= ceil(Tm / 16)); NWV: waves per problem
 template <int CTL, int MT, int NWV>
 __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs SA) {
   using M = Mfma<double>;
@@ -53,6 +75,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   __shared__ real SC[NWV * 8 + 8];
   __shared__ real AaRedS[NWV * (AMX + 2)];
   __shared__ real AaHS[NWV * (AMX * AMX + AMX)];
+  __shared__ real RowLam[16 * MT], RowLim[16 * MT], RowDj[16 * MT];   // per padded site row: eigenvalue, limit, rho / (a + rho lam)
+  __shared__ int RowTy[16 * MT];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  real* EH = reinterpret_cast<real*>(smem_raw);   // e^ [MT][CTL][4][64]
+  real* HH = EH + MT * CTL * 256;                 // h^ (start: Ghat z1)
 
   const int b = blockIdx.x, tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,27 +88,28 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
 #define RELANE() do { asm volatile("" : "+v"(lane)); g = lane >> 4; t = lane & 15; } while (0)
   const int N = A.N, Tm = A.Tm, NP = A.NP, K = A.K;
   const int NE = NP >> 4;                 // EVSE tiles
-  const int nct = (Tm + 15) >> 4;         // column tiles that hold periods (<= CTL); the rest is padding, never touched
+  const int nct = (Tm + 15) >> 4;         // column tiles that hold periods (<= CTL); the rest is padding, all zero
+  const int n_site = MT * nct, n_tile = n_site + NE * nct;   // tile items: site tiles first, then EVSE tiles
   const long long NT = (long long)NE * CTL * 256;
   real* W0 = SA.work + (size_t)b * SA.ws_per_problem;
-  real *Xs = W0, *Z1s = Xs + NT, *Y1s = Z1s + NT, *Qs = Y1s + NT, *LBs = Qs + NT, *UBs = LBs + NT;
-  real* RZ = UBs + NT;                    // r0 (written by phase 2, read by phase 1) / zh (the other way round)
-  real* MU = RZ + NT;                     // [K][NP]
-  real* Z2 = MU + (size_t)K * NP;         // site-row state in tile-fragment order [MT][CTL][4][64]
-  real* Y2 = Z2 + MT * CTL * 256;
-  real* GX = Y2 + MT * CTL * 256;
+  const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(W0, 0, (int)(SA.ws_per_problem * 8), 0x00020000);
+  const unsigned NT8 = (unsigned)NT * 8u;
+  const WsArr64 Xs{0}, Z1s{NT8}, Y1s{2 * NT8}, Qs{3 * NT8}, LBs{4 * NT8}, UBs{5 * NT8};
+  const WsArr64 RZ{6 * NT8};              // r0 (written by phase 2, read by phase 1) / zh (the other way round)
+  real* MU = W0 + 7 * NT;                 // [K][NP] (indexed per lane: a plain pointer)
+  const unsigned MS8 = (unsigned)(MT * CTL * 256) * 8u;
+  const WsArr64 Z2{7 * NT8 + (unsigned)(K * NP) * 8u};   // site-row state in tile-fragment order [MT][CTL][4][64]
+  const WsArr64 Y2{Z2.off + MS8}, GX{Y2.off + MS8};
   // Anderson acceleration (acn_qp_tiled.hpp, oracle/admm_port.c): pre-projection site rows of an event iteration, the
   // previous event's u / f / g over the EVSE part [0, NT) and the site part [NT, NT + MS), the dF / dG rings (floats)
   const int aa_m = min(max(A.accel_mem, 0), AMX);
   const unsigned MS = (unsigned)(MT * CTL * 256), DU = (unsigned)NT + MS;
-  float* Y1P = reinterpret_cast<float*>(GX + MS);   // duals at the previous check (infeasibility certificate)
-  float* Y2P = Y1P + NT;
-  real* ZHR = GX + MS + (NT + MS + 1) / 2;
-  real* UP = ZHR + MS;
-  real* FP = UP + DU;
-  real* GP = FP + DU;
-  float* HF = reinterpret_cast<float*>(GP + DU);
-  float* HG = HF + (size_t)aa_m * DU;
+  const WsArr32 Y1P{GX.off + MS8};        // duals at the previous check (infeasibility certificate)
+  const WsArr32 Y2P{Y1P.off + (unsigned)NT * 4u};
+  const WsArr64 ZHR{GX.off + MS8 + ((DU + 1) / 2) * 8u};
+  const WsArr64 UP{ZHR.off + MS8}, FP{UP.off + DU * 8u}, GP{FP.off + DU * 8u};
+  const WsArr32 HF{GP.off + DU * 8u};
+  const WsArr32 HG{HF.off + (unsigned)aa_m * DU * 4u};
   real* AaH = AaHS + wave * (AMX * AMX + AMX);   // this wave's copy of (H, b): every wave runs the small solve itself
   const real* FG = static_cast<const real*>(A.fragG);
   const real* FQ = static_cast<const real*>(A.fragQ);
@@ -92,9 +120,22 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   const real sigma = A.sigma, alpha = A.alpha;
   const real lfb = A.lf ? A.lf[b] / (A.flat_scale * A.flat_scale) : 0.0;
 
-  // offsets inside one problem's arrays fit 32 bits: scalar base + per-lane offset addressing
-  auto fidx = [&](int e, int c, int r) -> unsigned { return (unsigned)(((e * CTL + c) * 4 + r) * 64 + lane); };
-  auto sidx2 = [&](int m, int c, int r) -> unsigned { return (unsigned)(((m * CTL + c) * 4 + r) * 64 + lane); };
+  // Addressing: every access is (array + wave-uniform offset)[lane] -- a scalar base and one 32-bit lane offset per
+  // instruction instead of a 64-bit per-lane address computed for each of them.  fidx / sidx2 are the uniform parts.
+  auto fidx = [&](int e, int c, int r) -> unsigned { return (unsigned)(((e * CTL + c) * 4 + r) * 64); };
+  auto sidx2 = [&](int m, int c, int r) -> unsigned { return (unsigned)(((m * CTL + c) * 4 + r) * 64); };
+  // (the lane's byte offset is formed in 32 bits and zero-extended: the shape the scalar-base addressing mode takes)
+  auto at = [&](auto base, unsigned uo) -> decltype(auto) {
+    typedef decltype(base) B;
+    if constexpr (std::is_same<B, WsArr64>::value) return WsRef64{wsr, (unsigned)lane * 8u, base.off + uo * 8u};
+    else if constexpr (std::is_same<B, WsArr32>::value) return WsRef32{wsr, (unsigned)lane * 4u, base.off + uo * 4u};
+    else {   // a plain pointer (site fragments, LDS): uniform base, the lane's byte offset zero-extended from 32 bits
+      typedef typename std::remove_pointer<B>::type elem_t;
+      typedef typename std::conditional<std::is_const<elem_t>::value, const char, char>::type byte_t;
+      const unsigned lo = (unsigned)lane * (unsigned)sizeof(elem_t);
+      return (*reinterpret_cast<B>(reinterpret_cast<byte_t*>(base + uo) + lo));
+    }
+  };
 
   // ---- init (row items): inputs -> fragment order; |q|_inf, max ub; a session whose bounds cannot meet its energy
   // row ----------------------------------------------------------------------------------------------------------
@@ -106,21 +147,18 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     const int ev = 16 * e + M::rowof(g, r);
     real lbv[CTL], ubv[CTL];
 #pragma unroll
-    for (int c = 0; c < CTL; ++c) {
-      lbv[c] = 0; ubv[c] = 0;
-      if (c < nct) {
-        const int tt = 16 * c + t;
-        const bool ok = ev < N && tt < Tm;
-        const size_t idx = ((size_t)b * N + (ok ? ev : 0)) * Tm + (ok ? tt : 0);
-        const real l = ok ? A.lb[idx] : 0.0;
-        real u = ok ? A.ub[idx] : 0.0;
-        const real q = ok ? A.q[idx] : 0.0;
-        if (u < l) u = l;
-        lbv[c] = l; ubv[c] = u;
-        const unsigned i = fidx(e, c, r);
-        LBs[i] = l; UBs[i] = u; Qs[i] = q;
-        qn = fmax(qn, fabs(q)); um = fmax(um, u);
-      }
+    for (int c = 0; c < CTL; ++c) {   // every column register, padding included (zeros): the row passes never branch
+      const int tt = 16 * c + t;
+      const bool ok = ev < N && tt < Tm;
+      const size_t idx = ((size_t)b * N + (ok ? ev : 0)) * Tm + (ok ? tt : 0);
+      const real l = ok ? A.lb[idx] : 0.0;
+      real u = ok ? A.ub[idx] : 0.0;
+      const real q = ok ? A.q[idx] : 0.0;
+      if (u < l) u = l;
+      lbv[c] = l; ubv[c] = u;
+      const unsigned i = fidx(e, c, r);
+      at(LBs, i) = l; at(UBs, i) = u; at(Qs, i) = q;
+      qn = fmax(qn, fabs(q)); um = fmax(um, u);
     }
 #pragma unroll 1
     for (int k = 0; k < K; ++k) {
@@ -226,75 +264,35 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     }
   };
 
-  // P[:, c] = sum over EVSE tiles of Ghat[:, e] v[e, c], v = the RZ array (r0, or z1 during the start), in tile order.
-  // The operands of a tile are requested as one batch, a tile ahead of the MFMAs that consume them (two register
-  // sets): left to itself the compiler issues one load per MFMA and waits for each.
-  auto load_p = [&](int e, int c, const real* fgb, real (&bv)[4], real (&af)[MT][4]) __attribute__((always_inline)) {
-    const real* fg = fgb + (size_t)e * MT * 2 * 4 * 64 + lane;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) bv[s] = RZ[fidx(e, c, s)];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) af[m][s] = fg[((m * 2 + 0) * 4 + s) * 64];
-  };
-  auto mma_p = [&](const real (&bv)[4], const real (&af)[MT][4], vec4 (&p)[MT]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int m = 0; m < MT; ++m) p[m] = M::mma(af[m][s], bv[s], p[m]);
-  };
-  auto column_p = [&](int c, const real* fgb, vec4 (&p)[MT]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) p[m] = vec4{0, 0, 0, 0};
-    real bvA[4], afA[MT][4], bvB[4], afB[MT][4];
-    load_p(0, c, fgb, bvA, afA);
-#pragma unroll 1
-    for (int e = 0; e < NE; e += 2) {
-      if (e + 1 < NE) load_p(e + 1, c, fgb, bvB, afB);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_p(bvA, afA, p);
-      __builtin_amdgcn_sched_barrier(0);
-      if (e + 2 < NE) load_p(e + 2, c, fgb, bvA, afA);
-      __builtin_amdgcn_sched_barrier(0);
-      if (e + 1 < NE) mma_p(bvB, afB, p);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  // r0 of column c from the stored state (start, and after a rho change): column items, own columns only
-  auto rebuild_r0 = [&](int c) __attribute__((always_inline)) {
-#pragma unroll 2
-    for (int e = 0; e < NE; ++e)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned i = fidx(e, c, r);
-        RZ[i] = sigma * Xs[i] - Qs[i] + rho * Z1s[i] - Y1s[i];
-      }
-  };
 
-  // u = (z1 + y1 / rho, z2 + y2 / rho) of column c: the Anderson state at the start and after a rho change
-  auto reset_u = [&](int c) __attribute__((always_inline)) {
-    const real ir = 1.0 / rho;
-#pragma unroll 2
-    for (int e = 0; e < NE; ++e)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const unsigned i = fidx(e, c, r); UP[i] = Z1s[i] + Y1s[i] * ir; }
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const unsigned i = sidx2(m, c, r); UP[(unsigned)NT + i] = Z2[i] + Y2[i] * ir; }
+  // the site's row constants -> LDS
+  for (int j = tid; j < 16 * MT; j += NWV * 64) { RowLam[j] = Lm[j]; RowLim[j] = RL[j]; RowTy[j] = A.rowtype[j]; }
+  auto set_dj = [&]() {   // rho / (a + rho lam_j): after every rho change (a barrier follows every call)
+    const real a_ = sigma + pd + rho;
+    for (int j = tid; j < 16 * MT; j += NWV * 64) RowDj[j] = rho / (a_ + rho * Lm[j]);
   };
-  // projection of one site-row tile onto C from its pre-projection point: z2, y2, and the tile's residual terms
+  set_dj();
+
+  // tile item q -> (site tile mo, c) for q < n_site, (EVSE tile e, c) after; column fastest.  The quotient of the
+  // (uniform) division comes out of the vector ALU: readfirstlane puts it back into a scalar register, so that the
+  // tile addresses stay scalar.
+  // ---- projection of one site-row tile onto C from its pre-projection point: z2, y2, the tile's residual terms ----
   real sv0 = 0, sv2 = 0;   // |G x - z2|_inf, max(|G x|, |z2|): the site-row share of the residuals, per iteration
-  auto site_project = [&](int mo, int c, const real (&zhr)[4], const real (&gxn)[4], const int (&ty)[4],
-                          const real (&lim)[4], real pk) __attribute__((always_inline)) {
+  auto site_project = [&](int mo, int c, const real (&zhr)[4], const real (&gxn)[4], real quad) __attribute__((always_inline)) {
+    const int tt = 16 * c + t;
+    real pk = M::big;
+    if (A.peak && tt < Tm) { const double pv = A.peak[(size_t)b * Tm + tt]; pk = pv < M::big ? pv * A.peak_scale : M::big; }
+    int ty[4];
+    real lim[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int j = 16 * mo + M::rowof(g, r); ty[r] = RowTy[j]; lim[r] = RowLim[j]; }
     real scl[2] = {1.0, 1.0};
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr)
       if (ty[2 * pr] == kRowSocRe) {
         const real re = zhr[2 * pr], im = zhr[2 * pr + 1];
         const real n2 = re * re + im * im;
-        if (n2 > lim[2 * pr] * lim[2 * pr]) scl[pr] = lim[2 * pr] / sqrt(n2);
+        if (n2 > lim[2 * pr] * lim[2 * pr]) scl[pr] = lim[2 * pr] * rsqrt_nr(n2);
       }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -302,13 +300,50 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       real zn = zhr[r];
       if (ty[r] == kRowBox) zn = fmin(zn, lim[r]);
       else if (ty[r] == kRowPeak) zn = fmin(zn, pk);
-      else if (ty[r] == kRowQuad) zn = zn * (rho / (rho + lfb));
+      else if (ty[r] == kRowQuad) zn = zn * quad;
       else if (ty[r] == kRowSocRe || ty[r] == kRowSocIm) zn = zn * scl[r >> 1];
-      Y2[i] = rho * (zhr[r] - zn);
-      Z2[i] = zn;
+      at(Y2, i) = rho * (zhr[r] - zn);
+      at(Z2, i) = zn;
       sv0 = fmax(sv0, fabs(gxn[r] - zn));
       sv2 = fmax(sv2, fmax(fabs(gxn[r]), fabs(zn)));
     }
+  };
+  // P tile = sum over EVSE tiles of Ghat[mo, e] v[e, c], v = the RZ array (r0, or z1 during the start), in tile order,
+  // two tiles' operands per batch of loads
+  auto site_p = [&](int mo, int c, const real* fgb) -> vec4 {
+    vec4 p = {0, 0, 0, 0};
+#pragma unroll 1
+    for (int e = 0; e < NE; e += 2) {
+      const int e1 = e + 1 < NE ? e + 1 : e;
+      const real on1 = e + 1 < NE ? 1.0 : 0.0;
+      real b0[4], a0[4], b1[4], a1[4];
+      const real* f0 = fgb + (size_t)(e * MT + mo) * 2 * 4 * 64;
+      const real* f1 = fgb + (size_t)(e1 * MT + mo) * 2 * 4 * 64;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { b0[s] = at(RZ, fidx(e, c, s)); a0[s] = at(f0, s * 64); b1[s] = at(RZ, fidx(e1, c, s)); a1[s] = at(f1, s * 64); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) p = M::mma(a0[s], b0[s], p);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) p = M::mma(a1[s], b1[s] * on1, p);
+    }
+    return p;
+  };
+  // r0 and (if accelerated) u of one EVSE tile from the stored state: start, rho change
+  auto reset_evse = [&](int e, int c) __attribute__((always_inline)) {
+    const real ir = 1.0 / rho;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned i = fidx(e, c, r);
+      const real z = at(Z1s, i), y = at(Y1s, i);
+      at(RZ, i) = sigma * at(Xs, i) - at(Qs, i) + rho * z - y;
+      if (aa_m > 0) at(UP, i) = z + y * ir;
+    }
+  };
+  auto reset_site = [&](int mo, int c) __attribute__((always_inline)) {
+    const real ir = 1.0 / rho;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const unsigned i = sidx2(mo, c, r); at(UP, (unsigned)NT + i) = at(Z2, i) + at(Y2, i) * ir; }
   };
 
   // ---- start (see acn_qp_tiled.hpp): z1 = Proj_B(-kStartGain q), x = z1, y1 = -(q + pd z1); z2 = G z1 = Q (Ghat z1);
@@ -321,69 +356,78 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     real zs[CTL], lbv[CTL], ubv[CTL], z1[CTL];
 #pragma unroll
     for (int c = 0; c < CTL; ++c) {
-      zs[c] = 0; lbv[c] = 0; ubv[c] = 0;
-      if (c < nct) {
-        const unsigned i = fidx(e, c, r);
-        lbv[c] = LBs[i]; ubv[c] = UBs[i];
-        zs[c] = -kStartGain * Qs[i];
-        if (warm) {
-          const int ev = 16 * e + M::rowof(g, r), tt = 16 * c + t;
-          const bool ok = ev < N && tt < Tm;
-          zs[c] = ok ? A.warm_x[((size_t)b * N + (ok ? ev : 0)) * Tm + (ok ? tt : 0)] : 0.0;
-        }
+      const unsigned i = fidx(e, c, r);
+      lbv[c] = at(LBs, i); ubv[c] = at(UBs, i);
+      zs[c] = -kStartGain * at(Qs, i);
+      if (warm) {
+        const int ev = 16 * e + M::rowof(g, r), tt = 16 * c + t;
+        const bool ok = ev < N && tt < Tm;
+        zs[c] = ok ? A.warm_x[((size_t)b * N + (ok ? ev : 0)) * Tm + (ok ? tt : 0)] : 0.0;
       }
     }
     project_row(e, r, zs, lbv, ubv, z1, true);
 #pragma unroll
-    for (int c = 0; c < CTL; ++c)
-      if (c < nct) {
-        const unsigned i = fidx(e, c, r);
-        Xs[i] = z1[c]; Z1s[i] = z1[c]; Y1s[i] = -(Qs[i] + pd * z1[c]); RZ[i] = z1[c];
-      }
+    for (int c = 0; c < CTL; ++c) {
+      const unsigned i = fidx(e, c, r);
+      at(Xs, i) = z1[c]; at(Z1s, i) = z1[c]; at(Y1s, i) = -(at(Qs, i) + pd * z1[c]); at(RZ, i) = z1[c];
+    }
   }
   __syncthreads();
 #pragma unroll 1
-  for (int c = wave; c < nct; c += NWV) {
+  for (int q = wave; q < n_site; q += NWV) {   // Ghat z1 -> HH
     RELANE();
-    vec4 p[MT];
-    column_p(c, FG, p);
+    const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
+    const vec4 p = site_p(mo, c, FG);
 #pragma unroll
-    for (int mo = 0; mo < MT; ++mo) {
-      vec4 zt = {0, 0, 0, 0};
-#pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-          zt = M::mma(FQ[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane], p[mi][s], zt);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned i = sidx2(mo, c, r);
-        real yv = 0;
-        if (warm) {
-          const int j = 16 * mo + M::rowof(g, r), tt = 16 * c + t;
-          const int ja = A.rowabi[j];
-          if (ja >= 0 && tt < Tm) yv = A.warm_y[((size_t)b * A.Mg + ja) * Tm + tt] / static_cast<const real*>(A.rowscale)[j];
-        }
-        Z2[i] = zt[r]; GX[i] = zt[r]; Y2[i] = yv;
-      }
-    }
-    if (warm) {   // y1 = -(q + pd z1 + G' y2): the row items stored the G' y2 = 0 version
+    for (int r = 0; r < 4; ++r) at(HH, sidx2(mo, c, r)) = p[r];
+  }
+  __syncthreads();
 #pragma unroll 1
-      for (int e = 0; e < NE; ++e) {
+  for (int q = wave; q < n_site; q += NWV) {   // z2 = G z1 = Q (Ghat z1), y2
+    RELANE();
+    const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
+    vec4 zt = {0, 0, 0, 0};
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        zt = M::mma(at(FQ, (((mo * MT + mi) * 2 + 1) * 4 + s) * 64), at(HH, sidx2(mi, c, s)), zt);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned i = sidx2(mo, c, r);
+      real yv = 0;
+      if (warm) {
+        const int j = 16 * mo + M::rowof(g, r), tt = 16 * c + t;
+        const int ja = A.rowabi[j];
+        if (ja >= 0 && tt < Tm) yv = A.warm_y[((size_t)b * A.Mg + ja) * Tm + tt] / static_cast<const real*>(A.rowscale)[j];
+      }
+      at(Z2, i) = zt[r]; at(GX, i) = zt[r]; at(Y2, i) = yv;
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int q = wave; q < n_tile; q += NWV) {
+    RELANE();
+    if (q < n_site) {
+      const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
+      if (aa_m > 0) reset_site(mo, c);
+    } else {
+      const int qe = q - n_site;
+      const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
+      if (warm) {   // y1 = -(q + pd z1 + G' y2): the row items stored the G' y2 = 0 version
         vec4 gty = {0, 0, 0, 0};
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int s = 0; s < 4; ++s)
-            gty = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], Y2[sidx2(m, c, s)], gty);
+            gty = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], at(Y2, sidx2(m, c, s)), gty);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Y1s[fidx(e, c, r)] -= gty[r];
+        for (int r = 0; r < 4; ++r) at(Y1s, fidx(e, c, r)) -= gty[r];
       }
+      reset_evse(e, c);
     }
-    rebuild_r0(c);
-    if (aa_m > 0) reset_u(c);
   }
-  // the main loop's phase 1 reads what the same wave just wrote (columns keep their owner): no barrier
+  __syncthreads();
 
   int status = 2, it = 0, n_adapt = 0;
   real pri = M::big, dua = M::big;
@@ -403,6 +447,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   while (!done) {
     ++it;
     const real a = sigma + pd + rho, inv_a = 1.0 / a, inv_rho = 1.0 / rho;
+    const real quad = rho / (rho + lfb);
     const bool check = (it % A.check_every == 0) || it >= A.max_iter;
     // an offset the compiler cannot see through keeps the loads of loop-invariant site data inside the loop (L1 / L2
     // hits) instead of pinning registers across it
@@ -410,177 +455,149 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     asm volatile("" : "+s"(zoff));
     const real* FQi = FQ + zoff;
     const real* FGi = FG + zoff;
-    const real* Lmi = Lm + zoff;
-    const real* RLi = RL + zoff;
-    const int32_t* RTi = A.rowtype + zoff;
     sv0 = 0; sv2 = 0;
     const bool ev_it = aa_m > 0 && it % kAaPeriod == 0;   // Anderson event: the site rows are projected after it
-    // ================= phase 1: column items ===================================================================
+    // ================= phase 1a: site tiles -> e^, h^ ============================================================
 #pragma unroll 1
-    for (int c = wave; c < nct; c += NWV) {
+    for (int q = wave; q < n_site; q += NWV) {
       RELANE();
-      // the column's site-row state and the fragments of the eigen step: requested now, used after P
-      real z2v[MT][4], y2v[MT][4], fq0[MT][MT][4];
+      const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
+      real bz[MT][4], fq0[MT][4];
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const unsigned i = sidx2(m, c, r); z2v[m][r] = Z2[i]; y2v[m][r] = Y2[i]; }
-#pragma unroll
-      for (int mo = 0; mo < MT; ++mo)
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) fq0[mo][mi][s] = FQi[(((mo * MT + mi) * 2 + 0) * 4 + s) * 64 + lane];
-      vec4 p[MT];
-      column_p(c, FGi, p);
-      STAMP(0);   // P of the column
-      // requested now, used after the eigen step: the fragments of Q h^, G x, the row constants
-      real fq1[MT][MT][4], gxv[MT][4], ljv[MT][4], lim[MT][4];
-      int ty[MT][4];
-#pragma unroll
-      for (int mo = 0; mo < MT; ++mo) {
-#pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) fq1[mo][mi][s] = FQi[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int j = 16 * mo + M::rowof(g, r);
-          gxv[mo][r] = GX[sidx2(mo, c, r)];
-          ljv[mo][r] = Lmi[j]; lim[mo][r] = RLi[j]; ty[mo][r] = RTi[j];
+        for (int s = 0; s < 4; ++s) {
+          const unsigned i = sidx2(mi, c, s);
+          bz[mi][s] = rho * at(Z2, i) - at(Y2, i);
+          fq0[mi][s] = at(FQi, (((mo * MT + mi) * 2 + 0) * 4 + s) * 64);
         }
+      const vec4 p = site_p(mo, c, FGi);
+      vec4 wh = {0, 0, 0, 0};
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) wh = M::mma(fq0[mi][s], bz[mi][s], wh);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * mo + M::rowof(g, r);
+        const real lj = RowLam[j];
+        const real e_ = wh[r] - RowDj[j] * (p[r] + lj * wh[r]);
+        at(EH, sidx2(mo, c, r)) = e_;
+        at(HH, sidx2(mo, c, r)) = (p[r] + lj * e_) * inv_a;
       }
-      const int tt = 16 * c + t;
-      real pk = M::big;
-      if (A.peak && tt < Tm) { const double pv = A.peak[(size_t)b * Tm + tt]; pk = pv < M::big ? pv * A.peak_scale : M::big; }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- eigen space: e^, h^ (accumulator layout = the B operand of the products below) ----------------------
-      vec4 eh[MT], hh[MT];
-#pragma unroll
-      for (int mo = 0; mo < MT; ++mo) {
-        vec4 wh = {0, 0, 0, 0};
+    }
+    STAMP(0);   // 1a
+    __syncthreads();
+    STAMP(1);   // barrier
+    // ================= phase 1b: site tiles (G x~, projection onto C) and EVSE tiles (x~, zh) =======================
+#pragma unroll 1
+    for (int q = wave; q < n_tile; q += NWV) {
+      RELANE();
+      if (q < n_site) {
+        const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
+        real fq1[MT][4], hv[MT][4], gxv[4], z2v[4], y2v[4];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) wh = M::mma(fq0[mo][mi][s], rho * z2v[mi][s] - y2v[mi][s], wh);
+          for (int s = 0; s < 4; ++s) {
+            fq1[mi][s] = at(FQi, (((mo * MT + mi) * 2 + 1) * 4 + s) * 64);
+            hv[mi][s] = at(HH, sidx2(mi, c, s));
+          }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const real lj = ljv[mo][r];
-          const real e_ = wh[r] - (rho / (a + rho * lj)) * (p[mo][r] + lj * wh[r]);
-          eh[mo][r] = e_;
-          hh[mo][r] = (p[mo][r] + lj * e_) * inv_a;
-        }
-      }
-      // first EVSE tile of the x~ loop below: requested before the site-row products
-      real rA[4], xA[4], zA[4], yA[4], fA[MT][4], rB[4], xB[4], zB[4], yB[4], fB[MT][4];
-      auto load_x = [&](int e, real (&rv)[4], real (&xv)[4], real (&zv)[4], real (&yv)[4], real (&fx)[MT][4]) __attribute__((always_inline)) {
-        const real* fg = FGi + (size_t)e * MT * 2 * 4 * 64 + lane;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const unsigned i = fidx(e, c, r);
-          rv[r] = RZ[i]; xv[r] = Xs[i]; zv[r] = Z1s[i]; yv[r] = Y1s[i];
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) fx[m][s] = fg[((m * 2 + 1) * 4 + s) * 64];
-      };
-      load_x(0, rA, xA, zA, yA, fA);
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- site rows: G x~ = Q h^, relaxation, projection onto C, y2 ---------------------------------------------
-#pragma unroll
-      for (int mo = 0; mo < MT; ++mo) {
+        for (int r = 0; r < 4; ++r) { const unsigned i = sidx2(mo, c, r); gxv[r] = at(GX, i); z2v[r] = at(Z2, i); y2v[r] = at(Y2, i); }
+        __builtin_amdgcn_sched_barrier(0);
         vec4 zt = {0, 0, 0, 0};
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) zt = M::mma(fq1[mo][mi][s], hh[mi][s], zt);
+          for (int s = 0; s < 4; ++s) zt = M::mma(fq1[mi][s], hv[mi][s], zt);
         real zhr[4], gxn[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          gxn[r] = alpha * zt[r] + (1.0 - alpha) * gxv[mo][r];
-          zhr[r] = alpha * zt[r] + (1.0 - alpha) * z2v[mo][r] + y2v[mo][r] * inv_rho;
+          gxn[r] = alpha * zt[r] + (1.0 - alpha) * gxv[r];
+          zhr[r] = alpha * zt[r] + (1.0 - alpha) * z2v[r] + y2v[r] * inv_rho;
+          at(GX, sidx2(mo, c, r)) = gxn[r];
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) GX[sidx2(mo, c, r)] = gxn[r];
         if (ev_it) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ZHR[sidx2(mo, c, r)] = zhr[r];
+          for (int r = 0; r < 4; ++r) at(ZHR, sidx2(mo, c, r)) = zhr[r];
         } else {
-          site_project(mo, c, zhr, gxn, ty[mo], lim[mo], pk);
+          site_project(mo, c, zhr, gxn, quad);
         }
-      }
-      STAMP(1);   // eigen step, site rows
-      // ---- x~ of every EVSE tile of the column; zh takes r0's place (two register sets, as for P) -----------------
-      auto do_x = [&](int e, const real (&rv)[4], const real (&xv)[4], const real (&zv)[4], const real (&yv)[4],
-                      const real (&fx)[MT][4]) __attribute__((always_inline)) {
+      } else {
+        const int qe = q - n_site;
+        const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
+        const real* fg = FGi + (size_t)e * MT * 2 * 4 * 64;
+        real rv[4], xv[4], zv[4], yv[4], fx[MT][4], ev4[MT][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned i = fidx(e, c, r);
+          rv[r] = at(RZ, i); xv[r] = at(Xs, i); zv[r] = at(Z1s, i); yv[r] = at(Y1s, i);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { fx[m][s] = at(fg, ((m * 2 + 1) * 4 + s) * 64); ev4[m][s] = at(EH, sidx2(m, c, s)); }
+        __builtin_amdgcn_sched_barrier(0);
         vec4 acc = {rv[0], rv[1], rv[2], rv[3]};
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = M::mma(fx[m][s], eh[m][s], acc);
+          for (int s = 0; s < 4; ++s) acc = M::mma(fx[m][s], ev4[m][s], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const unsigned i = fidx(e, c, r);
           const real xn = acc[r] * inv_a;
-          RZ[i] = alpha * xn + (1.0 - alpha) * zv[r] + yv[r] * inv_rho;
-          Xs[i] = alpha * xn + (1.0 - alpha) * xv[r];
+          at(RZ, i) = alpha * xn + (1.0 - alpha) * zv[r] + yv[r] * inv_rho;
+          at(Xs, i) = alpha * xn + (1.0 - alpha) * xv[r];
         }
-      };
-#pragma unroll 1
-      for (int e = 0; e < NE; e += 2) {
-        if (e + 1 < NE) load_x(e + 1, rB, xB, zB, yB, fB);
-        __builtin_amdgcn_sched_barrier(0);
-        do_x(e, rA, xA, zA, yA, fA);
-        __builtin_amdgcn_sched_barrier(0);
-        if (e + 2 < NE) load_x(e + 2, rA, xA, zA, yA, fA);
-        __builtin_amdgcn_sched_barrier(0);
-        if (e + 1 < NE) do_x(e + 1, rB, xB, zB, yB, fB);
-        __builtin_amdgcn_sched_barrier(0);
       }
-      STAMP(2);   // x~, zh
     }
-    STAMP(2);
+    STAMP(2);   // 1b
     if (ev_it) {
       // ---- Anderson event (type II, acn_qp_tiled.hpp / oracle/admm_port.c): u = (zh, zhr) is the state of the
-      // fixed-point map.  Column items again: the wave that wrote a column's zh / zhr reads them back.
+      // fixed-point map.  Tile items again: the wave that wrote a tile's zh / zhr reads it back.
       const bool col = aa_have_prev;
       const int slot = aa_head;
       real d[AMX + 2];
 #pragma unroll
       for (int j = 0; j < AMX + 2; ++j) d[j] = 0;
       // four registers of one tile: g = zsrc[zo + 64 r], state index uo + 64 r
-      auto aa_tile = [&](const real* zsrc, unsigned zo, unsigned uo) __attribute__((always_inline)) {
+      auto aa_tile = [&](WsArr64 zsrc, unsigned zo, unsigned uo) __attribute__((always_inline)) {
         real gv[4], uv[4], fpv[4], gpv[4];
         float hv[AMX][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { gv[r] = zsrc[zo + 64 * r]; uv[r] = UP[uo + 64 * r]; fpv[r] = FP[uo + 64 * r]; gpv[r] = GP[uo + 64 * r]; }
+        for (int r = 0; r < 4; ++r) { gv[r] = at(zsrc, zo + 64 * r); uv[r] = at(UP, uo + 64 * r); fpv[r] = at(FP, uo + 64 * r); gpv[r] = at(GP, uo + 64 * r); }
 #pragma unroll
         for (int j = 0; j < AMX; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             hv[j][r] = 0.f;
-            if (((aa_valid >> j) & 1u) && j != slot) hv[j][r] = HF[(size_t)j * DU + uo + 64 * r];   // uniform
+            if (((aa_valid >> j) & 1u) && j != slot) hv[j][r] = at(HF + (size_t)j * DU, uo + 64 * r);   // uniform
           }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const real f = gv[r] - uv[r];
           d[AMX + 1] += f * f;
           const float cq = (float)(f - fpv[r]);
-          if (col) { HF[(size_t)slot * DU + uo + 64 * r] = cq; HG[(size_t)slot * DU + uo + 64 * r] = (float)(gv[r] - gpv[r]); }
+          if (col) { at(HF + (size_t)slot * DU, uo + 64 * r) = cq; at(HG + (size_t)slot * DU, uo + 64 * r) = (float)(gv[r] - gpv[r]); }
 #pragma unroll
           for (int j = 0; j < AMX; ++j) d[j] += (real)cq * (real)(j == slot ? cq : hv[j][r]);
           d[AMX] += (real)cq * f;
-          FP[uo + 64 * r] = f; GP[uo + 64 * r] = gv[r];
+          at(FP, uo + 64 * r) = f; at(GP, uo + 64 * r) = gv[r];
         }
       };
 #pragma unroll 1
-      for (int c = wave; c < nct; c += NWV) {
+      for (int q = wave; q < n_tile; q += NWV) {
         RELANE();
-#pragma unroll 1
-        for (int e = 0; e < NE; ++e) aa_tile(RZ, fidx(e, c, 0), fidx(e, c, 0));
-#pragma unroll
-        for (int m = 0; m < MT; ++m) aa_tile(ZHR, sidx2(m, c, 0), (unsigned)NT + sidx2(m, c, 0));
+        if (q < n_site) {
+          const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
+          aa_tile(ZHR, sidx2(mo, c, 0), (unsigned)NT + sidx2(mo, c, 0));
+        } else {
+          const int qe = q - n_site;
+          const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
+          aa_tile(RZ, fidx(e, c, 0), fidx(e, c, 0));
+        }
       }
 #pragma unroll
       for (int j = 0; j < AMX + 2; ++j) d[j] = wave_sum<real>(d[j]);
@@ -657,18 +674,18 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         aa_was = true;
       }
       // ---- apply: u = g - sum_j gamma_j dG_j; the site rows are projected from their (extrapolated) point -------
-      auto aa_apply = [&](real* zdst, unsigned zo, unsigned uo, real (&out)[4]) __attribute__((always_inline)) {
+      auto aa_apply = [&](WsArr64 zdst, unsigned zo, unsigned uo, real (&out)[4]) __attribute__((always_inline)) {
         real gv[4];
         float hv[AMX][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) gv[r] = zdst[zo + 64 * r];
+        for (int r = 0; r < 4; ++r) gv[r] = at(zdst, zo + 64 * r);
         if (ext) {
 #pragma unroll
           for (int j = 0; j < AMX; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               hv[j][r] = 0.f;
-              if ((aa_valid >> j) & 1u) hv[j][r] = HG[(size_t)j * DU + uo + 64 * r];   // uniform
+              if ((aa_valid >> j) & 1u) hv[j][r] = at(HG + (size_t)j * DU, uo + 64 * r);   // uniform
             }
 #pragma unroll
           for (int j = 0; j < AMX; ++j)
@@ -676,39 +693,33 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
             for (int r = 0; r < 4; ++r) gv[r] -= gam[j] * (real)hv[j][r];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { UP[uo + 64 * r] = gv[r]; out[r] = gv[r]; }
+        for (int r = 0; r < 4; ++r) { at(UP, uo + 64 * r) = gv[r]; out[r] = gv[r]; }
       };
 #pragma unroll 1
-      for (int c = wave; c < nct; c += NWV) {
+      for (int q = wave; q < n_tile; q += NWV) {
         RELANE();
-#pragma unroll 1
-        for (int e = 0; e < NE; ++e) {
+        if (q < n_site) {
+          const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
+          real zhr[4], gxn[4];
+          aa_apply(ZHR, sidx2(mo, c, 0), (unsigned)NT + sidx2(mo, c, 0), zhr);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gxn[r] = at(GX, sidx2(mo, c, r));
+          site_project(mo, c, zhr, gxn, quad);
+        } else {
+          const int qe = q - n_site;
+          const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
           real o4[4];
           aa_apply(RZ, fidx(e, c, 0), fidx(e, c, 0), o4);
           if (ext) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) RZ[fidx(e, c, r)] = o4[r];
+            for (int r = 0; r < 4; ++r) at(RZ, fidx(e, c, r)) = o4[r];
           }
-        }
-        const int tt = 16 * c + t;
-        real pk = M::big;
-        if (A.peak && tt < Tm) { const double pv = A.peak[(size_t)b * Tm + tt]; pk = pv < M::big ? pv * A.peak_scale : M::big; }
-#pragma unroll
-        for (int mo = 0; mo < MT; ++mo) {
-          real zhr[4], gxn[4], lim[4];
-          int ty[4];
-          aa_apply(ZHR, sidx2(mo, c, 0), (unsigned)NT + sidx2(mo, c, 0), zhr);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int j = 16 * mo + M::rowof(g, r);
-            gxn[r] = GX[sidx2(mo, c, r)]; lim[r] = RLi[j]; ty[r] = RTi[j];
-          }
-          site_project(mo, c, zhr, gxn, ty, lim, pk);
         }
       }
     }
+    STAMP(3);   // Anderson event (amortised)
     __syncthreads();
-    STAMP(3);   // barrier 1
+    STAMP(4);   // barrier
     // ================= phase 2: row items =========================================================================
 #pragma unroll 1
     for (int ri = wave; ri < 4 * NE; ri += NWV) {
@@ -716,59 +727,51 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       const int e = ri >> 2, r = ri & 3;
       real zh[CTL], lbv[CTL], ubv[CTL], z1[CTL];
 #pragma unroll
-      for (int c = 0; c < CTL; ++c) {
-        zh[c] = 0; lbv[c] = 0; ubv[c] = 0;
-        if (c < nct) {   // uniform
-          const unsigned i = fidx(e, c, r);
-          zh[c] = RZ[i]; lbv[c] = LBs[i]; ubv[c] = UBs[i];
-        }
+      for (int c = 0; c < CTL; ++c) {   // padding columns hold zeros and stay zero
+        const unsigned i = fidx(e, c, r);
+        zh[c] = at(RZ, i); lbv[c] = at(LBs, i); ubv[c] = at(UBs, i);
       }
-      STAMP(4);   // row loads issued
       project_row(e, r, zh, lbv, ubv, z1, false);
-      STAMP(5);   // water-filling (includes the wait for the loads)
+      STAMP(5);   // row loads, water-filling
       // x and q of the row as one batch (into the registers of the bounds), then y1, the new r0 and the stores
 #pragma unroll
-      for (int c = 0; c < CTL; ++c)
-        if (c < nct) { const unsigned i = fidx(e, c, r); lbv[c] = Xs[i]; ubv[c] = Qs[i]; }
+      for (int c = 0; c < CTL; ++c) { const unsigned i = fidx(e, c, r); lbv[c] = at(Xs, i); ubv[c] = at(Qs, i); }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < CTL; ++c) {
-        if (c < nct) {
-          const unsigned i = fidx(e, c, r);
-          const real y1n = rho * (zh[c] - z1[c]);
-          Z1s[i] = z1[c]; Y1s[i] = y1n;
-          RZ[i] = sigma * lbv[c] - ubv[c] + rho * z1[c] - y1n;   // the new r0
-        }
+        const unsigned i = fidx(e, c, r);
+        const real y1n = rho * (zh[c] - z1[c]);
+        at(Z1s, i) = z1[c]; at(Y1s, i) = y1n;
+        at(RZ, i) = sigma * lbv[c] - ubv[c] + rho * z1[c] - y1n;   // the new r0
       }
       STAMP(6);   // y1, new r0
     }
     STAMP(6);
     __syncthreads();
-    STAMP(7);   // barrier 2
+    STAMP(7);   // barrier
     if (check) {
-      // ---- residuals (column items; state re-read: L2-hot); (G' y2) by MFMA with the un-rotated site matrix --------
+      // ---- residuals (EVSE tile items; state re-read: L2-hot); (G' y2) by MFMA with the un-rotated site matrix ------
       real v0 = sv0, v1 = 0, v2 = sv2, v4 = 0, v5 = 0;
 #pragma unroll 1
-      for (int c = wave; c < nct; c += NWV) {
+      for (int q = wave + n_site; q < n_tile; q += NWV) {
         RELANE();
-#pragma unroll 1
-        for (int e = 0; e < NE; ++e) {
-          vec4 gty = {0, 0, 0, 0};
+        const int qe = q - n_site;
+        const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
+        vec4 gty = {0, 0, 0, 0};
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-              gty = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], Y2[sidx2(m, c, s)], gty);
+          for (int s = 0; s < 4; ++s)
+            gty = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], at(Y2, sidx2(m, c, s)), gty);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const unsigned i = fidx(e, c, r);
-            const real xk = Xs[i], qk = Qs[i], yk = Y1s[i], zk = Z1s[i];
-            v0 = fmax(v0, fabs(xk - zk));
-            v1 = fmax(v1, fabs(pd * xk + qk + yk + gty[r]));
-            v2 = fmax(v2, fmax(fabs(xk), fabs(zk)));
-            v4 = fmax(v4, fabs(pd * xk));
-            v5 = fmax(v5, fabs(yk + gty[r]));
-          }
+        for (int r = 0; r < 4; ++r) {
+          const unsigned i = fidx(e, c, r);
+          const real xk = at(Xs, i), qk = at(Qs, i), yk = at(Y1s, i), zk = at(Z1s, i);
+          v0 = fmax(v0, fabs(xk - zk));
+          v1 = fmax(v1, fabs(pd * xk + qk + yk + gty[r]));
+          v2 = fmax(v2, fmax(fabs(xk), fabs(zk)));
+          v4 = fmax(v4, fabs(pd * xk));
+          v5 = fmax(v5, fabs(yk + gty[r]));
         }
       }
       real v[5] = {v0, v1, v2, v4, v5};
@@ -784,31 +787,29 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         // phi(l) = l cap + sum_t [ub (v_t - l)+ + lb (v_t - l)-] for any admissible l.
         real w6[2] = {0, 0};   // |v|, |v1 + G'v2|
 #pragma unroll 1
-        for (int c = wave; c < nct; c += NWV) {
+        for (int q = wave; q < n_tile; q += NWV) {
           RELANE();
-          real dv2[MT][4];
+          if (q < n_site) {
+            const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const unsigned i = sidx2(m, c, r);
-              dv2[m][r] = Y2[i] - (real)Y2P[i];
-              w6[0] = fmax(w6[0], fabs(dv2[m][r]));
-            }
-#pragma unroll 1
-          for (int e = 0; e < NE; ++e) {
+            for (int r = 0; r < 4; ++r) { const unsigned i = sidx2(mo, c, r); w6[0] = fmax(w6[0], fabs(at(Y2, i) - (real)at(Y2P, i))); }
+          } else {
+            const int qe = q - n_site;
+            const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
             vec4 gtv = {0, 0, 0, 0};
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-              for (int s = 0; s < 4; ++s)
-                gtv = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], dv2[m][s], gtv);
+              for (int s = 0; s < 4; ++s) {
+                const unsigned i = sidx2(m, c, s);
+                gtv = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], at(Y2, i) - (real)at(Y2P, i), gtv);
+              }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const unsigned i = fidx(e, c, r);
-              const real v1 = Y1s[i] - (real)Y1P[i];
-              w6[0] = fmax(w6[0], fabs(v1));
-              w6[1] = fmax(w6[1], fabs(v1 + gtv[r]));
+              const real v1_ = at(Y1s, i) - (real)at(Y1P, i);
+              w6[0] = fmax(w6[0], fabs(v1_));
+              w6[1] = fmax(w6[1], fabs(v1_ + gtv[r]));
             }
           }
         }
@@ -817,32 +818,30 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         const real vtol = 1e-4 * vn;
         if (vn > 1e-12 * fmax(1.0, qnorm) && w6[1] <= vtol) {   // block-uniform
           real ssum = 0, bad = 0;
-          // site rows (column items)
 #pragma unroll 1
-          for (int c = wave; c < nct; c += NWV) {
+          for (int q = wave; q < n_site; q += NWV) {   // site rows
             RELANE();
+            const int m = __builtin_amdgcn_readfirstlane(q / nct), c = q - m * nct;
             const int tt = 16 * c + t;
             real pk = M::big;
             if (A.peak && tt < Tm) { const double pv = A.peak[(size_t)b * Tm + tt]; pk = pv < M::big ? pv * A.peak_scale : M::big; }
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const unsigned i = sidx2(m, c, r);
-                const int j = 16 * m + M::rowof(g, r);
-                const real v2 = Y2[i] - (real)Y2P[i];
-                const int ty = RTi[j];
-                if (ty == kRowBox) { ssum += RLi[j] * fmax(v2, 0.0); if (v2 < -vtol) bad = 1; }
-                else if (ty == kRowPeak) {
-                  if (pk < M::big) ssum += pk * fmax(v2, 0.0); else if (v2 > vtol) bad = 1;
-                  if (v2 < -vtol) bad = 1;
-                } else if (ty == kRowSocRe) {
-                  const unsigned i2 = sidx2(m, c, (r + 1) & 3);
-                  const real vi = Y2[i2] - (real)Y2P[i2];
-                  ssum += RLi[j] * sqrt(v2 * v2 + vi * vi);
-                } else if (ty == kRowSocIm) {
-                } else if (fabs(v2) > vtol) bad = 1;   // free / quadratic rows admit no ray
-              }
+            for (int r = 0; r < 4; ++r) {
+              const unsigned i = sidx2(m, c, r);
+              const int j = 16 * m + M::rowof(g, r);
+              const real v2_ = at(Y2, i) - (real)at(Y2P, i);
+              const int ty = RowTy[j];
+              if (ty == kRowBox) { ssum += RowLim[j] * fmax(v2_, 0.0); if (v2_ < -vtol) bad = 1; }
+              else if (ty == kRowPeak) {
+                if (pk < M::big) ssum += pk * fmax(v2_, 0.0); else if (v2_ > vtol) bad = 1;
+                if (v2_ < -vtol) bad = 1;
+              } else if (ty == kRowSocRe) {
+                const unsigned i2 = sidx2(m, c, (r + 1) & 3);
+                const real vi = at(Y2, i2) - (real)at(Y2P, i2);
+                ssum += RowLim[j] * sqrt(v2_ * v2_ + vi * vi);
+              } else if (ty == kRowSocIm) {
+              } else if (fabs(v2_) > vtol) bad = 1;   // free / quadratic rows admit no ray
+            }
           }
           // sessions (row items): bound each session's support function; periods outside every window are pinned
           // to lb = ub: support lb * v
@@ -856,9 +855,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
 #pragma unroll
             for (int c = 0; c < CTL; ++c) {
               vv[c] = 0; lbv[c] = 0; ubv[c] = 0; cov[c] = false;
-              if (c < nct) {
+              if (c < nct) {   // the snapshot only covers the columns that hold periods
                 const unsigned i = fidx(e, c, r);
-                vv[c] = Y1s[i] - (real)Y1P[i]; lbv[c] = LBs[i]; ubv[c] = UBs[i];
+                vv[c] = at(Y1s, i) - (real)at(Y1P, i); lbv[c] = at(LBs, i); ubv[c] = at(UBs, i);
               }
             }
 #pragma unroll 1
@@ -915,16 +914,18 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       }
       if (!done) {   // snapshot for the next certificate test
 #pragma unroll 1
-        for (int c = wave; c < nct; c += NWV) {
+        for (int q = wave; q < n_tile; q += NWV) {
           RELANE();
-#pragma unroll 1
-          for (int e = 0; e < NE; ++e)
+          if (q < n_site) {
+            const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const unsigned i = fidx(e, c, r); Y1P[i] = (float)Y1s[i]; }
+            for (int r = 0; r < 4; ++r) { const unsigned i = sidx2(mo, c, r); at(Y2P, i) = (float)at(Y2, i); }
+          } else {
+            const int qe = q - n_site;
+            const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const unsigned i = sidx2(m, c, r); Y2P[i] = (float)Y2[i]; }
+            for (int r = 0; r < 4; ++r) { const unsigned i = fidx(e, c, r); at(Y1P, i) = (float)at(Y1s, i); }
+          }
         }
         have_prev = true;
       }
@@ -939,13 +940,20 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         if (ratio > tol_eff || ratio < 1.0 / tol_eff) {
           ++n_adapt;
           rho = fmin(fmax(rho * ratio, 1e-6), 1e6);
+          set_dj();
+          // r0 and u depend on rho; the fixed-point map changed: restart the ring from the current (z, y)
 #pragma unroll 1
-          for (int c = wave; c < nct; c += NWV) { RELANE(); rebuild_r0(c); if (aa_m > 0) reset_u(c); }   // r0 and u depend on rho; own columns
-          if (aa_m > 0) {   // the fixed-point map changed: restart the ring from the current (z, y)
+          for (int q = wave; q < n_tile; q += NWV) {
+            RELANE();
+            if (q < n_site) { const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct; if (aa_m > 0) reset_site(mo, c); }
+            else { const int qe = q - n_site; const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct; reset_evse(e, c); }
+          }
+          if (aa_m > 0) {
             aa_cnt = 0; aa_head = 0; aa_valid = 0; aa_have_prev = false; aa_was = false;
             __builtin_amdgcn_wave_barrier();
             for (int k = lane; k < AMX * AMX + AMX; k += 64) AaH[k] = 0;
           }
+          __syncthreads();
         }
       }
     }
@@ -959,31 +967,33 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   // ---- results: the feasible iterate z1 is the schedule --------------------------------------------------------
   real ol = 0;
 #pragma unroll 1
-  for (int c = wave; c < nct; c += NWV)
-#pragma unroll 1
-    for (int e = 0; e < NE; ++e)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ev = 16 * e + M::rowof(g, r), tt = 16 * c + t;
-        if (ev < N && tt < Tm) {
-          const unsigned i = fidx(e, c, r);
-          const real z = Z1s[i];
-          A.x[((size_t)b * N + ev) * Tm + tt] = z;
-          ol += (0.5 * pd_user * z + Qs[i]) * z;
-        }
-      }
-  if (A.y_out) {   // site-row multipliers in the caller's row order and units
-#pragma unroll 1
-    for (int c = wave; c < nct; c += NWV)
-#pragma unroll
-      for (int mo = 0; mo < MT; ++mo)
+  for (int q = wave; q < n_tile; q += NWV) {
+    RELANE();
+    if (q < n_site) {
+      if (A.y_out) {   // site-row multipliers in the caller's row order and units
+        const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * mo + M::rowof(g, r), tt = 16 * c + t;
           const int ja = A.rowabi[j];
           if (ja >= 0 && tt < Tm)
-            A.y_out[((size_t)b * A.Mg + ja) * Tm + tt] = Y2[sidx2(mo, c, r)] * static_cast<const real*>(A.rowscale)[j];
+            A.y_out[((size_t)b * A.Mg + ja) * Tm + tt] = at(Y2, sidx2(mo, c, r)) * static_cast<const real*>(A.rowscale)[j];
         }
+      }
+    } else {
+      const int qe = q - n_site;
+      const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ev = 16 * e + M::rowof(g, r), tt = 16 * c + t;
+        if (ev < N && tt < Tm) {
+          const unsigned i = fidx(e, c, r);
+          const real z = at(Z1s, i);
+          A.x[((size_t)b * N + ev) * Tm + tt] = z;
+          ol += (0.5 * pd_user * z + at(Qs, i)) * z;
+        }
+      }
+    }
   }
   ol = wave_sum<real>(ol);
   if (lane == 0) SC[wave] = ol;

@@ -11,17 +11,17 @@ from adacharge_amd.builder import build_batch
 infra = sites.caltech54()
 iface = Interface({"infrastructure_info": infra, "period": 5})
 obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
-names = ["P column", "eigen+site", "x~ / zh", "barrier 1", "row loads", "water-fill", "y1 / r0", "barrier 2", "check"]
+names = ["1a site tiles", "barrier", "1b tiles", "AA event", "barrier", "rows: fill", "rows: y1/r0", "barrier", "check"]
 NB = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 for T in (48, 144, 288):
     snaps = sites.snapshot_batch(infra, T, NB, seed=100 + T, demand_range=(5.0, 60.0))
     batch = build_batch(snaps, infra, iface, obj, "SOC")
     h = SiteHandle(batch.site, 0)
-    res = h.solve(batch, default_options())
+    res = h.solve(batch, default_options(accel_mem=int(os.environ.get("AA", "5"))))
     lib = load_library()
     buf = (C.c_ulonglong * (1024 * 16 * 12))()
     lib.acnqp_debug_read_stamps(buf, 1024 * 16 * 12)
-    nw = 8 if (T > 144 or os.environ.get("ACNQP_LONG_WAVES8")) else 16
+    nw = 8 if T > 144 else 16
     st = np.array(buf, dtype=np.float64).reshape(1024, 16, 12)[:NB, :nw]
     per_iter = st / res.iters[:, None, None]
     tot = per_iter.sum(-1).mean()
