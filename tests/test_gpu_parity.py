@@ -677,6 +677,92 @@ def test_randomised_paths_match_c_port(case):
     h.close()
 
 
+# ---- long horizons: the long-horizon MFMA kernel, and the general-shape kernel it replaced for these shapes ---------
+@pytest.mark.parametrize("site_name,T,ct,accel", [
+    ("caltech54", 48, "SOC", 0), ("caltech54", 144, "SOC", 0), ("caltech54", 144, "LINEAR", 5),
+    ("jpl52", 96, "SOC", 5), ("caltech54", 288, "SOC", 5)])
+def test_long_horizon_kernel_matches_c_twin(site_name, T, ct, accel):
+    """Horizons 33 ... 288 (the reference's 54 x 144 stress shape, tests/test_adacharge_stress.py; a day at 5-minute
+    periods) run through acn_qp_long.hpp.  Plain ADMM follows the C twin iteration for iteration (same status, same
+    iteration count, 1e-6 A); with Anderson acceleration the trajectories may part at a rounding of the event's dot
+    products, so the optimum is compared instead."""
+    from adacharge_amd.acn import Interface
+    from oracle import admm_port
+
+    infra = getattr(sites, site_name)()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
+    snaps = sites.snapshot_batch(infra, T, 6, seed=100 + T, demand_range=(5.0, 60.0))
+    batch = build_batch(snaps, infra, iface, obj, ct)
+    h = SiteHandle(batch.site, 0)
+    opts = default_options(accel_mem=accel)
+    assert h.accel_columns(batch.Tm, batch.K, opts) == accel
+    res = h.solve(batch, opts)
+    ref = admm_port.solve_batch(batch, threads=6, accel_mem=accel)
+    assert (res.status == 1).all() and (ref["status"] == 1).all()
+    if accel == 0:
+        assert (res.iters == ref["iters"]).all()
+        assert np.abs(res.x - ref["x"]).max() <= 1e-6
+    else:
+        assert np.abs(res.iters.astype(int) - ref["iters"].astype(int)).max() <= 0.5 * ref["iters"].max()
+    assert np.abs(res.obj - ref["obj"]).max() <= 2e-5 * np.abs(ref["obj"]).max()
+    # the schedule itself is feasible: bounds, energy rows, network (1e-3 A on the 54-term rows)
+    assert (res.x <= batch.ub + 1e-9).all() and (res.x >= batch.lb - 1e-9).all()
+    for b in range(batch.B):
+        assert iface.is_feasible({sid: res.x[b, i] for i, sid in enumerate(infra.station_ids)}, linear=(ct == "LINEAR"), violation_tolerance=5e-3)
+    h.close()
+
+
+def test_long_horizon_kernel_many_sessions_per_evse_and_warm_start():
+    """K = 3 session slots per EVSE over 96 periods (multipliers of every slot live in the workspace), then the same
+    batch warm-started from its own solution: fewer iterations, same optimum."""
+    from adacharge_amd.acn import Interface
+
+    infra = sites.caltech54()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    rng = np.random.default_rng(96)
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    snaps = [sites.random_sessions_general(infra, 96, rng, True, min_rates=False, demand_scale=1.0) for _ in range(4)]
+    batch = build_batch(snaps, infra, iface, obj, "SOC")
+    assert batch.Tm > 48 and batch.K >= 2
+    h = SiteHandle(batch.site, 0)
+    cold = h.solve(batch, default_options(), want_y=True)
+    assert (cold.status == 1).all()
+    warm = h.solve(batch, default_options(), warm=(cold.x, cold.y))
+    assert (warm.status == 1).all()
+    assert warm.iters.sum() < 0.5 * cold.iters.sum()
+    assert np.abs(warm.x - cold.x).max() <= 5e-4
+    h.close()
+
+
+@pytest.mark.parametrize("ct", ["LINEAR", "SOC"])
+def test_general_kernel_still_serves_what_the_long_kernel_does_not(ct, monkeypatch):
+    """The general-shape kernel keeps the demand-charge row at long horizons, more than 32 site rows and horizons
+    beyond 288; ACNQP_NO_LONG=1 (a diagnostic switch read at every call) routes a long-horizon problem to it: same
+    answer as the long-horizon kernel, and the same infeasibility certificate."""
+    from adacharge_amd.acn import Interface
+
+    infra = sites.caltech54()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    batch = build_batch(sites.snapshot_batch(infra, 40, 4, seed=40), infra, iface, obj, ct)
+    h = SiteHandle(batch.site, 0)
+    fast = h.solve(batch, default_options())
+    monkeypatch.setenv("ACNQP_NO_LONG", "1")
+    slow = h.solve(batch, default_options())
+    assert (fast.status == 1).all() and (slow.status == 1).all()
+    assert np.abs(fast.x - slow.x).max() <= 5e-4
+    h.close()
+    k = 208 * 5 / 60 / 1e3
+    sd = session_generator(2, [0, 0], [40, 40], [20 * 40 * k] * 2, [20 * 40 * k] * 2, [32] * 2)
+    ti = TestingInterface({"active_sessions": sd, "infrastructure_info": single_phase_single_constraint(2, 30),
+                           "current_time": 0, "period": 5})
+    opt = AdaptiveChargingOptimization(DEFAULT_OBJECTIVE, ti, constraint_type=ct, enforce_energy_equality=True,
+                                       solver_options=dict(max_iter=20000))
+    with pytest.raises(InfeasibilityException, match="Solve failed with status infeasible"):
+        opt.solve(ti.active_sessions(), ti.infrastructure_info())
+
+
 # ---- introspection entry points added for benchmarking / CPU restatements ------------------------------
 def test_accel_columns_and_kernel_times():
     import torch
@@ -692,7 +778,7 @@ def test_accel_columns_and_kernel_times():
     assert h.accel_columns(batch.Tm, batch.K, default_options(accel_mem=0)) == 0
     assert h.accel_columns(batch.Tm, batch.K, default_options(accel_mem=3)) == 3
     assert h.accel_columns(batch.Tm, batch.K, default_options(accel_mem=64)) == 5     # what the kernels hold
-    assert h.accel_columns(144, 1, o) == 5                                            # general kernel: same ring size
+    assert h.accel_columns(144, 1, o) == 5                                            # long-horizon kernel: same ring size
     h.kernel_times()   # forget earlier launches
     dev = DeviceBatch(batch, "cuda:0")
     for _ in range(3):
@@ -737,8 +823,8 @@ def test_max_iter_with_small_residuals_is_optimal_inaccurate():
 
 
 @pytest.mark.parametrize("ct", ["LINEAR", "SOC"])
-def test_general_kernel_certifies_infeasibility(ct):
-    """Horizon 40 takes the general-shape kernel.  Two EVSEs must each receive exactly 13.9 kWh (20 A for 40
+def test_long_horizon_kernel_certifies_infeasibility(ct):
+    """Horizon 40 takes the long-horizon kernel.  Two EVSEs must each receive exactly 13.9 kWh (20 A for 40
     periods) through a 30 A feeder: no schedule exists, and the kernel says so instead of iterating to max_iter."""
     k = 208 * 5 / 60 / 1e3
     sd = session_generator(2, [0, 0], [40, 40], [20 * 40 * k] * 2, [20 * 40 * k] * 2, [32] * 2)
