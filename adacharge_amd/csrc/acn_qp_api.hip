@@ -395,7 +395,7 @@ static hipError_t launch_stream(const acnqp::StreamArgs& sa, hipStream_t st) {
 
 // shapes the long-horizon MFMA kernel takes (acn_qp_long.hpp): what the two kernels above leave, up to 288 periods
 // and two row tiles, no demand-charge row
-static int long_tiles(int t_max) { return t_max <= 96 ? 6 : (t_max <= 144 ? 9 : (t_max <= 192 ? 12 : 18)); }
+static int long_tiles(int t_max) { return t_max <= 32 ? 2 : (t_max <= 96 ? 6 : (t_max <= 144 ? 9 : (t_max <= 192 ? 12 : 18))); }
 static bool long_shape(const acnqp_handle* h, int t_max, int k_sessions) {
   if (std::getenv("ACNQP_NO_LONG")) return false;   // diagnostic: the general-shape kernel instead
   return !tiled_shape(h, t_max, k_sessions) && !stream_shape(h, t_max) && !h->has_max && t_max <= 288 &&
@@ -420,6 +420,8 @@ static hipError_t launch_long_one(const acnqp::StreamArgs& sa, hipStream_t st) {
 static hipError_t launch_long(const acnqp::StreamArgs& sa, hipStream_t st) {
   const int CTL = long_tiles(sa.t.Tm), MT = sa.t.MR / 16;
   switch (CTL * 10 + MT) {
+    case 21: return launch_long_one<2, 1>(sa, st);
+    case 22: return launch_long_one<2, 2>(sa, st);
     case 61: return launch_long_one<6, 1>(sa, st);
     case 62: return launch_long_one<6, 2>(sa, st);
     case 91: return launch_long_one<9, 1>(sa, st);

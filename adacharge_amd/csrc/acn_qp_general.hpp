@@ -128,7 +128,8 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   }
   const real sigma = (real)A.sigma, alpha = (real)A.alpha;
   real rho = (real)A.rho0;
-  int status = 2, it = 0, n_adapt = 0;
+  int status = 2, it = 0, n_adapt = 0, best_it = 0;
+  real best_score = M::big;
   real pri = M::big, dua = M::big;
   bool done = false, have_prev = false;
   // ---- energy rows: one thread per session, safeguarded Newton on g(m) = sum clip(zh - m); reads zh and the
@@ -505,11 +506,15 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
         for (int k = tid; k < mt; k += kGenThreads) y2p[k] = (real)(float)y2[k];
         have_prev = true;
       }
+      const real score = fmax(pri / fmax((real)A.eps_abs + (real)A.eps_rel * npri, (real)1e-300),
+                              dua / fmax((real)A.eps_abs + (real)A.eps_rel * ndua, (real)1e-300));
+      if (score < (real)kStallGain * best_score) { best_score = score; best_it = it; }
+      const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel);
+      const bool stalled = it - best_it >= kStallIters && score <= (real)kStallNear * best_score && inacc;   // acn_qp_tiled.hpp
       if (done) {
-      } else if (it >= A.max_iter) {
+      } else if (it >= A.max_iter || stalled) {
         done = true;
-        if (pri <= (real)kInaccurate * ((real)A.eps_abs + (real)A.eps_rel * npri) &&
-            dua <= (real)kInaccurate * ((real)A.eps_abs + (real)A.eps_rel * ndua)) status = 5;   // solved, inaccurately
+        if (inacc) status = 5;   // solved, inaccurately
       }
       else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
         const real sp = pri / fmax(npri, (real)1e-12), sd = dua / fmax(ndua, (real)1e-12);

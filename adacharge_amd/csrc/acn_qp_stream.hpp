@@ -401,7 +401,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   }
   rebuild_p();
 
-  int status = 2, it = 0, n_adapt = 0;
+  int status = 2, it = 0, n_adapt = 0, best_it = 0;
+  real best_score = M::big;
   real pri = M::big, dua = M::big;
   bool done = false;
 #pragma unroll 1
@@ -575,10 +576,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       pri = v[0]; dua = v[1];
       const real npri = v[2], ndua = fmax(fmax(v[3], v[4]), qnorm);
       const real eps_p = A.eps_abs + A.eps_rel * npri, eps_d = A.eps_abs + A.eps_rel * ndua;
+      const real score = fmax(pri / fmax(eps_p, 1e-300), dua / fmax(eps_d, 1e-300));
+      if (score < kStallGain * best_score) { best_score = score; best_it = it; }
+      const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel);
+      const bool stalled = it - best_it >= kStallIters && score <= kStallNear * best_score && inacc;   // acn_qp_tiled.hpp
       if (pri <= eps_p && dua <= eps_d) { status = 1; done = true; }
-      else if (it >= A.max_iter) {
+      else if (it >= A.max_iter || stalled) {
         done = true;
-        if (pri <= kInaccurate * eps_p && dua <= kInaccurate * eps_d) status = 5;
+        if (inacc) status = 5;
       } else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
         const real sp = pri / fmax(npri, 1e-12), sd = dua / fmax(ndua, 1e-12);
         const real ratio = sqrt(sp / fmax(sd, 1e-30));

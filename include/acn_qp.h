@@ -51,12 +51,14 @@ extern "C" {
  * InfeasibilityException exactly as aco.py:319-320 does for cvxpy statuses */
 #define ACNQP_STATUS_UNSET 0
 #define ACNQP_STATUS_SOLVED 1             /* cp.OPTIMAL                     */
-#define ACNQP_STATUS_MAX_ITER 2           /* residuals above tolerance      */
+#define ACNQP_STATUS_MAX_ITER 2           /* residuals above tolerance at max_iter */
 #define ACNQP_STATUS_PRIMAL_INFEASIBLE 3  /* ADMM certificate (cp.INFEASIBLE) */
 #define ACNQP_STATUS_EMPTY_SET 4          /* a session's bounds cannot meet its energy row */
-#define ACNQP_STATUS_SOLVED_INACCURATE 5   /* max_iter reached with both residuals within 100x their
-                                             tolerance: cp.OPTIMAL_INACCURATE, which the reference
-                                             accepts (aco.py:319)              */
+#define ACNQP_STATUS_SOLVED_INACCURATE 5   /* max_iter or the stall rule (no 10 % progress of the residuals for
+                                             3000 iterations) ended the problem with both residuals
+                                             within 100x their tolerance, or within the tolerance cvxpy gives
+                                             OSQP by default (1e-5), whichever is looser: cp.OPTIMAL_INACCURATE,
+                                             which the reference accepts (aco.py:319)              */
 
 /* return codes (never C++ exceptions across the ABI) */
 #define ACNQP_OK 0

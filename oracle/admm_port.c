@@ -83,6 +83,11 @@ static void project_window(int L, const double* v, const double* lb, const doubl
 static const double kStartGain = 1e5;
 static const double kAdaptWiden = 8.0;   /* rho adaptation band: adapt_tol (1 + adaptations / kAdaptWiden) */
 static const int kAaPeriod = 5;
+/* stall rule of the device kernels (acn_qp_tiled.hpp): no 10 % improvement of max(pri / eps_pri, dua / eps_dua) for
+ * kStallIters iterations, the score within kStallNear of its best and the residuals good enough for SOLVED_INACCURATE
+ * end the problem as such */
+static const double kStallGain = 0.9, kStallNear = 1.25;
+static const int kStallIters = 3000;
 static const double kAaReg = 1e-4, kAaSafe = 1.2, kAaDrift = 1e-3;
 
 /* solve (H + eta I) gamma = b for the valid columns (LDL', no pivoting: H is a Gram matrix) */
@@ -144,7 +149,8 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
     qnorm = fmax(qnorm, fabs(q[k]));
     ubmax = fmax(ubmax, ub[k]);
   }
-  int status = 2, it = 0;
+  int status = 2, it = 0, best_it = 0;
+  double best_score = 1e300;
   for (int k = 0; k < K; ++k)
     for (int i = 0; i < N; ++i) {
       const int L = s_len[k * N + i], o = s_off[k * N + i];
@@ -437,10 +443,16 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
         for (int k = 0; k < mt; ++k) yprev[n + k] = (double)(float)y2[k];
         have_yprev = 1;
       }
+      const double score = fmax(pri / fmax(O->eps_abs + O->eps_rel * npri, 1e-300), dua / fmax(O->eps_abs + O->eps_rel * ndua, 1e-300));
+      if (score < kStallGain * best_score) { best_score = score; best_it = it; }
+      /* solved, inaccurately: within 100 x the tolerance, or within cvxpy's OSQP default 1e-5, whichever is looser */
+      const double ea = fmax(100.0 * O->eps_abs, 1e-5), er = fmax(100.0 * O->eps_rel, 1e-5);
+      const int inacc = pri <= ea + er * npri && dua <= ea + er * ndua;
+      const int stalled = it - best_it >= kStallIters && score <= kStallNear * best_score && inacc;
       if (done) {
-      } else if (it >= O->max_iter) {
+      } else if (it >= O->max_iter || stalled) {
         done = 1;
-        if (pri <= 100.0 * (O->eps_abs + O->eps_rel * npri) && dua <= 100.0 * (O->eps_abs + O->eps_rel * ndua)) status = 5;   /* solved, inaccurately */
+        if (inacc) status = 5;
       }
       else if (O->adapt_every > 0 && it % O->adapt_every == 0) {
         const double sp = pri / fmax(npri, 1e-12), sd = dua / fmax(ndua, 1e-12);

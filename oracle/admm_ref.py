@@ -54,6 +54,7 @@ class AdmmOptions:
 
 START_GAIN = 1e5
 ADAPT_WIDEN = 8.0
+STALL_GAIN, STALL_NEAR, STALL_ITERS = 0.9, 1.25, 3000   # the device kernels' stall rule (acn_qp_tiled.hpp)
 AA_PERIOD, AA_REG, AA_SAFE, AA_DRIFT = 5, 1e-4, 1.2, 1e-3
 
 
@@ -224,6 +225,7 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
     pri = dua = np.inf
     it = 0
     n_adapt = 0
+    best_score, best_it = np.inf, 0
     aa = _Anderson(opts.accel_mem, N * Tm + Mg * Tm) if opts.accel_mem > 0 else None
     if aa is not None:
         aa.uprev = np.concatenate([(z1 + y1 / rho).ravel(), z2.ravel()])
@@ -261,8 +263,17 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
             if pri <= opts.eps_abs + opts.eps_rel * npri and dua <= opts.eps_abs + opts.eps_rel * ndua:
                 status = ST_SOLVED
                 break
-            if it == opts.max_iter and pri <= 100 * (opts.eps_abs + opts.eps_rel * npri) and dua <= 100 * (opts.eps_abs + opts.eps_rel * ndua):
+            score = max(pri / max(opts.eps_abs + opts.eps_rel * npri, 1e-300), dua / max(opts.eps_abs + opts.eps_rel * ndua, 1e-300))
+            if score < STALL_GAIN * best_score:
+                best_score, best_it = score, it
+            ea, er = max(100 * opts.eps_abs, 1e-5), max(100 * opts.eps_rel, 1e-5)   # 100 x tolerance or cvxpy's OSQP default
+            inacc = pri <= ea + er * npri and dua <= ea + er * ndua
+            # the device kernels' stall rule (acn_qp_tiled.hpp)
+            stalled = it - best_it >= STALL_ITERS and score <= STALL_NEAR * best_score and inacc
+            if (it == opts.max_iter or stalled) and inacc:
                 status = ST_SOLVED_INACCURATE
+            if stalled:
+                break
             if opts.adaptive_rho and it % opts.adapt_every == 0:
                 ratio = np.sqrt((pri / max(npri, 1e-12)) / max(dua / max(ndua, 1e-12), 1e-30))
                 tol_eff = opts.adapt_tol * (1.0 + n_adapt / ADAPT_WIDEN)   # the band widens: no limit cycles

@@ -373,10 +373,12 @@ def test_config4_stochastic_mpc_1024_scenarios_times_8_sites():
         batch = scenario_batch(base, f)
         h = SiteHandle(batch.site, 0)
         res = h.solve(batch, default_options())
-        # On the most congested synthetic sites 1-2 % of the scenarios sit on a plateau of the primal residual (SOC discs
-        # touching the energy rows tangentially: ADMM turns sub-linear) and end SOLVED_INACCURATE or
-        # MAX_ITER -- reported as such, never as SOLVED; every returned schedule is feasible all the same.
-        assert np.isin(res.status, (1, 2, 5)).all() and (res.status == 1).mean() >= 0.97, (k, np.unique(res.status, return_counts=True))
+        # On the most congested synthetic site ~3 % of the scenarios sit on a plateau of the primal residual (SOC discs
+        # touching the energy rows tangentially: ADMM turns sub-linear): the stall rule ends them
+        # as SOLVED_INACCURATE (residuals below cvxpy's OSQP default 1e-5, above the 1e-8 asked for) -- reported as such,
+        # never as SOLVED; no scenario fails, and every returned schedule is feasible (network rows to 5e-3 A).
+        assert np.isin(res.status, (1, 5)).all() and (res.status == 1).mean() >= 0.96, (k, np.unique(res.status, return_counts=True))
+        assert res.iters.max() <= 12000
         assert (res.x <= batch.ub + 1e-9).all() and (res.x >= batch.lb - 1e-9).all()
         e = np.zeros((S, base.N))
         for i in range(base.N):

@@ -1,6 +1,6 @@
 """One device-resident launch of a BASELINE.json configuration other than the bench's (profiling target):
 
-    python3 tools/run_config.py cfg2-caltech|cfg2-jpl|cfg5|stress144 [batch]
+    python3 tools/run_config.py cfg2-caltech|cfg2-jpl|cfg4|cfg5|stress144 [batch]
 
 cfg2: horizon 24, batch 4096, fp64 (tiled kernel, two column tiles); cfg5: synthetic 512 EVSE x 48, load_flattening
 (large-site MFMA kernel); stress144: the reference's N = 54 x T = 144 stress LP shape (general-shape kernel).
@@ -15,6 +15,32 @@ from adacharge_amd.builder import ProblemBatch, build_batch, scenario_batch
 
 which = sys.argv[1]
 reps = 3
+if which == "cfg4":
+    # configs[3]: 1024 demand scenarios x 8 sites, horizon 12; on one GPU the 8 site shards run one after the other
+    # (on a node: one site per rank).  One JSON line: per-site kernel time, statuses, and the total.
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    st = torch.cuda.current_stream().cuda_stream
+    rows, tot_ms, tot_n = [], 0.0, 0
+    for k, infra in enumerate(sites.eight_sites()):
+        iface = Interface({"infrastructure_info": infra, "period": 5})
+        rng = np.random.default_rng(500 + k)
+        base = build_batch([sites.random_sessions(infra, 12, rng)], infra, iface, obj, "SOC")
+        batch = scenario_batch(base, rng.lognormal(0.0, 0.25, size=(S, base.K, base.N)))
+        h = SiteHandle(batch.site, 0)
+        dev = DeviceBatch(batch, "cuda:0")
+        ms = []
+        for _ in range(reps):
+            h.solve_device(dev, default_options(), stream=st)
+            torch.cuda.synchronize()
+            ms.append(h.last_kernel_ms())
+        it = dev.iters.cpu().numpy(); s_ = dev.status.cpu().numpy()
+        rows.append(dict(site=infra.name if hasattr(infra, "name") else k, n_evse=batch.N, kernel_ms=min(ms), iters_mean=float(it.mean()),
+                         iters_max=int(it.max()), solved=int((s_ == 1).sum()), inaccurate=int((s_ == 5).sum()), max_iter=int((s_ == 2).sum())))
+        tot_ms += min(ms); tot_n += S
+        h.close()
+    print(json.dumps(dict(config="cfg4", scenarios_per_site=S, problems=tot_n, kernel_ms_total=tot_ms, qps=tot_n / tot_ms * 1e3, sites=rows)))
+    raise SystemExit(0)
 if which.startswith("cfg2"):
     infra = sites.caltech54() if which.endswith("caltech") else sites.jpl52()
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
