@@ -65,7 +65,10 @@ __host__ __device__ inline long long long_workspace(int NP, int CTL, int K, int 
 }
 
 // CTL: column registers of a row item (>= ceil(Tm / 16)); NWV: waves per problem
-template <int CTL, int MT, int NWV>
+// LDSR: the iterates (x, z1, y1, q, lb, ub, r0 / zh and the site-row state) live in LDS instead of the workspace -- for
+// problems small enough (N <= 64, horizon <= 32: 7 x 16 KB + site rows + e^, h^ <= 156 KB); only the Anderson vectors,
+// the certificate's snapshot and the session multipliers stay in the workspace.
+template <int CTL, int MT, int NWV, bool LDSR = false>
 __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs SA) {
   using M = Mfma<double>;
   using vec4 = M::vec4;
@@ -94,19 +97,30 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   real* W0 = SA.work + (size_t)b * SA.ws_per_problem;
   const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(W0, 0, (int)(SA.ws_per_problem * 8), 0x00020000);
   const unsigned NT8 = (unsigned)NT * 8u;
-  const WsArr64 Xs{0}, Z1s{NT8}, Y1s{2 * NT8}, Qs{3 * NT8}, LBs{4 * NT8}, UBs{5 * NT8};
-  const WsArr64 RZ{6 * NT8};              // r0 (written by phase 2, read by phase 1) / zh (the other way round)
-  real* MU = W0 + 7 * NT;                 // [K][NP] (indexed per lane: a plain pointer)
   const unsigned MS8 = (unsigned)(MT * CTL * 256) * 8u;
-  const WsArr64 Z2{7 * NT8 + (unsigned)(K * NP) * 8u};   // site-row state in tile-fragment order [MT][CTL][4][64]
-  const WsArr64 Y2{Z2.off + MS8}, GX{Y2.off + MS8};
+  // RZ: r0 (written by phase 2, read by phase 1) / zh (the other way round); Z2, Y2, GX: site-row state in
+  // tile-fragment order [MT][CTL][4][64].  Same workspace layout either way (the LDS-resident variant leaves its
+  // share of it unused).
+  typedef typename std::conditional<LDSR, real*, WsArr64>::type StArr;
+  StArr Xs, Z1s, Y1s, Qs, LBs, UBs, RZ, Z2, Y2, GX;
+  const unsigned z2off = 7 * NT8 + (unsigned)(K * NP) * 8u;
+  if constexpr (LDSR) {
+    real* S0 = HH + MT * CTL * 256;
+    Xs = S0; Z1s = S0 + NT; Y1s = S0 + 2 * NT; Qs = S0 + 3 * NT; LBs = S0 + 4 * NT; UBs = S0 + 5 * NT; RZ = S0 + 6 * NT;
+    Z2 = S0 + 7 * NT; Y2 = Z2 + MT * CTL * 256; GX = Y2 + MT * CTL * 256;
+  } else {
+    Xs = WsArr64{0}; Z1s = WsArr64{NT8}; Y1s = WsArr64{2 * NT8}; Qs = WsArr64{3 * NT8}; LBs = WsArr64{4 * NT8};
+    UBs = WsArr64{5 * NT8}; RZ = WsArr64{6 * NT8};
+    Z2 = WsArr64{z2off}; Y2 = WsArr64{z2off + MS8}; GX = WsArr64{z2off + 2 * MS8};
+  }
+  real* MU = W0 + 7 * NT;                 // [K][NP] (indexed per lane: a plain pointer)
   // Anderson acceleration (acn_qp_tiled.hpp, oracle/admm_port.c): pre-projection site rows of an event iteration, the
   // previous event's u / f / g over the EVSE part [0, NT) and the site part [NT, NT + MS), the dF / dG rings (floats)
   const int aa_m = min(max(A.accel_mem, 0), AMX);
   const unsigned MS = (unsigned)(MT * CTL * 256), DU = (unsigned)NT + MS;
-  const WsArr32 Y1P{GX.off + MS8};        // duals at the previous check (infeasibility certificate)
+  const WsArr32 Y1P{z2off + 3 * MS8};     // duals at the previous check (infeasibility certificate)
   const WsArr32 Y2P{Y1P.off + (unsigned)NT * 4u};
-  const WsArr64 ZHR{GX.off + MS8 + ((DU + 1) / 2) * 8u};
+  const WsArr64 ZHR{z2off + 3 * MS8 + ((DU + 1) / 2) * 8u};
   const WsArr64 UP{ZHR.off + MS8}, FP{UP.off + DU * 8u}, GP{FP.off + DU * 8u};
   const WsArr32 HF{GP.off + DU * 8u};
   const WsArr32 HG{HF.off + (unsigned)aa_m * DU * 4u};
@@ -564,7 +578,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
 #pragma unroll
       for (int j = 0; j < AMX + 2; ++j) d[j] = 0;
       // four registers of one tile: g = zsrc[zo + 64 r], state index uo + 64 r
-      auto aa_tile = [&](WsArr64 zsrc, unsigned zo, unsigned uo) __attribute__((always_inline)) {
+      auto aa_tile = [&](auto zsrc, unsigned zo, unsigned uo) __attribute__((always_inline)) {
         real gv[4], uv[4], fpv[4], gpv[4];
         float hv[AMX][4];
 #pragma unroll
@@ -675,7 +689,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         aa_was = true;
       }
       // ---- apply: u = g - sum_j gamma_j dG_j; the site rows are projected from their (extrapolated) point -------
-      auto aa_apply = [&](WsArr64 zdst, unsigned zo, unsigned uo, real (&out)[4]) __attribute__((always_inline)) {
+      auto aa_apply = [&](auto zdst, unsigned zo, unsigned uo, real (&out)[4]) __attribute__((always_inline)) {
         real gv[4];
         float hv[AMX][4];
 #pragma unroll

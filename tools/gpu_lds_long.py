@@ -1,0 +1,29 @@
+"""A/B of the LDS-resident variant of the long-horizon kernel against the register-resident tiled kernel on small
+shapes (set ACNQP_LDS_LONG=1 or 2 for the variant): kernel time, iterations, parity of the schedules."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from adacharge_amd import ObjectiveComponent, equal_share, quick_charge, sites
+from adacharge_amd.acn import Interface
+from adacharge_amd.backend import SiteHandle, default_options
+from adacharge_amd.builder import build_batch
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+for site_name, T in (("jpl52", 24), ("caltech54", 24), ("jpl52", 12), ("caltech54", 12)):
+    infra = getattr(sites, site_name)()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
+    batch = build_batch(sites.snapshot_batch(infra, T, B, seed=20240), infra, iface, obj, "SOC")
+    out = {}
+    for mode in ("", "1"):
+        if mode: os.environ["ACNQP_LDS_LONG"] = mode
+        else: os.environ.pop("ACNQP_LDS_LONG", None)
+        h = SiteHandle(batch.site, 0)
+        res = h.solve(batch, default_options())
+        res = h.solve(batch, default_options())
+        out[mode] = res
+        print(f"{site_name} T={T} B={B} {'lds-long' if mode else 'tiled   '}: kernel {res.kernel_ms:8.2f} ms  {B / res.kernel_ms:8.1f} kQP/s  its mean {res.iters.mean():.0f} max {res.iters.max()}"
+              f"  status {dict(zip(*np.unique(res.status, return_counts=True)))}", flush=True)
+        h.close()
+    both = (out[""].status == 1) & (out["1"].status == 1)
+    print("   max |dx| on problems solved by both: %.2e" % np.abs(out[""].x[both] - out["1"].x[both]).max(), flush=True)
