@@ -353,16 +353,11 @@ hipError_t launch_any(const acnqp::TiledArgs& a, int NW, hipStream_t st) {
 // synthetic JPL site at horizon 24 of configs[2]) run through the LDS-resident variant of the long-horizon kernel: the
 // register-resident kernel replicates the site-row state in every wave and spills 359+ registers at that shape
 // (measured on 4,096 jpl52 x 24 problems: 189 ms tiled, 128 ms here; every other small shape is faster tiled).
-// ACNQP_LDS_LONG=0 switches it off, =1 / =2 force it for every small shape / every two-row-tile shape (diagnostics).
+// ACNQP_LDS_LONG=0 switches it off (diagnostic).
 static bool lds_long_shape(const acnqp_handle* h, int t_max) {
-  if (!(h->N <= 64 && t_max <= 32 && !h->has_max && h->dev64.MR <= 32)) return false;
   const char* e = std::getenv("ACNQP_LDS_LONG");
-  if (e) {
-    const int mode = std::atoi(e);
-    if (mode == 0) return false;
-    return h->dev64.MR / 16 >= mode;
-  }
-  return t_max > 16 && h->dev64.MR == 32;
+  if (e && std::atoi(e) == 0) return false;
+  return h->N <= 64 && t_max > 16 && t_max <= 32 && !h->has_max && h->dev64.MR == 32;
 }
 static bool tiled_shape(const acnqp_handle* h, int t_max, int k_sessions) {
   if (lds_long_shape(h, t_max)) return false;
@@ -411,7 +406,7 @@ static hipError_t launch_stream(const acnqp::StreamArgs& sa, hipStream_t st) {
 
 // shapes the long-horizon MFMA kernel takes (acn_qp_long.hpp): what the two kernels above leave, up to 288 periods
 // and two row tiles, no demand-charge row
-static int long_tiles(int t_max, bool lds_resident = false) { return (t_max <= 16 && lds_resident) ? 1 : t_max <= 32 ? 2 : (t_max <= 96 ? 6 : (t_max <= 144 ? 9 : (t_max <= 192 ? 12 : 18))); }
+static int long_tiles(int t_max) { return t_max <= 32 ? 2 : (t_max <= 96 ? 6 : (t_max <= 144 ? 9 : 18)); }
 static bool long_shape(const acnqp_handle* h, int t_max, int k_sessions) {
   if (std::getenv("ACNQP_NO_LONG")) return false;   // diagnostic: the general-shape kernel instead
   return !tiled_shape(h, t_max, k_sessions) && !stream_shape(h, t_max) && !h->has_max && t_max <= 288 &&
@@ -446,15 +441,8 @@ static hipError_t launch_long_lds(const acnqp::StreamArgs& sa, hipStream_t st) {
 }
 
 static hipError_t launch_long(const acnqp::StreamArgs& sa, hipStream_t st, bool lds_resident) {
-  const int CTL = long_tiles(sa.t.Tm, lds_resident), MT = sa.t.MR / 16;
-  if (lds_resident) {
-    switch (CTL * 10 + MT) {
-      case 11: return launch_long_lds<1, 1>(sa, st);
-      case 12: return launch_long_lds<1, 2>(sa, st);
-      case 21: return launch_long_lds<2, 1>(sa, st);
-      default: return launch_long_lds<2, 2>(sa, st);
-    }
-  }
+  const int CTL = long_tiles(sa.t.Tm), MT = sa.t.MR / 16;
+  if (lds_resident) return launch_long_lds<2, 2>(sa, st);   // lds_long_shape: two column tiles, two row tiles
   switch (CTL * 10 + MT) {
     case 21: return launch_long_one<2, 1>(sa, st);
     case 22: return launch_long_one<2, 2>(sa, st);
@@ -462,8 +450,6 @@ static hipError_t launch_long(const acnqp::StreamArgs& sa, hipStream_t st, bool 
     case 62: return launch_long_one<6, 2>(sa, st);
     case 91: return launch_long_one<9, 1>(sa, st);
     case 92: return launch_long_one<9, 2>(sa, st);
-    case 121: return launch_long_one<12, 1>(sa, st);
-    case 122: return launch_long_one<12, 2>(sa, st);
     case 181: return launch_long_one<18, 1>(sa, st);
     default: return launch_long_one<18, 2>(sa, st);
   }
@@ -635,7 +621,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   } else if (lng) {
     // long-horizon kernel: same workspace idea, one more array (r0 / zh)
     a.accel_mem = std::min(a.accel_mem, acnqp::kLongAccelMax);
-    sa.ws_per_problem = acnqp::long_workspace(h->NP, long_tiles(p->t_max, lds_long_shape(h, p->t_max)), p->k_sessions, d->MR / 16, a.accel_mem);
+    sa.ws_per_problem = acnqp::long_workspace(h->NP, long_tiles(p->t_max), p->k_sessions, d->MR / 16, a.accel_mem);
     DevBuf* wsb = h->workspace_for(st);
     const size_t need = (size_t)sa.ws_per_problem * p->batch * sizeof(double);
     if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));
