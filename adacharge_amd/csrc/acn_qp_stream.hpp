@@ -399,7 +399,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       }
     }
   }
-  rebuild_p();
+  if (warm) {
+    rebuild_p();
+  } else {
+    // cold start: y1 = -(q + pd z1) and x = z1 make r0 = (sigma + pd + rho) z1 exactly, so P = a (Ghat z1) -- which the
+    // owner waves still hold from the start rounds: one multiplication instead of a pass over four arrays
+    const real a0 = sigma + pd + rho;
+#pragma unroll
+    for (int k = 0; k < NOWN; ++k) pown[k] = pown[k] * a0;
+  }
 
   int status = 2, it = 0, n_adapt = 0, best_it = 0;
   real best_score = M::big;
