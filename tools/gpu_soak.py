@@ -1,4 +1,4 @@
-"""Dev tool: soak the tiled kernel on the randomised problem classes of tests/test_gpu_parity.py (two session slots,
+"""Dev tool: soak the kernels on the randomised problem classes of tests/test_gpu_parity.py (two session slots,
 ragged horizons, peak vectors, equality rows, min rates, two sites) at a larger batch, checking statuses,
 finiteness and the structural invariants of every solved schedule."""
 import sys
@@ -12,13 +12,17 @@ from tests.test_gpu_parity import _random_sessions_general
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 bad_total = 0
-for case in range(8):
+# cases 8-13: the long-horizon kernel (horizons 40 ... 200, two session slots, peaks, equality rows) and its
+# LDS-resident variant (jpl52 at horizons 24 / 30)
+for case in range(14):
     rng = np.random.default_rng(5000 + case)
-    T = [12, 16, 24, 30, 12, 20, 9, 32][case]
+    T = [12, 16, 24, 30, 12, 20, 9, 32, 40, 72, 144, 200, 24, 30][case]
     ct = ["SOC", "LINEAR"][case % 2]
-    eq = case in (2, 5); two = case in (1, 3, 5, 7); with_peak = case in (0, 3, 4, 7)
-    infra = sites.caltech54() if case != 6 else sites.jpl52()
-    iface = Interface({"infrastructure_info": infra, "period": 5, "prices": rng.uniform(0.05, 0.4, size=64)})
+    eq = case in (2, 5, 9); two = case in (1, 3, 5, 7, 8, 10, 13); with_peak = case in (0, 3, 4, 7, 9, 11, 12)
+    infra = sites.caltech54() if case not in (6, 10, 12, 13) else sites.jpl52()
+    if case >= 8 and T > 32:
+        B = max(32, B // 16)
+    iface = Interface({"infrastructure_info": infra, "period": 5, "prices": rng.uniform(0.05, 0.4, size=256)})
     obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 10.0 ** rng.uniform(-4, -2)),
            ObjectiveComponent(tou_energy_cost, float(rng.uniform(0, 5))), ObjectiveComponent(total_energy, float(rng.uniform(0, 2)))]
     snaps, peaks = [], []
