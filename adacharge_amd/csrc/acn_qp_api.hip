@@ -779,6 +779,13 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
         chunks.emplace_back();
         cur_T = (int)Tm; cur_K = (int)K; cur_opt = opt; fill = 0;
         cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96);
+        // ramp: the first kernel cannot start before its chunk's H2D has landed, and nothing overlaps that copy -- a
+        // quarter-size first chunk (then a half-size one) shortens the exposed head of the pipeline
+        static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
+        if (ramp && cap >= 2048) {
+          if (chunks.size() == 1) cap /= 4;
+          else if (chunks.size() == 2) cap /= 2;
+        }
       }
       const long long n = std::min(B - lo, cap - fill);
       chunks.back().push_back({g, lo, n, fill});

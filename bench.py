@@ -12,8 +12,9 @@ One "step" = ONE call of the product entry point `acnqp_solve_batches` over `--b
 batches per GPU, i.e. 16,384 problems per GPU per step, from pinned HOST buffers to pinned HOST buffers:
 H2D of every problem array + kernels + D2H of schedules, statuses, iterations, residuals and objectives,
 all inside the timed region (the metric SURVEY.md section 8d defines; `acnqp_create` -- the one-time site
-upload -- is outside).  The library pipelines the call internally (chunks of 2,048 problems rotate over
-four streams with their own device staging), so there is nothing for the bench to overlap by hand and
+upload -- is outside).  The library pipelines the call internally (chunks of up to 2,048 problems -- 512 and 1,024
+for the first two, which shortens the exposed head of the pipeline -- rotate over four streams with their own
+device staging), so there is nothing for the bench to overlap by hand and
 `value` is what any caller of the API gets.  Weak scaling: every rank owns its own 64 x 256 snapshots.
 For N > 1 each step leaves the rank's schedules in HBM as well (acnqp_results.x_dev) and ends with the
 job's single collective, one RCCL all-gather of the schedules over xGMI, overlapped with the next step's
@@ -38,7 +39,6 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TF = 78.6     # vector fp64 (vendor figure)
-CHUNK_PROBLEMS = 2048        # problems per kernel launch inside acnqp_solve_batches (acn_qp_api.hip, chunk_problems)
 
 
 def parse(argv=None):
@@ -305,7 +305,9 @@ def main():
         del dbig
     if rank == 0:
         batch = batches[0]
-        launch_b = min(CHUNK_PROBLEMS, per_step)
+        # launches of one step differ in size (512, 1,024, then 2,048 problems: acn_qp_api.hip, run_pipeline): the
+        # roofline is stated per MEAN launch -- mean problems per launch over mean launch duration
+        launch_b = per_step * args.steps / max(len(kernel_ms), 1)
         k_avg_ms = float(np.mean(kernel_ms))
         k_sum_ms = float(np.sum(kernel_ms))
         abytes, per_qp, site_bytes = algorithmic_bytes(launch_b, N, Tm, K, batch.site)
@@ -314,7 +316,9 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):   # committed result of the separate rocprofv3 --pmc passes (same command)
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tfile))
+                # launches differ in size: scale the measured bytes per problem to this run's mean launch
+                traffic = tj["hbm_bytes_per_problem"] * launch_b if tj.get("hbm_bytes_per_problem") else tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         fl = flops_per_iteration(N, Tm, batch.site)

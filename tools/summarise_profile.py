@@ -24,6 +24,7 @@ if stats:   # newest run only (gpurun merges, it does not delete)
 summary = {}
 meta = None
 newest = {}
+problems = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
     d_ = os.path.dirname(f)
     if d_ not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d_]):
@@ -35,12 +36,19 @@ for f in sorted(newest.values()):
             continue
         per.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
         per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+        try:   # one workgroup per problem: problems of the dispatch = grid / workgroup size
+            problems.setdefault(row["Counter_Name"], {})[row["Dispatch_Id"]] = int(row["Grid_Size"]) // int(row["Workgroup_Size"])
+        except (KeyError, ValueError, ZeroDivisionError):
+            pass
         if meta is None:
             meta = {k: row[k] for k in ("Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
                                         "Accum_VGPR_Count", "SGPR_Count") if k in row}
     for name, d in per.items():
         v = list(d.values())
         summary[name] = {"dispatches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)}
+        if name in problems and len(problems[name]) == len(v):
+            summary[name]["problems"] = sum(problems[name].values())
+            summary[name]["per_problem"] = sum(v) / max(summary[name]["problems"], 1)
 summary["_kernel"] = meta
 summary["_command"] = "rocprofv3 --pmc <counter> --output-format csv -- python3 <program> (one pass per counter group, tools/profile_r02.sh)"
 json.dump(summary, open(os.path.join(dst, f"{tag}_pmc_summary.json"), "w"), indent=1)
@@ -53,5 +61,8 @@ if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
                       "streaming read -> doubled; WRITE_SIZE exact; KB = 1024 B",
         "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
         "raw_uncorrected_bytes_per_launch": (fk + wk) * 1024,
+        # launches differ in size (ramped chunks, the kernel-only launch): the per-problem figure is the one to scale
+        "hbm_bytes_per_problem": ((2 * summary["FETCH_SIZE"]["per_problem"] + summary["WRITE_SIZE"]["per_problem"]) * 1024
+                                  if "per_problem" in summary["FETCH_SIZE"] and "per_problem" in summary["WRITE_SIZE"] else None),
     }, open(os.path.join(dst, TRAFFIC_FILE), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if not k.startswith("_")}, indent=1)[:3000])
