@@ -409,8 +409,7 @@ static hipError_t launch_stream(const acnqp::StreamArgs& sa, hipStream_t st) {
 static int long_tiles(int t_max) { return t_max <= 32 ? 2 : (t_max <= 96 ? 6 : (t_max <= 144 ? 9 : 18)); }
 static bool long_shape(const acnqp_handle* h, int t_max, int k_sessions) {
   if (std::getenv("ACNQP_NO_LONG")) return false;   // diagnostic: the general-shape kernel instead
-  return !tiled_shape(h, t_max, k_sessions) && !stream_shape(h, t_max) && !h->has_max && t_max <= 288 &&
-         h->dev64.MR <= 32;
+  return !tiled_shape(h, t_max, k_sessions) && !stream_shape(h, t_max) && t_max <= 288 && h->dev64.MR <= 32;
 }
 
 template <int CTL, int MT>

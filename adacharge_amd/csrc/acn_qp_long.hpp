@@ -22,8 +22,8 @@
 // What bounds an iteration is the CU's vector-memory issue rate: a 64-lane 8-byte access costs ~16 cycles of the
 // texture addresser whoever issues it (tools/micro/rt_latency.hip), and an iteration makes ~2,800 of them.
 // Anderson acceleration as in the other kernels (the ring lives in the workspace; its passes run over the tile items
-// of 1b); the infeasibility certificate of acn_qp_tiled.hpp.  Not in this kernel (the general-shape kernel keeps it):
-// the demand-charge row, whose prox couples the periods of a SITE row.
+// of 1b); the infeasibility certificate of acn_qp_tiled.hpp; the demand-charge row (its prox couples the periods of a
+// SITE row: one more item, run by one wave at the start of phase 2).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -133,6 +133,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   const bool eq = A.s_eq[b] != 0;
   const real sigma = A.sigma, alpha = A.alpha;
   const real lfb = A.lf ? A.lf[b] / (A.flat_scale * A.flat_scale) : 0.0;
+  // demand charge (acn_qp_tiled.hpp): prox of dc * max(max_t z_t, floor) over the WHOLE horizon of the "max" site row
+  const real dcb = A.dc ? A.dc[b] / A.max_scale : 0.0;
+  const real dfl = A.dfloor ? A.dfloor[b] * A.max_scale : 0.0;
+  int jdc = -1;   // padded index of that row (uniform)
+  if (dcb > 0.0)
+    for (int j = 0; j < 16 * MT; ++j) jdc = A.rowtype[j] == kRowMax ? j : jdc;
+  const bool dc_on = jdc >= 0;
 
   // Addressing: every access is (array + wave-uniform offset)[lane] -- a scalar base and one 32-bit lane offset per
   // instruction instead of a 64-bit per-lane address computed for each of them.  fidx / sidx2 are the uniform parts.
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     real f[3] = {qn, um, bad};
     stream_block_max<3, NWV>(f, SC, lane, wave);
     qnorm = f[0];
-    pd = effective_pdiag<real>(pd_user, A.reg_rel, qnorm, f[1], A.horizon[b], lfb > 0.0);
+    pd = effective_pdiag<real>(pd_user, A.reg_rel, qnorm, f[1], A.horizon[b], lfb > 0.0 || dcb > 0.0);
     if (f[2] > 0) {
       for (size_t k = tid; k < (size_t)N * Tm; k += NWV * 64) A.x[(size_t)b * N * Tm + k] = 0;
       if (tid == 0) { A.status[b] = 4; A.iters[b] = 0; A.pri[b] = M::big; A.dua[b] = M::big; A.obj[b] = 0; }
@@ -316,10 +323,63 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       else if (ty[r] == kRowPeak) zn = fmin(zn, pk);
       else if (ty[r] == kRowQuad) zn = zn * quad;
       else if (ty[r] == kRowSocRe || ty[r] == kRowSocIm) zn = zn * scl[r >> 1];
+      // kRowMax: zn = zhr here; the horizon-wide prox (dc_row below) follows once every column tile is through
       at(Y2, i) = rho * (zhr[r] - zn);
       at(Z2, i) = zn;
-      sv0 = fmax(sv0, fabs(gxn[r] - zn));
-      sv2 = fmax(sv2, fmax(fabs(gxn[r]), fabs(zn)));
+      if (!(dc_on && ty[r] == kRowMax)) {
+        sv0 = fmax(sv0, fabs(gxn[r] - zn));
+        sv2 = fmax(sv2, fmax(fabs(gxn[r]), fabs(zn)));
+      }
+    }
+  };
+  // ---- demand charge: z_t = min(zh_t, max(tau, floor)), tau = root of sum_t (zh_t - tau)+ = dc / rho (Newton on a convex
+  // piecewise-linear function), over the whole horizon of the "max" row: one wave, after every site tile has stored
+  // its pre-projection point of the row in Z2.  The row's periods are the 16 lanes of ONE lane group (g = jdc & 3) x the
+  // column tiles; the other three lane groups run along on their own rows and store nothing.
+  auto dc_row = [&]() __attribute__((always_inline)) {
+    const int mo = jdc >> 4, rr = jdc & 15, gd = rr & 3, rd = rr >> 2;   // rowof(g, r) = g + 4 r
+    real zv[CTL], gxv[CTL];
+#pragma unroll
+    for (int c = 0; c < CTL; ++c) {
+      zv[c] = 0; gxv[c] = 0;
+      if (c < nct) { zv[c] = at(Z2, sidx2(mo, c, rd)); gxv[c] = at(GX, sidx2(mo, c, rd)); }
+    }
+    const real cw = dcb / rho;
+    real vmax_l = -M::big;
+#pragma unroll
+    for (int c = 0; c < CTL; ++c) vmax_l = (16 * c + t < Tm) ? fmax(vmax_l, zv[c]) : vmax_l;
+    const real vmax = row_max<real>(vmax_l);
+    real tau = vmax - cw;
+    bool need = g == gd;
+    int guard = 0;
+    while (__any(need)) {
+      ++guard;
+      real sl = 0, nl = 0;
+#pragma unroll
+      for (int c = 0; c < CTL; ++c) {
+        const real dd = zv[c] - tau;
+        const bool on = (16 * c + t < Tm) && dd > 0.0;
+        sl += on ? dd : 0.0;
+        nl += on ? 1.0 : 0.0;
+      }
+      const real S = row_sum<real>(sl), nn = row_sum<real>(nl);
+      const real f = S - cw;
+      const real tn = nn > 0.0 ? tau + f / nn : vmax - cw;
+      const bool fin = fabs(f) <= M::proj_tol * fmax(1.0, cw) * 16.0 || tn == tau || guard > 200;
+      tau = (need && !fin) ? tn : tau;
+      need = need && !fin;
+    }
+    const real lev = fmax(tau, dfl);
+    if (g == gd) {
+#pragma unroll
+      for (int c = 0; c < CTL; ++c)
+        if (c < nct) {
+          const real zn = (16 * c + t < Tm) ? fmin(zv[c], lev) : zv[c];
+          at(Y2, sidx2(mo, c, rd)) = rho * (zv[c] - zn);
+          at(Z2, sidx2(mo, c, rd)) = zn;
+          sv0 = fmax(sv0, fabs(gxv[c] - zn));
+          sv2 = fmax(sv2, fmax(fabs(gxv[c]), fabs(zn)));
+        }
     }
   };
   // P tile = sum over EVSE tiles of Ghat[mo, e] v[e, c], v = the RZ array (r0, or z1 during the start), in tile order,
@@ -735,7 +795,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     STAMP(3);   // Anderson event (amortised)
     __syncthreads();
     STAMP(4);   // barrier
-    // ================= phase 2: row items =========================================================================
+    // ================= phase 2: row items (and the demand-charge row, by the last wave) ============================
+    if (dc_on && wave == NWV - 1) { RELANE(); dc_row(); }
 #pragma unroll 1
     for (int ri = wave; ri < 4 * NE; ri += NWV) {
       RELANE();

@@ -545,6 +545,36 @@ def test_demand_charge_matches_oracle(ct, T):
     assert abs(opt.last_result.obj[0] - prob.objective(ref)) <= 1e-6 * abs(prob.objective(ref))
 
 
+@pytest.mark.parametrize("ct,T", [("SOC", 96), ("LINEAR", 144)])
+def test_long_horizon_demand_charge_matches_c_twin(ct, T):
+    """The demand-charge row (prox over the whole horizon of one site row) in the long-horizon kernel: against the C
+    twin on a batch, and the billed peak against the general-shape kernel's answer."""
+    from adacharge_amd import demand_charge, total_energy
+    from adacharge_amd.acn import Interface
+    from oracle import admm_port
+
+    infra = sites.caltech54()
+    iface = Interface({"infrastructure_info": infra, "period": 5, "demand_charge": 15.0, "prev_peak": 50.0})
+    obj = [ObjectiveComponent(total_energy, 20.0), ObjectiveComponent(demand_charge), ObjectiveComponent(equal_share, 1e-3)]
+    snaps = sites.snapshot_batch(infra, T, 6, seed=7 + T, demand_range=(5.0, 40.0))
+    batch = build_batch(snaps, infra, iface, obj, ct)
+    assert batch.site.has_max
+    h = SiteHandle(batch.site, 0)
+    res = h.solve(batch, default_options())
+    ref = admm_port.solve_batch(batch, threads=6, accel_mem=h.accel_columns(batch.Tm, batch.K, default_options()))
+    assert (res.status == 1).all() and (ref["status"] == 1).all()
+    assert np.abs(res.x - ref["x"]).max() <= RATE_TOL
+    v = infra.voltages / 1e3
+    peak_kw = np.einsum("n,bnt->bt", v, res.x).max(axis=1)
+    peak_ref = np.einsum("n,bnt->bt", v, ref["x"]).max(axis=1)
+    assert np.abs(peak_kw - peak_ref).max() <= 1e-4
+    # the twin reports the smooth part of the objective; the binding adds the demand-charge term on the host
+    vrow = batch.site.G[batch.site.max_row]
+    full = ref["obj"] + batch.dc * np.maximum(np.einsum("n,bnt->bt", vrow, ref["x"]).max(axis=1), batch.dfloor)
+    assert np.abs(res.obj - full).max() <= 1e-6 * np.abs(full).max()
+    h.close()
+
+
 def test_peak_objective_sign_is_checked():
     from adacharge_amd import peak
     from adacharge_amd.acn import Interface
