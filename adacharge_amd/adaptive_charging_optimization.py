@@ -193,7 +193,10 @@ class AdaptiveChargingOptimization:
             ("ECOS", "OSQP", None, cvxpy constants ...); every value runs the
             HIP ADMM backend.  Backend options go in ``solver_options``.
         solver_options (dict): overrides of ``acnqp_options`` fields
-            (eps_abs, eps_rel, max_iter, rho, reg_rel, precision, ...).
+            (eps_abs, eps_rel, max_iter, rho, reg_rel, precision, ...), plus
+            ``retry_stalled`` (default True): problems the adaptive first
+            pass leaves on a residual plateau are solved once more from a
+            cold start with a fixed penalty (``backend.SiteHandle.solve``).
         device (int): HIP device ordinal.
     """
 
@@ -370,7 +373,8 @@ class AdaptiveChargingOptimization:
                     T = min(batch.Tm, x0.shape[1], y0.shape[1])
                     wx[b, :, :T], wy[b, :, :T] = x0[:, :T], y0[:, :T]
             warm = (wx, wy)
-        res = handle.solve(batch, backend.default_options(**opts), warm=warm, want_y=True)
+        retry = bool(opts.pop("retry_stalled", True))   # not an acnqp_options field: second pass for stalled problems
+        res = handle.solve(batch, backend.default_options(**opts), warm=warm, want_y=True, retry_stalled=retry)
         self.last_result = res
         self.last_batch = batch   # the structured problems behind last_result (diagnostics, tests)
         return res, batch

@@ -344,17 +344,54 @@ class SiteHandle:
         return res
 
     def solve(self, batch: ProblemBatch, options: Optional[Options] = None, pinned_results: bool = False,
-              warm=None, want_y: bool = False) -> BatchResult:
+              warm=None, want_y: bool = False, retry_stalled: bool = False) -> BatchResult:
         """acnqp_solve_batch: one batch, host buffers in and out, synchronous (pipelined in chunks inside).
         ``warm = (x0, y0)``: optional warm start (an earlier schedule (B, N, Tm) and its ``BatchResult.y`` (B, Mg, Tm),
-        shifted by the caller); ``want_y``: also return the site-row multipliers ``y`` for a later warm start."""
+        shifted by the caller); ``want_y``: also return the site-row multipliers ``y`` for a later warm start.
+        ``retry_stalled``: problems the first pass leaves SOLVED_INACCURATE / MAX_ITER are solved once more from a cold
+        start with a FIXED penalty (see ``_retry_stalled``)."""
         self._check_site(batch)
         o = options if options is not None else default_options()
         p, r, res, keep = self._marshal(batch, pinned_results, warm=warm, want_y=want_y)
         _check(self._lib.acnqp_solve_batch(self._h, C.byref(p), C.byref(o), C.byref(r)), "acnqp_solve_batch")
         del keep
         res.kernel_ms = float(self._lib.acnqp_last_kernel_ms(self._h))
+        if retry_stalled and o.adapt_every > 0:
+            self._retry_stalled(batch, o, res, want_y)
         return self._finish(batch, res)
+
+    # Second pass for stalled problems.  Traced on the C twin (DESIGN.md section 2): the congested instances that sit on
+    # a plateau of the primal residual do so because the penalty adaptation keeps kicking them (rho swings by 10x in the
+    # first hundreds of iterations and the iterate ends in a region it leaves only sub-linearly); from a cold start
+    # with ANY fixed rho in [0.3, 4] every one of them converges in 900 ... 4,400 iterations -- while a fixed rho from
+    # the start would double the iterations of the average problem.  So: adaptive first, fixed-rho retry for the few
+    # that stall.  A retry that does not reach SOLVED leaves the first answer in place.
+    RETRY_RHO = 0.5
+    RETRY_MAX_ITER = 8000
+    RETRY_MIN_ITERS = 3000   # = kStallIters of the kernels
+
+    def _retry_stalled(self, batch: ProblemBatch, o: Options, res: "BatchResult", want_y: bool) -> None:
+        # a problem that stopped before the stall window could have elapsed hit the caller's max_iter: not retried
+        bad = np.flatnonzero(((res.status == STATUS_SOLVED_INACCURATE) | (res.status == STATUS_MAX_ITER))
+                             & (res.iters >= self.RETRY_MIN_ITERS))
+        if bad.size == 0:
+            return
+        o2 = Options.from_buffer_copy(o)
+        o2.rho = self.RETRY_RHO
+        o2.adapt_every = 0
+        o2.max_iter = min(int(o.max_iter), self.RETRY_MAX_ITER)
+        sub = batch.subset(bad)
+        p, r, res2, keep = self._marshal(sub, False, want_y=want_y)
+        _check(self._lib.acnqp_solve_batch(self._h, C.byref(p), C.byref(o2), C.byref(r)), "acnqp_solve_batch (retry)")
+        del keep
+        res.kernel_ms += float(self._lib.acnqp_last_kernel_ms(self._h))
+        res.iters[bad] += res2.iters
+        won = res2.status == STATUS_SOLVED
+        idx = bad[won]
+        for name in ("x", "status", "pri_res", "dua_res", "obj"):
+            getattr(res, name)[idx] = getattr(res2, name)[won]
+        if want_y and res.y is not None:
+            res.y[idx] = res2.y[won]
 
     def solve_many(self, batches, options: Optional[Options] = None, pinned_results: bool = True):
         """acnqp_solve_batches: several independent batches in ONE pipelined pass (shared launches, overlapped

@@ -372,13 +372,16 @@ def test_config4_stochastic_mpc_1024_scenarios_times_8_sites():
         f = rng.lognormal(0.0, 0.25, size=(S, base.K, base.N))   # demand scaled per session per scenario
         batch = scenario_batch(base, f)
         h = SiteHandle(batch.site, 0)
-        res = h.solve(batch, default_options())
-        # On the most congested synthetic site ~3 % of the scenarios sit on a plateau of the primal residual (SOC discs
-        # touching the energy rows tangentially: ADMM turns sub-linear): the stall rule ends them
-        # as SOLVED_INACCURATE (residuals below cvxpy's OSQP default 1e-5, above the 1e-8 asked for) -- reported as such,
-        # never as SOLVED; no scenario fails, and every returned schedule is feasible (network rows to 5e-3 A).
-        assert np.isin(res.status, (1, 5)).all() and (res.status == 1).mean() >= 0.96, (k, np.unique(res.status, return_counts=True))
-        assert res.iters.max() <= 12000
+        first = h.solve(batch, default_options())
+        # On the most congested synthetic site ~3 % of the scenarios sit on a plateau of the primal residual after the
+        # adaptive first pass: the stall rule ends them as SOLVED_INACCURATE (residuals below
+        # cvxpy's OSQP default 1e-5, above the 1e-8 asked for) -- reported as such, never as SOLVED, none fails ...
+        assert np.isin(first.status, (1, 5)).all() and (first.status == 1).mean() >= 0.96, (k, np.unique(first.status, return_counts=True))
+        assert first.iters.max() <= 12000
+        # ... and the binding's second pass (cold start, fixed penalty) solves them to the 1e-8 asked for (all but at
+        # most one in a thousand, which keeps its first answer)
+        res = h.solve(batch, default_options(), retry_stalled=True)
+        assert np.isin(res.status, (1, 5)).all() and (res.status == 1).mean() >= 0.998, (k, np.unique(res.status, return_counts=True))
         assert (res.x <= batch.ub + 1e-9).all() and (res.x >= batch.lb - 1e-9).all()
         e = np.zeros((S, base.N))
         for i in range(base.N):
@@ -393,12 +396,12 @@ def test_config4_stochastic_mpc_1024_scenarios_times_8_sites():
         # determinism and batch-composition independence: the first 64 scenarios alone give the same bits
         sb = batch.subset(slice(0, 64))
         again = h.solve(sb, default_options())
-        assert np.array_equal(again.x, res.x[:64]) and np.array_equal(again.iters, res.iters[:64])
+        assert np.array_equal(again.x, first.x[:64]) and np.array_equal(again.iters, first.iters[:64])
         m_eff = h.accel_columns(batch.Tm, batch.K, default_options())
         ref = admm_port.solve_batch(sb, threads=8, accel_mem=m_eff)
         both = (ref["status"] == 1) & (again.status == 1)
         assert both.sum() >= 60
-        assert np.abs(ref["x"][both] - res.x[:64][both]).max() <= 5e-4
+        assert np.abs(ref["x"][both] - first.x[:64][both]).max() <= 5e-4
         total += S
         h.close()
     assert total == 8192
