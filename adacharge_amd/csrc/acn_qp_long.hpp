@@ -39,6 +39,9 @@ namespace acnqp {
 // of the instruction.  With ~20 arrays, plain pointers cost a 64-bit per-lane address per array (the compiler forms
 // base + lane once and keeps -- or spills -- all of them); this costs nothing per access.
 typedef unsigned ws_v2u __attribute__((ext_vector_type(2)));
+typedef unsigned ws_v4u __attribute__((ext_vector_type(4)));
+typedef double ws_d2 __attribute__((ext_vector_type(2)));
+typedef float ws_f2 __attribute__((ext_vector_type(2)));
 struct WsArr64 { unsigned off; };   // byte offset of an array of doubles inside the problem's workspace
 struct WsArr32 { unsigned off; };   // ... of floats
 __device__ inline WsArr32 operator+(WsArr32 a, size_t n) { return WsArr32{a.off + (unsigned)n * 4u}; }
@@ -141,21 +144,69 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     for (int j = 0; j < 16 * MT; ++j) jdc = A.rowtype[j] == kRowMax ? j : jdc;
   const bool dc_on = jdc >= 0;
 
-  // Addressing: every access is (array + wave-uniform offset)[lane] -- a scalar base and one 32-bit lane offset per
-  // instruction instead of a 64-bit per-lane address computed for each of them.  fidx / sidx2 are the uniform parts.
-  auto fidx = [&](int e, int c, int r) -> unsigned { return (unsigned)(((e * CTL + c) * 4 + r) * 64); };
-  auto sidx2 = [&](int m, int c, int r) -> unsigned { return (unsigned)(((m * CTL + c) * 4 + r) * 64); };
-  // (the lane's byte offset is formed in 32 bits and zero-extended: the shape the scalar-base addressing mode takes)
+  // Layout of every state array (workspace or LDS): 16 x 16 tiles in MFMA fragment order, the four accumulator
+  // registers of a lane stored as two adjacent PAIRS -- element (tile, r, lane) at (tile * 2 + r / 2) * 128 + lane * 2 +
+  // r % 2 -- so that one 16-byte access per lane moves two registers: the CU's address unit prices a 64-lane access
+  // at ~16 cycles whatever its width (tools/micro/rt_latency.hip), and an iteration is bound by that count.
+  // Addressing: (array + wave-uniform offset)[lane] -- a scalar base / buffer descriptor and one 32-bit lane offset per
+  // instruction instead of a 64-bit per-lane address computed for each of them.  fidx / sidx2 are the uniform parts
+  // (they include r % 2); roff(r) is the offset of register r inside its tile.
+  auto roff = [&](int r) -> unsigned { return (unsigned)((r >> 1) * 128 + (r & 1)); };
+  auto fidx = [&](int e, int c, int r) -> unsigned { return (unsigned)((e * CTL + c) * 256) + roff(r); };
+  auto sidx2 = [&](int m, int c, int r) -> unsigned { return (unsigned)((m * CTL + c) * 256) + roff(r); };
+  // one element (8 / 4 bytes) of a state array; the lane's byte offset is formed in 32 bits and zero-extended: the
+  // shape the scalar-base addressing mode takes
   auto at = [&](auto base, unsigned uo) -> decltype(auto) {
     typedef decltype(base) B;
-    if constexpr (std::is_same<B, WsArr64>::value) return WsRef64{wsr, (unsigned)lane * 8u, base.off + uo * 8u};
-    else if constexpr (std::is_same<B, WsArr32>::value) return WsRef32{wsr, (unsigned)lane * 4u, base.off + uo * 4u};
-    else {   // a plain pointer (site fragments, LDS): uniform base, the lane's byte offset zero-extended from 32 bits
+    if constexpr (std::is_same<B, WsArr64>::value) return WsRef64{wsr, (unsigned)lane * 16u, base.off + uo * 8u};
+    else if constexpr (std::is_same<B, WsArr32>::value) return WsRef32{wsr, (unsigned)lane * 8u, base.off + uo * 4u};
+    else {   // LDS-resident state
       typedef typename std::remove_pointer<B>::type elem_t;
       typedef typename std::conditional<std::is_const<elem_t>::value, const char, char>::type byte_t;
-      const unsigned lo = (unsigned)lane * (unsigned)sizeof(elem_t);
+      const unsigned lo = (unsigned)lane * 2u * (unsigned)sizeof(elem_t);
       return (*reinterpret_cast<B>(reinterpret_cast<byte_t*>(base + uo) + lo));
     }
+  };
+  // two adjacent registers (2 rp, 2 rp + 1; uo = fidx / sidx2 of the even one) in one 16-byte access (float arrays:
+  // 8-byte, widened to / rounded from double exactly as the single-element accessor does)
+  auto ld2 = [&](auto base, unsigned uo, real& a, real& b) __attribute__((always_inline)) {
+    typedef decltype(base) B;
+    if constexpr (std::is_same<B, WsArr64>::value) {
+      const ws_d2 d = __builtin_bit_cast(ws_d2, __builtin_amdgcn_raw_buffer_load_b128(wsr, (unsigned)lane * 16u, base.off + uo * 8u, 0));
+      a = d.x; b = d.y;
+    } else if constexpr (std::is_same<B, WsArr32>::value) {
+      const ws_f2 d = __builtin_bit_cast(ws_f2, __builtin_amdgcn_raw_buffer_load_b64(wsr, (unsigned)lane * 8u, base.off + uo * 4u, 0));
+      a = d.x; b = d.y;
+    } else {   // LDS-resident state (doubles)
+      const ws_d2 d = *reinterpret_cast<const ws_d2*>(reinterpret_cast<const char*>(base + uo) + (unsigned)lane * 16u);
+      a = d.x; b = d.y;
+    }
+  };
+  auto st2 = [&](auto base, unsigned uo, real a, real b) __attribute__((always_inline)) {
+    typedef decltype(base) B;
+    if constexpr (std::is_same<B, WsArr64>::value) {
+      const ws_d2 d = {a, b};
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_v4u, d), wsr, (unsigned)lane * 16u, base.off + uo * 8u, 0);
+    } else if constexpr (std::is_same<B, WsArr32>::value) {
+      const ws_f2 d = {(float)a, (float)b};
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ws_v2u, d), wsr, (unsigned)lane * 8u, base.off + uo * 4u, 0);
+    } else {
+      const ws_d2 d = {a, b};
+      *reinterpret_cast<ws_d2*>(reinterpret_cast<char*>(base + uo) + (unsigned)lane * 16u) = d;
+    }
+  };
+  // the four registers of a tile (uo = fidx / sidx2 of register 0)
+  auto ld4 = [&](auto base, unsigned uo, real (&v)[4]) __attribute__((always_inline)) {
+    ld2(base, uo, v[0], v[1]);
+    ld2(base, uo + 128u, v[2], v[3]);
+  };
+  auto st4 = [&](auto base, unsigned uo, const real (&v)[4]) __attribute__((always_inline)) {
+    st2(base, uo, v[0], v[1]);
+    st2(base, uo + 128u, v[2], v[3]);
+  };
+  // one fragment value of the site matrices (plain [k-slice][lane] order, shared with the other kernels)
+  auto atf = [&](const real* base, unsigned uo) -> real {
+    return *reinterpret_cast<const real*>(reinterpret_cast<const char*>(base + uo) + (unsigned)lane * 8u);
   };
 
   // ---- init (row items): inputs -> fragment order; |q|_inf, max ub; a session whose bounds cannot meet its energy
@@ -315,22 +366,24 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         const real n2 = re * re + im * im;
         if (n2 > lim[2 * pr] * lim[2 * pr]) scl[pr] = lim[2 * pr] * rsqrt_nr(n2);
       }
+    real z2n[4], y2n[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const unsigned i = sidx2(mo, c, r);
       real zn = zhr[r];
       if (ty[r] == kRowBox) zn = fmin(zn, lim[r]);
       else if (ty[r] == kRowPeak) zn = fmin(zn, pk);
       else if (ty[r] == kRowQuad) zn = zn * quad;
       else if (ty[r] == kRowSocRe || ty[r] == kRowSocIm) zn = zn * scl[r >> 1];
       // kRowMax: zn = zhr here; the horizon-wide prox (dc_row below) follows once every column tile is through
-      at(Y2, i) = rho * (zhr[r] - zn);
-      at(Z2, i) = zn;
+      y2n[r] = rho * (zhr[r] - zn);
+      z2n[r] = zn;
       if (!(dc_on && ty[r] == kRowMax)) {
         sv0 = fmax(sv0, fabs(gxn[r] - zn));
         sv2 = fmax(sv2, fmax(fabs(gxn[r]), fabs(zn)));
       }
     }
+    st4(Y2, sidx2(mo, c, 0), y2n);
+    st4(Z2, sidx2(mo, c, 0), z2n);
   };
   // ---- demand charge: z_t = min(zh_t, max(tau, floor)), tau = root of sum_t (zh_t - tau)+ = dc / rho (Newton on a convex
   // piecewise-linear function), over the whole horizon of the "max" row: one wave, after every site tile has stored
@@ -393,8 +446,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       real b0[4], a0[4], b1[4], a1[4];
       const real* f0 = fgb + (size_t)(e * MT + mo) * 2 * 4 * 64;
       const real* f1 = fgb + (size_t)(e1 * MT + mo) * 2 * 4 * 64;
+      ld4(RZ, fidx(e, c, 0), b0);
+      ld4(RZ, fidx(e1, c, 0), b1);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) { b0[s] = at(RZ, fidx(e, c, s)); a0[s] = at(f0, s * 64); b1[s] = at(RZ, fidx(e1, c, s)); a1[s] = at(f1, s * 64); }
+      for (int s = 0; s < 4; ++s) { a0[s] = atf(f0, s * 64); a1[s] = atf(f1, s * 64); }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) p = M::mma(a0[s], b0[s], p);
@@ -465,7 +520,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        zt = M::mma(at(FQ, (((mo * MT + mi) * 2 + 1) * 4 + s) * 64), at(HH, sidx2(mi, c, s)), zt);
+        zt = M::mma(atf(FQ, (((mo * MT + mi) * 2 + 1) * 4 + s) * 64), at(HH, sidx2(mi, c, s)), zt);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const unsigned i = sidx2(mo, c, r);
@@ -539,27 +594,32 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
       real bz[MT][4], fq0[MT][4];
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
+      for (int mi = 0; mi < MT; ++mi) {
+        real z2t[4], y2t[4];
+        ld4(Z2, sidx2(mi, c, 0), z2t);
+        ld4(Y2, sidx2(mi, c, 0), y2t);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const unsigned i = sidx2(mi, c, s);
-          bz[mi][s] = rho * at(Z2, i) - at(Y2, i);
-          fq0[mi][s] = at(FQi, (((mo * MT + mi) * 2 + 0) * 4 + s) * 64);
+          bz[mi][s] = rho * z2t[s] - y2t[s];
+          fq0[mi][s] = atf(FQi, (((mo * MT + mi) * 2 + 0) * 4 + s) * 64);
         }
+      }
       const vec4 p = site_p(mo, c, FGi);
       vec4 wh = {0, 0, 0, 0};
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int s = 0; s < 4; ++s) wh = M::mma(fq0[mi][s], bz[mi][s], wh);
+      real eo[4], ho[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = 16 * mo + M::rowof(g, r);
         const real lj = RowLam[j];
-        const real e_ = wh[r] - RowDj[j] * (p[r] + lj * wh[r]);
-        at(EH, sidx2(mo, c, r)) = e_;
-        at(HH, sidx2(mo, c, r)) = (p[r] + lj * e_) * inv_a;
+        eo[r] = wh[r] - RowDj[j] * (p[r] + lj * wh[r]);
+        ho[r] = (p[r] + lj * eo[r]) * inv_a;
       }
+      st4(EH, sidx2(mo, c, 0), eo);
+      st4(HH, sidx2(mo, c, 0), ho);
     }
     STAMP(0);   // 1a
     __syncthreads();
@@ -572,14 +632,12 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
         real fq1[MT][4], hv[MT][4], gxv[4], z2v[4], y2v[4];
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi)
+        for (int mi = 0; mi < MT; ++mi) {
+          ld4(HH, sidx2(mi, c, 0), hv[mi]);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            fq1[mi][s] = at(FQi, (((mo * MT + mi) * 2 + 1) * 4 + s) * 64);
-            hv[mi][s] = at(HH, sidx2(mi, c, s));
-          }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const unsigned i = sidx2(mo, c, r); gxv[r] = at(GX, i); z2v[r] = at(Z2, i); y2v[r] = at(Y2, i); }
+          for (int s = 0; s < 4; ++s) fq1[mi][s] = atf(FQi, (((mo * MT + mi) * 2 + 1) * 4 + s) * 64);
+        }
+        ld4(GX, sidx2(mo, c, 0), gxv); ld4(Z2, sidx2(mo, c, 0), z2v); ld4(Y2, sidx2(mo, c, 0), y2v);
         __builtin_amdgcn_sched_barrier(0);
         vec4 zt = {0, 0, 0, 0};
 #pragma unroll
@@ -591,11 +649,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         for (int r = 0; r < 4; ++r) {
           gxn[r] = alpha * zt[r] + (1.0 - alpha) * gxv[r];
           zhr[r] = alpha * zt[r] + (1.0 - alpha) * z2v[r] + y2v[r] * inv_rho;
-          at(GX, sidx2(mo, c, r)) = gxn[r];
         }
+        st4(GX, sidx2(mo, c, 0), gxn);
         if (ev_it) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) at(ZHR, sidx2(mo, c, r)) = zhr[r];
+          st4(ZHR, sidx2(mo, c, 0), zhr);
         } else {
           site_project(mo, c, zhr, gxn, quad);
         }
@@ -604,28 +661,28 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
         const real* fg = FGi + (size_t)e * MT * 2 * 4 * 64;
         real rv[4], xv[4], zv[4], yv[4], fx[MT][4], ev4[MT][4];
+        ld4(RZ, fidx(e, c, 0), rv); ld4(Xs, fidx(e, c, 0), xv); ld4(Z1s, fidx(e, c, 0), zv); ld4(Y1s, fidx(e, c, 0), yv);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const unsigned i = fidx(e, c, r);
-          rv[r] = at(RZ, i); xv[r] = at(Xs, i); zv[r] = at(Z1s, i); yv[r] = at(Y1s, i);
+        for (int m = 0; m < MT; ++m) {
+          ld4(EH, sidx2(m, c, 0), ev4[m]);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) fx[m][s] = atf(fg, ((m * 2 + 1) * 4 + s) * 64);
         }
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) { fx[m][s] = at(fg, ((m * 2 + 1) * 4 + s) * 64); ev4[m][s] = at(EH, sidx2(m, c, s)); }
         __builtin_amdgcn_sched_barrier(0);
         vec4 acc = {rv[0], rv[1], rv[2], rv[3]};
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int s = 0; s < 4; ++s) acc = M::mma(fx[m][s], ev4[m][s], acc);
+        real zo4[4], xo4[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const unsigned i = fidx(e, c, r);
           const real xn = acc[r] * inv_a;
-          at(RZ, i) = alpha * xn + (1.0 - alpha) * zv[r] + yv[r] * inv_rho;
-          at(Xs, i) = alpha * xn + (1.0 - alpha) * xv[r];
+          zo4[r] = alpha * xn + (1.0 - alpha) * zv[r] + yv[r] * inv_rho;
+          xo4[r] = alpha * xn + (1.0 - alpha) * xv[r];
         }
+        st4(RZ, fidx(e, c, 0), zo4);
+        st4(Xs, fidx(e, c, 0), xo4);
       }
     }
     STAMP(2);   // 1b
@@ -639,28 +696,26 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       for (int j = 0; j < AMX + 2; ++j) d[j] = 0;
       // four registers of one tile: g = zsrc[zo + 64 r], state index uo + 64 r
       auto aa_tile = [&](auto zsrc, unsigned zo, unsigned uo) __attribute__((always_inline)) {
-        real gv[4], uv[4], fpv[4], gpv[4];
-        float hv[AMX][4];
+        real gv[4], uv[4], fpv[4], gpv[4], hv[AMX][4], cqv[4], cgv[4], fv[4];
+        ld4(zsrc, zo, gv); ld4(UP, uo, uv); ld4(FP, uo, fpv); ld4(GP, uo, gpv);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { gv[r] = at(zsrc, zo + 64 * r); uv[r] = at(UP, uo + 64 * r); fpv[r] = at(FP, uo + 64 * r); gpv[r] = at(GP, uo + 64 * r); }
+        for (int j = 0; j < AMX; ++j) {
 #pragma unroll
-        for (int j = 0; j < AMX; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            hv[j][r] = 0.f;
-            if (((aa_valid >> j) & 1u) && j != slot) hv[j][r] = at(HF + (size_t)j * DU, uo + 64 * r);   // uniform
-          }
+          for (int r = 0; r < 4; ++r) hv[j][r] = 0;
+          if (((aa_valid >> j) & 1u) && j != slot) ld4(HF + (size_t)j * DU, uo, hv[j]);   // uniform
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const real f = gv[r] - uv[r];
           d[AMX + 1] += f * f;
           const float cq = (float)(f - fpv[r]);
-          if (col) { at(HF + (size_t)slot * DU, uo + 64 * r) = cq; at(HG + (size_t)slot * DU, uo + 64 * r) = (float)(gv[r] - gpv[r]); }
+          cqv[r] = cq; cgv[r] = (float)(gv[r] - gpv[r]); fv[r] = f;
 #pragma unroll
-          for (int j = 0; j < AMX; ++j) d[j] += (real)cq * (real)(j == slot ? cq : hv[j][r]);
+          for (int j = 0; j < AMX; ++j) d[j] += (real)cq * (j == slot ? (real)cq : hv[j][r]);
           d[AMX] += (real)cq * f;
-          at(FP, uo + 64 * r) = f; at(GP, uo + 64 * r) = gv[r];
         }
+        if (col) { st4(HF + (size_t)slot * DU, uo, cqv); st4(HG + (size_t)slot * DU, uo, cgv); }
+        st4(FP, uo, fv); st4(GP, uo, gv);
       };
 #pragma unroll 1
       for (int q = wave; q < n_tile; q += NWV) {
@@ -750,25 +805,21 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       }
       // ---- apply: u = g - sum_j gamma_j dG_j; the site rows are projected from their (extrapolated) point -------
       auto aa_apply = [&](auto zdst, unsigned zo, unsigned uo, real (&out)[4]) __attribute__((always_inline)) {
-        real gv[4];
-        float hv[AMX][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gv[r] = at(zdst, zo + 64 * r);
+        real hv[AMX][4];
+        ld4(zdst, zo, out);
         if (ext) {
 #pragma unroll
+          for (int j = 0; j < AMX; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[j][r] = 0;
+            if ((aa_valid >> j) & 1u) ld4(HG + (size_t)j * DU, uo, hv[j]);   // uniform
+          }
+#pragma unroll
           for (int j = 0; j < AMX; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              hv[j][r] = 0.f;
-              if ((aa_valid >> j) & 1u) hv[j][r] = at(HG + (size_t)j * DU, uo + 64 * r);   // uniform
-            }
-#pragma unroll
-          for (int j = 0; j < AMX; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) gv[r] -= gam[j] * (real)hv[j][r];
+            for (int r = 0; r < 4; ++r) out[r] -= gam[j] * hv[j][r];
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { at(UP, uo + 64 * r) = gv[r]; out[r] = gv[r]; }
+        st4(UP, uo, out);
       };
 #pragma unroll 1
       for (int q = wave; q < n_tile; q += NWV) {
@@ -777,18 +828,14 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
           const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
           real zhr[4], gxn[4];
           aa_apply(ZHR, sidx2(mo, c, 0), (unsigned)NT + sidx2(mo, c, 0), zhr);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) gxn[r] = at(GX, sidx2(mo, c, r));
+          ld4(GX, sidx2(mo, c, 0), gxn);
           site_project(mo, c, zhr, gxn, quad);
         } else {
           const int qe = q - n_site;
           const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
           real o4[4];
           aa_apply(RZ, fidx(e, c, 0), fidx(e, c, 0), o4);
-          if (ext) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) at(RZ, fidx(e, c, r)) = o4[r];
-          }
+          if (ext) st4(RZ, fidx(e, c, 0), o4);
         }
       }
     }
@@ -797,6 +844,37 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     STAMP(4);   // barrier
     // ================= phase 2: row items (and the demand-charge row, by the last wave) ============================
     if (dc_on && wave == NWV - 1) { RELANE(); dc_row(); }
+    if constexpr (CTL <= 9) {
+      // an item = the two rows of a register pair (8 EVSEs x the whole horizon): every access moves 16 bytes per lane
+#pragma unroll 1
+      for (int pi = wave; pi < 2 * NE; pi += NWV) {
+        RELANE();
+        const int e = pi >> 1, r0_ = (pi & 1) * 2;
+        real zh2[2][CTL], lb2[2][CTL], ub2[2][CTL], z1p[2][CTL];
+#pragma unroll
+        for (int c = 0; c < CTL; ++c) {   // padding columns hold zeros and stay zero
+          const unsigned i = fidx(e, c, r0_);
+          ld2(RZ, i, zh2[0][c], zh2[1][c]); ld2(LBs, i, lb2[0][c], lb2[1][c]); ld2(UBs, i, ub2[0][c], ub2[1][c]);
+        }
+        project_row(e, r0_, zh2[0], lb2[0], ub2[0], z1p[0], false);
+        project_row(e, r0_ + 1, zh2[1], lb2[1], ub2[1], z1p[1], false);
+        STAMP(5);   // row loads, water-filling
+        // x and q of the rows as one batch (into the registers of the bounds), then y1, the new r0 and the stores
+#pragma unroll
+        for (int c = 0; c < CTL; ++c) { const unsigned i = fidx(e, c, r0_); ld2(Xs, i, lb2[0][c], lb2[1][c]); ld2(Qs, i, ub2[0][c], ub2[1][c]); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CTL; ++c) {
+          const unsigned i = fidx(e, c, r0_);
+          const real ya = rho * (zh2[0][c] - z1p[0][c]), yb = rho * (zh2[1][c] - z1p[1][c]);
+          st2(Z1s, i, z1p[0][c], z1p[1][c]);
+          st2(Y1s, i, ya, yb);
+          st2(RZ, i, sigma * lb2[0][c] - ub2[0][c] + rho * z1p[0][c] - ya, sigma * lb2[1][c] - ub2[1][c] + rho * z1p[1][c] - yb);   // the new r0
+        }
+        STAMP(6);   // y1, new r0
+      }
+    } else {
+      // rows of more than 144 periods: one row per item (two would not fit the registers), 8-byte accesses
 #pragma unroll 1
     for (int ri = wave; ri < 4 * NE; ri += NWV) {
       RELANE();
@@ -821,6 +899,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         at(RZ, i) = sigma * lbv[c] - ubv[c] + rho * z1[c] - y1n;   // the new r0
       }
       STAMP(6);   // y1, new r0
+    }
     }
     STAMP(6);
     __syncthreads();
