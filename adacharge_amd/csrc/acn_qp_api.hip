@@ -100,11 +100,12 @@ struct SiteDev {
   double peak_scale = 1, flat_scale = 1, max_scale = 1;   // row-equilibration factors of the prox rows
   void *G = nullptr, *Ghat = nullptr, *Q = nullptr, *lam = nullptr, *rowlim = nullptr;
   void *fragG = nullptr, *fragQ = nullptr;   // Ghat / Q in MFMA A-operand fragment order (tiled kernel)
+  void *fragG2 = nullptr, *fragQ2 = nullptr; // the same with the four k-slices of a fragment as two adjacent pairs per lane (long-horizon kernel)
   int32_t* rowtype = nullptr;
   int32_t* rowabi = nullptr;     // internal row -> row of acnqp_site.G (-1: padding)
   void* rowscale = nullptr;      // equilibration factor of each internal row
   void release() {
-    for (void** p : {&G, &Ghat, &Q, &lam, &rowlim, &fragG, &fragQ, &rowscale}) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    for (void** p : {&G, &Ghat, &Q, &lam, &rowlim, &fragG, &fragQ, &fragG2, &fragQ2, &rowscale}) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (rowtype) (void)hipFree(rowtype);
     if (rowabi) (void)hipFree(rowabi);
     rowtype = nullptr; rowabi = nullptr;
@@ -252,6 +253,19 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
   hipError_t e = up(&d->G, Gi);
   if (e == hipSuccess && !fragG.empty()) e = up(&d->fragG, fragG);
   if (e == hipSuccess && !fragQ.empty()) e = up(&d->fragQ, fragQ);
+  {
+    // pair order: [k-slice / 2][lane][k-slice % 2] inside every 4 x 64 fragment block (one 16-byte load per lane
+    // fetches two k-slices: acn_qp_long.hpp)
+    auto paired = [](const std::vector<double>& in) {
+      std::vector<double> out(in.size());
+      for (size_t blk = 0; blk + 256 <= in.size(); blk += 256)
+        for (int sI = 0; sI < 4; ++sI)
+          for (int lane = 0; lane < 64; ++lane) out[blk + (size_t)(sI >> 1) * 128 + lane * 2 + (sI & 1)] = in[blk + (size_t)sI * 64 + lane];
+      return out;
+    };
+    if (e == hipSuccess && !fragG.empty()) e = up(&d->fragG2, paired(fragG));
+    if (e == hipSuccess && !fragQ.empty()) e = up(&d->fragQ2, paired(fragQ));
+  }
   if (e == hipSuccess) e = up(&d->Ghat, Gh);
   if (e == hipSuccess) e = up(&d->Q, Q);
   if (e == hipSuccess) e = up(&d->lam, lam);
@@ -584,7 +598,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   acnqp::TiledArgs a;
   a.B = p->batch; a.N = h->N; a.Tm = p->t_max; a.K = p->k_sessions; a.NP = h->NP; a.MR = d->MR;
   a.G = d->G; a.Ghat = d->Ghat; a.Q = d->Q; a.lam = d->lam; a.rowlim = d->rowlim; a.rowtype = d->rowtype;
-  a.fragG = d->fragG; a.fragQ = d->fragQ;
+  a.fragG = d->fragG; a.fragQ = d->fragQ; a.fragG2 = d->fragG2; a.fragQ2 = d->fragQ2;
   a.horizon = p->horizon; a.lb = p->lb; a.ub = p->ub; a.q = p->q; a.pdiag = p->pdiag;
   a.s_off = p->s_off; a.s_len = p->s_len; a.s_cap = p->s_cap; a.s_eq = p->s_eq; a.peak = h->has_peak ? p->peak : nullptr;
   a.lf = h->has_flat ? p->lf : nullptr;

@@ -57,7 +57,11 @@ struct WsRef32 {
   __device__ inline void operator=(float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, so, 0); }
 };
 
-constexpr int kLongAccelMax = 5;   // Anderson columns (the ring lives in the workspace: any shape takes all five)
+constexpr int kLongAccelMax = 5;
+#ifndef ACNQP_LONG_PAIR_ROWS
+#define ACNQP_LONG_PAIR_ROWS 9
+#endif
+constexpr int kLongPairRows = ACNQP_LONG_PAIR_ROWS;   // longest row (column tiles) whose two paired rows fit the registers   // Anderson columns (the ring lives in the workspace: any shape takes all five)
 
 // doubles of workspace one problem needs (accel = Anderson columns in use)
 __host__ __device__ inline long long long_workspace(int NP, int CTL, int K, int MT, int accel) {
@@ -128,8 +132,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   const WsArr32 HF{GP.off + DU * 8u};
   const WsArr32 HG{HF.off + (unsigned)aa_m * DU * 4u};
   real* AaH = AaHS + wave * (AMX * AMX + AMX);   // this wave's copy of (H, b): every wave runs the small solve itself
-  const real* FG = static_cast<const real*>(A.fragG);
-  const real* FQ = static_cast<const real*>(A.fragQ);
+  const real* FG = static_cast<const real*>(A.fragG2);   // pair order: a 16-byte load per lane fetches two k-slices
+  const real* FQ = static_cast<const real*>(A.fragQ2);
   const real* Gm = static_cast<const real*>(A.G);
   const real* Lm = static_cast<const real*>(A.lam);
   const real* RL = static_cast<const real*>(A.rowlim);
@@ -204,9 +208,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     st2(base, uo, v[0], v[1]);
     st2(base, uo + 128u, v[2], v[3]);
   };
-  // one fragment value of the site matrices (plain [k-slice][lane] order, shared with the other kernels)
-  auto atf = [&](const real* base, unsigned uo) -> real {
-    return *reinterpret_cast<const real*>(reinterpret_cast<const char*>(base + uo) + (unsigned)lane * 8u);
+  // the four k-slices of one 4 x 64 fragment block of the site matrices (pair order: two 16-byte loads)
+  auto ldf4 = [&](const real* blk, real (&v)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const ws_d2 d = *reinterpret_cast<const ws_d2*>(reinterpret_cast<const char*>(blk + 128 * h) + (unsigned)lane * 16u);
+      v[2 * h] = d.x; v[2 * h + 1] = d.y;
+    }
   };
 
   // ---- init (row items): inputs -> fragment order; |q|_inf, max ub; a session whose bounds cannot meet its energy
@@ -448,8 +456,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       const real* f1 = fgb + (size_t)(e1 * MT + mo) * 2 * 4 * 64;
       ld4(RZ, fidx(e, c, 0), b0);
       ld4(RZ, fidx(e1, c, 0), b1);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) { a0[s] = atf(f0, s * 64); a1[s] = atf(f1, s * 64); }
+      ldf4(f0, a0); ldf4(f1, a1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s) p = M::mma(a0[s], b0[s], p);
@@ -517,10 +524,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
     vec4 zt = {0, 0, 0, 0};
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+    for (int mi = 0; mi < MT; ++mi) {
+      real fq[4], hv[4];
+      ldf4(FQ + ((mo * MT + mi) * 2 + 1) * 256, fq);
+      ld4(HH, sidx2(mi, c, 0), hv);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
-        zt = M::mma(atf(FQ, (((mo * MT + mi) * 2 + 1) * 4 + s) * 64), at(HH, sidx2(mi, c, s)), zt);
+      for (int s = 0; s < 4; ++s) zt = M::mma(fq[s], hv[s], zt);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const unsigned i = sidx2(mo, c, r);
@@ -598,11 +608,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         real z2t[4], y2t[4];
         ld4(Z2, sidx2(mi, c, 0), z2t);
         ld4(Y2, sidx2(mi, c, 0), y2t);
+        ldf4(FQi + ((mo * MT + mi) * 2 + 0) * 256, fq0[mi]);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          bz[mi][s] = rho * z2t[s] - y2t[s];
-          fq0[mi][s] = atf(FQi, (((mo * MT + mi) * 2 + 0) * 4 + s) * 64);
-        }
+        for (int s = 0; s < 4; ++s) bz[mi][s] = rho * z2t[s] - y2t[s];
       }
       const vec4 p = site_p(mo, c, FGi);
       vec4 wh = {0, 0, 0, 0};
@@ -634,8 +642,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
           ld4(HH, sidx2(mi, c, 0), hv[mi]);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) fq1[mi][s] = atf(FQi, (((mo * MT + mi) * 2 + 1) * 4 + s) * 64);
+          ldf4(FQi + ((mo * MT + mi) * 2 + 1) * 256, fq1[mi]);
         }
         ld4(GX, sidx2(mo, c, 0), gxv); ld4(Z2, sidx2(mo, c, 0), z2v); ld4(Y2, sidx2(mo, c, 0), y2v);
         __builtin_amdgcn_sched_barrier(0);
@@ -665,8 +672,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           ld4(EH, sidx2(m, c, 0), ev4[m]);
-#pragma unroll
-          for (int s = 0; s < 4; ++s) fx[m][s] = atf(fg, ((m * 2 + 1) * 4 + s) * 64);
+          ldf4(fg + (m * 2 + 1) * 256, fx[m]);
         }
         __builtin_amdgcn_sched_barrier(0);
         vec4 acc = {rv[0], rv[1], rv[2], rv[3]};
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     STAMP(4);   // barrier
     // ================= phase 2: row items (and the demand-charge row, by the last wave) ============================
     if (dc_on && wave == NWV - 1) { RELANE(); dc_row(); }
-    if constexpr (CTL <= 9) {
+    if constexpr (CTL <= kLongPairRows) {
       // an item = the two rows of a register pair (8 EVSEs x the whole horizon): every access moves 16 bytes per lane
 #pragma unroll 1
       for (int pi = wave; pi < 2 * NE; pi += NWV) {
@@ -913,15 +919,19 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         const int qe = q - n_site;
         const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
         vec4 gty = {0, 0, 0, 0};
+        real xs4[4], qs4[4], ys4[4], zs4[4];
+        ld4(Xs, fidx(e, c, 0), xs4); ld4(Qs, fidx(e, c, 0), qs4); ld4(Y1s, fidx(e, c, 0), ys4); ld4(Z1s, fidx(e, c, 0), zs4);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m) {
+          real y2t[4];
+          ld4(Y2, sidx2(m, c, 0), y2t);
 #pragma unroll
           for (int s = 0; s < 4; ++s)
-            gty = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], at(Y2, sidx2(m, c, s)), gty);
+            gty = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], y2t[s], gty);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const unsigned i = fidx(e, c, r);
-          const real xk = at(Xs, i), qk = at(Qs, i), yk = at(Y1s, i), zk = at(Z1s, i);
+          const real xk = xs4[r], qk = qs4[r], yk = ys4[r], zk = zs4[r];
           v0 = fmax(v0, fabs(xk - zk));
           v1 = fmax(v1, fabs(pd * xk + qk + yk + gty[r]));
           v2 = fmax(v2, fmax(fabs(xk), fabs(zk)));

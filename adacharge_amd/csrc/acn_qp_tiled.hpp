@@ -63,6 +63,7 @@ struct TiledArgs {
   const void *G, *Ghat, *Q, *lam, *rowlim;   // [MR][NP], [MR][NP], [MR][MR], [MR], [MR]  (real)
   const int32_t* rowtype;                     // [MR]
   const void *fragG, *fragQ;                  // Ghat, Q as MFMA A-operand fragments: [NW][MT][2][4][64], [MT][MT][2][4][64]
+  const void *fragG2, *fragQ2;                // the same blocks with the k-slices as two pairs per lane: [..][2][64][2] (acn_qp_long.hpp)
   const int32_t* horizon;
   const double *lb, *ub, *q, *pdiag;
   const int32_t *s_off, *s_len;
