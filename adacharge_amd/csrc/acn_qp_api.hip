@@ -441,6 +441,23 @@ static hipError_t launch_long_one(const acnqp::StreamArgs& sa, hipStream_t st) {
   return hipGetLastError();
 }
 
+// r0 / zh in LDS when the array fits next to e^, h^ (acn_qp_long.hpp, RZL): <= 156 KB of dynamic LDS
+template <int CTL, int MT>
+static hipError_t launch_long_rzl(const acnqp::StreamArgs& sa, hipStream_t st) {
+  constexpr int NWV = 8;
+  const int NE = sa.t.NP / 16;
+  const size_t lds = (size_t)256 * CTL * (2 * MT + NE) * sizeof(double);
+  auto kern = &acnqp::admm_long_kernel<CTL, MT, NWV, false, true>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
+  return hipGetLastError();
+}
+static bool rzl_fits(int CTL, int MT, int NP) {
+  static const bool off = std::getenv("ACNQP_NO_RZL") != nullptr;   // diagnostic: r0 / zh in the workspace
+  return !off && (CTL == 6 || CTL == 9) && (size_t)256 * CTL * (2 * MT + NP / 16) * sizeof(double) <= (size_t)156 * 1024;
+}
+
 template <int CTL, int MT>
 static hipError_t launch_long_lds(const acnqp::StreamArgs& sa, hipStream_t st) {
   constexpr int NWV = 8;
@@ -456,6 +473,14 @@ static hipError_t launch_long_lds(const acnqp::StreamArgs& sa, hipStream_t st) {
 static hipError_t launch_long(const acnqp::StreamArgs& sa, hipStream_t st, bool lds_resident) {
   const int CTL = long_tiles(sa.t.Tm), MT = sa.t.MR / 16;
   if (lds_resident) return launch_long_lds<2, 2>(sa, st);   // lds_long_shape: two column tiles, two row tiles
+  if (rzl_fits(CTL, MT, sa.t.NP)) {
+    switch (CTL * 10 + MT) {
+      case 61: return launch_long_rzl<6, 1>(sa, st);
+      case 62: return launch_long_rzl<6, 2>(sa, st);
+      case 91: return launch_long_rzl<9, 1>(sa, st);
+      default: return launch_long_rzl<9, 2>(sa, st);
+    }
+  }
   switch (CTL * 10 + MT) {
     case 21: return launch_long_one<2, 1>(sa, st);
     case 22: return launch_long_one<2, 2>(sa, st);

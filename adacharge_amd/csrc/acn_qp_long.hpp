@@ -75,7 +75,9 @@ __host__ __device__ inline long long long_workspace(int NP, int CTL, int K, int 
 // LDSR: the iterates (x, z1, y1, q, lb, ub, r0 / zh and the site-row state) live in LDS instead of the workspace -- for
 // problems small enough (N <= 64, horizon <= 32: 7 x 16 KB + site rows + e^, h^ <= 156 KB); only the Anderson vectors,
 // the certificate's snapshot and the session multipliers stay in the workspace.
-template <int CTL, int MT, int NWV, bool LDSR = false>
+// RZL: only the r0 / zh array lives in LDS (it is the array with the most passes per iteration: written and read by
+// both phases, 5 of 15) -- for problems whose one array fits next to e^, h^ (54 x 144: 72 + 18 KB).
+template <int CTL, int MT, int NWV, bool LDSR = false, bool RZL = false>
 __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs SA) {
   using M = Mfma<double>;
   using vec4 = M::vec4;
@@ -109,7 +111,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   // tile-fragment order [MT][CTL][4][64].  Same workspace layout either way (the LDS-resident variant leaves its
   // share of it unused).
   typedef typename std::conditional<LDSR, real*, WsArr64>::type StArr;
-  StArr Xs, Z1s, Y1s, Qs, LBs, UBs, RZ, Z2, Y2, GX;
+  typedef typename std::conditional<LDSR || RZL, real*, WsArr64>::type RzArr;
+  StArr Xs, Z1s, Y1s, Qs, LBs, UBs, Z2, Y2, GX;
+  RzArr RZ;
   const unsigned z2off = 7 * NT8 + (unsigned)(K * NP) * 8u;
   if constexpr (LDSR) {
     real* S0 = HH + MT * CTL * 256;
@@ -117,7 +121,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     Z2 = S0 + 7 * NT; Y2 = Z2 + MT * CTL * 256; GX = Y2 + MT * CTL * 256;
   } else {
     Xs = WsArr64{0}; Z1s = WsArr64{NT8}; Y1s = WsArr64{2 * NT8}; Qs = WsArr64{3 * NT8}; LBs = WsArr64{4 * NT8};
-    UBs = WsArr64{5 * NT8}; RZ = WsArr64{6 * NT8};
+    UBs = WsArr64{5 * NT8};
+    if constexpr (RZL) RZ = HH + MT * CTL * 256; else RZ = WsArr64{6 * NT8};
     Z2 = WsArr64{z2off}; Y2 = WsArr64{z2off + MS8}; GX = WsArr64{z2off + 2 * MS8};
   }
   real* MU = W0 + 7 * NT;                 // [K][NP] (indexed per lane: a plain pointer)
