@@ -219,7 +219,8 @@ class BatchResult:
     pri_res: np.ndarray
     dua_res: np.ndarray
     obj: np.ndarray
-    kernel_ms: float = float("nan")
+    kernel_ms: float = float("nan")   # sum of the HIP-event durations of the call's launches (chunks of the pipelined
+                                      # entry overlap on the GPU: an upper bound of the time the GPU was busy)
     y: Optional[np.ndarray] = None   # (B, Mg, Tm) multipliers of the site rows (when asked for): warm_y of a later solve
 
 
@@ -353,9 +354,10 @@ class SiteHandle:
         self._check_site(batch)
         o = options if options is not None else default_options()
         p, r, res, keep = self._marshal(batch, pinned_results, warm=warm, want_y=want_y)
+        self.kernel_times()   # forget earlier launches: kernel_ms below is the sum over THIS call's launches (chunks)
         _check(self._lib.acnqp_solve_batch(self._h, C.byref(p), C.byref(o), C.byref(r)), "acnqp_solve_batch")
         del keep
-        res.kernel_ms = float(self._lib.acnqp_last_kernel_ms(self._h))
+        res.kernel_ms = float(sum(self.kernel_times()))
         if retry_stalled and o.adapt_every > 0:
             self._retry_stalled(batch, o, res, want_y)
         return self._finish(batch, res)
@@ -384,7 +386,7 @@ class SiteHandle:
         p, r, res2, keep = self._marshal(sub, False, want_y=want_y)
         _check(self._lib.acnqp_solve_batch(self._h, C.byref(p), C.byref(o2), C.byref(r)), "acnqp_solve_batch (retry)")
         del keep
-        res.kernel_ms += float(self._lib.acnqp_last_kernel_ms(self._h))
+        res.kernel_ms += float(sum(self.kernel_times()))
         res.iters[bad] += res2.iters
         won = res2.status == STATUS_SOLVED
         idx = bad[won]
