@@ -453,6 +453,22 @@ static hipError_t launch_long_rzl(const acnqp::StreamArgs& sa, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
   return hipGetLastError();
 }
+// ... and x as well (horizons up to 96: 2 x 48 KB next to e^, h^)
+template <int MT>
+static hipError_t launch_long_xsl(const acnqp::StreamArgs& sa, hipStream_t st) {
+  constexpr int NWV = 8, CTL = 6;
+  const int NE = sa.t.NP / 16;
+  const size_t lds = (size_t)256 * CTL * (2 * MT + 2 * NE) * sizeof(double);
+  auto kern = &acnqp::admm_long_kernel<CTL, MT, NWV, false, true, true>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
+  return hipGetLastError();
+}
+static bool xsl_fits(int CTL, int MT, int NP) {
+  static const bool off = std::getenv("ACNQP_NO_XSL") != nullptr || std::getenv("ACNQP_NO_RZL") != nullptr;   // diagnostics
+  return !off && CTL == 6 && (size_t)256 * CTL * (2 * MT + 2 * (NP / 16)) * sizeof(double) <= (size_t)156 * 1024;
+}
 static bool rzl_fits(int CTL, int MT, int NP) {
   static const bool off = std::getenv("ACNQP_NO_RZL") != nullptr;   // diagnostic: r0 / zh in the workspace
   return !off && (CTL == 6 || CTL == 9) && (size_t)256 * CTL * (2 * MT + NP / 16) * sizeof(double) <= (size_t)156 * 1024;
@@ -473,6 +489,7 @@ static hipError_t launch_long_lds(const acnqp::StreamArgs& sa, hipStream_t st) {
 static hipError_t launch_long(const acnqp::StreamArgs& sa, hipStream_t st, bool lds_resident) {
   const int CTL = long_tiles(sa.t.Tm), MT = sa.t.MR / 16;
   if (lds_resident) return launch_long_lds<2, 2>(sa, st);   // lds_long_shape: two column tiles, two row tiles
+  if (xsl_fits(CTL, MT, sa.t.NP)) return MT == 1 ? launch_long_xsl<1>(sa, st) : launch_long_xsl<2>(sa, st);
   if (rzl_fits(CTL, MT, sa.t.NP)) {
     switch (CTL * 10 + MT) {
       case 61: return launch_long_rzl<6, 1>(sa, st);

@@ -77,7 +77,8 @@ __host__ __device__ inline long long long_workspace(int NP, int CTL, int K, int 
 // the certificate's snapshot and the session multipliers stay in the workspace.
 // RZL: only the r0 / zh array lives in LDS (it is the array with the most passes per iteration: written and read by
 // both phases, 5 of 15) -- for problems whose one array fits next to e^, h^ (54 x 144: 72 + 18 KB).
-template <int CTL, int MT, int NWV, bool LDSR = false, bool RZL = false>
+// XSL (with RZL): x too (3 passes) -- horizons up to 96 on a 64-EVSE site.
+template <int CTL, int MT, int NWV, bool LDSR = false, bool RZL = false, bool XSL = false>
 __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs SA) {
   using M = Mfma<double>;
   using vec4 = M::vec4;
@@ -112,15 +113,19 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   // share of it unused).
   typedef typename std::conditional<LDSR, real*, WsArr64>::type StArr;
   typedef typename std::conditional<LDSR || RZL, real*, WsArr64>::type RzArr;
-  StArr Xs, Z1s, Y1s, Qs, LBs, UBs, Z2, Y2, GX;
+  typedef typename std::conditional<LDSR || XSL, real*, WsArr64>::type XsArr;
+  static_assert(!XSL || RZL, "x joins r0 / zh in LDS, never alone");
+  StArr Z1s, Y1s, Qs, LBs, UBs, Z2, Y2, GX;
   RzArr RZ;
+  XsArr Xs;
   const unsigned z2off = 7 * NT8 + (unsigned)(K * NP) * 8u;
   if constexpr (LDSR) {
     real* S0 = HH + MT * CTL * 256;
     Xs = S0; Z1s = S0 + NT; Y1s = S0 + 2 * NT; Qs = S0 + 3 * NT; LBs = S0 + 4 * NT; UBs = S0 + 5 * NT; RZ = S0 + 6 * NT;
     Z2 = S0 + 7 * NT; Y2 = Z2 + MT * CTL * 256; GX = Y2 + MT * CTL * 256;
   } else {
-    Xs = WsArr64{0}; Z1s = WsArr64{NT8}; Y1s = WsArr64{2 * NT8}; Qs = WsArr64{3 * NT8}; LBs = WsArr64{4 * NT8};
+    if constexpr (XSL) Xs = HH + MT * CTL * 256 + NT; else Xs = WsArr64{0};
+    Z1s = WsArr64{NT8}; Y1s = WsArr64{2 * NT8}; Qs = WsArr64{3 * NT8}; LBs = WsArr64{4 * NT8};
     UBs = WsArr64{5 * NT8};
     if constexpr (RZL) RZ = HH + MT * CTL * 256; else RZ = WsArr64{6 * NT8};
     Z2 = WsArr64{z2off}; Y2 = WsArr64{z2off + MS8}; GX = WsArr64{z2off + 2 * MS8};
