@@ -770,6 +770,40 @@ def test_long_horizon_kernel_many_sessions_per_evse_and_warm_start():
     h.close()
 
 
+def test_long_horizon_kernel_same_bits_with_arrays_in_lds_or_workspace(tmp_path):
+    """Where the r0 / zh array (and x, up to 96 periods) lives -- LDS or the workspace -- is a placement, not an
+    algorithm: a child process with ACNQP_NO_RZL=1 (read once per process) must return the same iterations and the
+    same bits."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from adacharge_amd import ObjectiveComponent, equal_share, quick_charge, sites\n"
+        "from adacharge_amd.acn import Interface\n"
+        "from adacharge_amd.backend import SiteHandle, default_options\n"
+        "from adacharge_amd.builder import build_batch\n"
+        "infra = sites.caltech54(); iface = Interface({'infrastructure_info': infra, 'period': 5})\n"
+        "obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]\n"
+        "out = {}\n"
+        "for T in (96, 144):\n"
+        "    batch = build_batch(sites.snapshot_batch(infra, T, 4, seed=100 + T, demand_range=(5.0, 60.0)), infra, iface, obj, 'SOC')\n"
+        "    h = SiteHandle(batch.site, 0); r = h.solve(batch, default_options()); h.close()\n"
+        "    out['x%%d' %% T] = r.x; out['it%%d' %% T] = r.iters\n"
+        "np.savez(sys.argv[1], **out)\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = {}
+    for tag, env in (("lds", {}), ("ws", {"ACNQP_NO_RZL": "1"})):
+        files[tag] = str(tmp_path / f"{tag}.npz")
+        e = dict(os.environ); e.update(env)
+        subprocess.run([sys.executable, "-c", code, files[tag]], check=True, env=e, timeout=600)
+    a, b = np.load(files["lds"]), np.load(files["ws"])
+    for T in (96, 144):
+        assert np.array_equal(a[f"it{T}"], b[f"it{T}"])
+        assert np.array_equal(a[f"x{T}"], b[f"x{T}"])
+
+
 @pytest.mark.parametrize("ct", ["LINEAR", "SOC"])
 def test_general_kernel_still_serves_what_the_long_kernel_does_not(ct, monkeypatch):
     """The general-shape kernel keeps the demand-charge row at long horizons, more than 32 site rows and horizons
