@@ -10,18 +10,20 @@ from adacharge_amd.backend import SiteHandle, default_options
 from adacharge_amd.builder import build_batch
 from tests.test_gpu_parity import _random_sessions_general
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+B0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # second argument: seed offset (other instances of the same classes)
 bad_total = 0
 # cases 8-13: the long-horizon kernel (horizons 40 ... 200, two session slots, peaks, equality rows) and its
 # LDS-resident variant (jpl52 at horizons 24 / 30)
 for case in range(14):
-    rng = np.random.default_rng(5000 + case)
+    rng = np.random.default_rng(5000 + case + 100 * SEED)
+    B = B0
     T = [12, 16, 24, 30, 12, 20, 9, 32, 40, 72, 144, 200, 24, 30][case]
     ct = ["SOC", "LINEAR"][case % 2]
     eq = case in (2, 5, 9); two = case in (1, 3, 5, 7, 8, 10, 13); with_peak = case in (0, 3, 4, 7, 9, 11, 12)
     infra = sites.caltech54() if case not in (6, 10, 12, 13) else sites.jpl52()
     if case >= 8 and T > 32:
-        B = max(32, B // 16)
+        B = max(32, B0 // 16)
     iface = Interface({"infrastructure_info": infra, "period": 5, "prices": rng.uniform(0.05, 0.4, size=256)})
     obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 10.0 ** rng.uniform(-4, -2)),
            ObjectiveComponent(tou_energy_cost, float(rng.uniform(0, 5))), ObjectiveComponent(total_energy, float(rng.uniform(0, 2)))]
