@@ -510,7 +510,7 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
                               dua / fmax((real)A.eps_abs + (real)A.eps_rel * ndua, (real)1e-300));
       if (score < (real)kStallGain * best_score) { best_score = score; best_it = it; }
       const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel);
-      const bool stalled = it - best_it >= kStallIters && score <= (real)kStallNear * best_score && inacc;   // acn_qp_tiled.hpp
+      const bool stalled = it - best_it >= kStallIters && score <= (real)kStallNear * best_score;   // acn_qp_tiled.hpp
       if (done) {
       } else if (it >= A.max_iter || stalled) {
         done = true;

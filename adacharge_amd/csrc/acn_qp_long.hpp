@@ -1107,7 +1107,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       const real score = fmax(pri / fmax(eps_p, 1e-300), dua / fmax(eps_d, 1e-300));
       if (score < kStallGain * best_score) { best_score = score; best_it = it; }
       const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel);
-      const bool stalled = it - best_it >= kStallIters && score <= kStallNear * best_score && inacc;   // acn_qp_tiled.hpp
+      const bool stalled = it - best_it >= kStallIters && score <= kStallNear * best_score;   // acn_qp_tiled.hpp
       if (done) {
       } else if (it >= A.max_iter || stalled) {
         done = true;

@@ -224,12 +224,12 @@ __host__ __device__ inline bool inaccurate_ok(real pri, real dua, real npri, rea
   return pri <= ea + er * npri && dua <= ea + er * ndua;
 }
 // Stall rule: a problem whose residual score max(pri / eps_pri, dua / eps_dua) has not improved by 10 % for
-// kStallIters iterations, sits within kStallNear of its best score (i.e. on the plateau, not in the transient after a
-// rho change) and qualifies as SOLVED_INACCURATE by the rule above is finished as such.  Converging problems never
+// kStallIters iterations and sits within kStallNear of its best score (i.e. on the plateau, not in the transient after
+// a rho change) is finished: SOLVED_INACCURATE if it qualifies by the rule above, MAX_ITER otherwise (what it would be
+// max_iter - it iterations later; the binding's second pass re-solves both kinds).  Converging problems never
 // wait that long between improvements (longest wait seen on solved instances of every shape in tools/ and tests/:
 // 1,240 iterations, a caltech54 x 12 LINEAR LP); the ones that do are the tangentially degenerate congested instances of DESIGN.md section 6, which
-// otherwise burn max_iter iterations on a plateau and end with the same status.  A problem that does not qualify
-// keeps iterating to max_iter.
+// otherwise burn max_iter iterations on a plateau and end with the same status.
 constexpr double kStallGain = 0.9, kStallNear = 1.25;
 constexpr int kStallIters = 3000;
 constexpr double kAdaptWiden = 8.0;   // rho adaptation band: adapt_tol (1 + adaptations / kAdaptWiden): no limit cycles
@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
       const real score = fmax(pri / fmax(eps_p, (real)1e-300), dua / fmax(eps_d, (real)1e-300));
       if (score < (real)kStallGain * best_score) { best_score = score; best_it = it; }
       const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel);
-      const bool stalled = it - best_it >= kStallIters && score <= (real)kStallNear * best_score && inacc;
+      const bool stalled = it - best_it >= kStallIters && score <= (real)kStallNear * best_score;
       if (done) {
       } else if (it >= A.max_iter || stalled) {
         done = true;

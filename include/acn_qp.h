@@ -51,7 +51,8 @@ extern "C" {
  * InfeasibilityException exactly as aco.py:319-320 does for cvxpy statuses */
 #define ACNQP_STATUS_UNSET 0
 #define ACNQP_STATUS_SOLVED 1             /* cp.OPTIMAL                     */
-#define ACNQP_STATUS_MAX_ITER 2           /* residuals above tolerance at max_iter */
+#define ACNQP_STATUS_MAX_ITER 2           /* residuals above tolerance at max_iter, or stalled above the
+                                             SOLVED_INACCURATE level (no 10 % progress for 3000 iterations) */
 #define ACNQP_STATUS_PRIMAL_INFEASIBLE 3  /* ADMM certificate (cp.INFEASIBLE) */
 #define ACNQP_STATUS_EMPTY_SET 4          /* a session's bounds cannot meet its energy row */
 #define ACNQP_STATUS_SOLVED_INACCURATE 5   /* max_iter or the stall rule (no 10 % progress of the residuals for

@@ -84,8 +84,8 @@ static const double kStartGain = 1e5;
 static const double kAdaptWiden = 8.0;   /* rho adaptation band: adapt_tol (1 + adaptations / kAdaptWiden) */
 static const int kAaPeriod = 5;
 /* stall rule of the device kernels (acn_qp_tiled.hpp): no 10 % improvement of max(pri / eps_pri, dua / eps_dua) for
- * kStallIters iterations, the score within kStallNear of its best and the residuals good enough for SOLVED_INACCURATE
- * end the problem as such */
+ * kStallIters iterations with the score within kStallNear of its best end the problem (SOLVED_INACCURATE if the
+ * residuals are good enough for it, MAX_ITER otherwise) */
 static const double kStallGain = 0.9, kStallNear = 1.25;
 static const int kStallIters = 3000;
 static const double kAaReg = 1e-4, kAaSafe = 1.2, kAaDrift = 1e-3;
@@ -448,7 +448,7 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
       /* solved, inaccurately: within 100 x the tolerance, or within cvxpy's OSQP default 1e-5, whichever is looser */
       const double ea = fmax(100.0 * O->eps_abs, 1e-5), er = fmax(100.0 * O->eps_rel, 1e-5);
       const int inacc = pri <= ea + er * npri && dua <= ea + er * ndua;
-      const int stalled = it - best_it >= kStallIters && score <= kStallNear * best_score && inacc;
+      const int stalled = it - best_it >= kStallIters && score <= kStallNear * best_score;
       if (done) {
       } else if (it >= O->max_iter || stalled) {
         done = 1;

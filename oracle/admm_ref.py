@@ -269,7 +269,7 @@ def solve_one(batch, b, opts: AdmmOptions = AdmmOptions(), trace=None):
             ea, er = max(100 * opts.eps_abs, 1e-5), max(100 * opts.eps_rel, 1e-5)   # 100 x tolerance or cvxpy's OSQP default
             inacc = pri <= ea + er * npri and dua <= ea + er * ndua
             # the device kernels' stall rule (acn_qp_tiled.hpp)
-            stalled = it - best_it >= STALL_ITERS and score <= STALL_NEAR * best_score and inacc
+            stalled = it - best_it >= STALL_ITERS and score <= STALL_NEAR * best_score
             if (it == opts.max_iter or stalled) and inacc:
                 status = ST_SOLVED_INACCURATE
             if stalled:
