@@ -2,21 +2,30 @@
 
 ``python -m adacharge_amd.build`` or ``__graft_entry__.build()``.  hipcc
 cross-compiles without a GPU; the built .so is git-ignored but travels to the
-GPU box with the repo snapshot.
+GPU box with the repo snapshot.  Every kernel family is its own translation unit
+(objects under adacharge_amd/lib/obj/, rebuilt only when a file they include
+changed), compiled in parallel and linked into one shared library.
 """
 from __future__ import annotations
 
+import concurrent.futures
 import os
+import re
 import shutil
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "adacharge_amd", "csrc")
+INC = os.path.join(ROOT, "include")
 LIBDIR = os.path.join(ROOT, "adacharge_amd", "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libacn_qp_hip.so")
-SOURCES = [os.path.join(CSRC, "acn_qp_api.hip")]
-DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("acn_qp_tiled.hpp", "acn_qp_general.hpp", "acn_qp_stream.hpp", "acn_qp_long.hpp")] + [os.path.join(ROOT, "include", "acn_qp.h")]
+UNITS = ("acn_qp_api", "acn_qp_tiled_ct1", "acn_qp_tiled_ct2", "acn_qp_stream", "acn_qp_long", "acn_qp_general")
+SOURCES = [os.path.join(CSRC, u + ".hip") for u in UNITS]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans", "-mno-amdgpu-ieee", "-fPIC"]
+
+_INCLUDE = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
 
 
 def hipcc_path() -> str:
@@ -26,26 +35,64 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or add /opt/rocm/bin to PATH)")
 
 
+def dependencies(path: str, seen=None) -> set:
+    """The file and every project header it includes (transitively)."""
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    for name in _INCLUDE.findall(open(path).read()):
+        for base in (CSRC, INC):
+            dependencies(os.path.join(base, name), seen)
+    return seen
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
 def up_to_date() -> bool:
-    if not os.path.exists(LIB):
-        return False
-    t = os.path.getmtime(LIB)
-    return all(os.path.getmtime(d) <= t for d in DEPS)
+    deps = set()
+    for s in SOURCES:
+        deps |= dependencies(s)
+    return not _stale(LIB, deps | {os.path.abspath(__file__)})
 
 
-def build_hip_library(force: bool = False, verbose: bool = True) -> str:
-    if not force and up_to_date():
+def build_hip_library(force: bool = False, verbose: bool = True, extra_flags=(), out: str = LIB) -> str:
+    """Compile stale translation units (in parallel) and link.  ``extra_flags`` / ``out``: diagnostic builds
+    (e.g. ``-DACNQP_STAMPS``) into another file, always from scratch."""
+    diagnostic = bool(extra_flags) or out != LIB
+    if not force and not diagnostic and up_to_date():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [
-        hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans", "-mno-amdgpu-ieee", "-fPIC", "-shared",
-        "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-        *SOURCES, "-o", LIB,
-    ]
+    objdir = OBJDIR if not diagnostic else OBJDIR + "_diag"
+    os.makedirs(objdir, exist_ok=True)
+    todo = []
+    for unit in UNITS:
+        obj = os.path.join(objdir, unit + ".o")
+        if force or diagnostic or _stale(obj, dependencies(os.path.join(CSRC, unit + ".hip")) | {os.path.abspath(__file__)}):
+            todo.append(unit)
+    workers = max(1, min(len(todo), (os.cpu_count() or 2) - 1, 6))
+
+    def one(unit):
+        src = os.path.join(CSRC, unit + ".hip")
+        obj = os.path.join(objdir, unit + ".o")
+        cmd = [hipcc_path(), *FLAGS, *extra_flags, "-I" + INC, "-I" + CSRC, "-c", src, "-o", obj]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if todo:
+        with concurrent.futures.ThreadPoolExecutor(workers) as pool:
+            list(pool.map(one, todo))
+    objs = [os.path.join(objdir, u + ".o") for u in UNITS]
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", *objs, "-o", out]
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -10,10 +10,7 @@
 #include <vector>
 
 #include "acn_qp.h"
-#include "acn_qp_tiled.hpp"
-#include "acn_qp_general.hpp"
-#include "acn_qp_stream.hpp"
-#include "acn_qp_long.hpp"
+#include "acn_qp_launch.hpp"
 
 namespace {
 
@@ -118,7 +115,7 @@ struct acnqp_handle {
   int N = 0, M = 0, Mg = 0, cone = 0, has_peak = 0, has_flat = 0, has_max = 0;
   int NW = 4, NP = 64;
   std::vector<double> G, limits;   // host copy in ABI order
-  SiteDev dev64, dev32;
+  SiteDev dev64;
   static constexpr int kEvRing = 64;               // event pairs of the most recent launches
   hipEvent_t ev_start[kEvRing] = {}, ev_stop[kEvRing] = {};
   long long launches = 0, reported = 0;           // launches recorded / already handed out by acnqp_kernel_times
@@ -143,9 +140,9 @@ inline int soc_slot(bool f64, int c, int im) {
   return f64 ? 8 * (c / 4) + (c % 4) + 4 * im : 2 * c + im;
 }
 
-template <typename real>
 int build_site_dev(acnqp_handle* h, SiteDev* d) {
-  const bool f64 = sizeof(real) == 8;
+  using real = double;
+  const bool f64 = true;
   const int N = h->N, M = h->M, NP = h->NP;
   int raw;
   if (h->cone == ACNQP_CONE_SOC) raw = (f64 ? 8 * ((M + 3) / 4) : 2 * M) + h->has_peak + h->has_flat + h->has_max;
@@ -281,87 +278,6 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
   return ACNQP_OK;
 }
 
-// LDS one workgroup may use: the whole CU when alone, half of it when two share the CU
-constexpr int kLdsPerCu = 160 * 1024;
-constexpr int kAccelMax1 = 5, kAccelMax2 = 5;   // Anderson columns compiled into the OCC = 1 / OCC = 2 variants
-
-// Anderson columns that fit next to the solver's own LDS for this kernel shape with `occ` workgroups per CU
-template <typename real>
-int accel_capacity(int NW, int MT, int CT, int NP, int K, int occ, int pbuf_single = 0) {
-  const acnqp::TiledLds base(NW, MT, CT, NP, K, occ == 1 ? kAccelMax1 : kAccelMax2, 1, (int)sizeof(real), pbuf_single);
-  const int col = acnqp::TiledLds::column_bytes(NW, MT, CT);
-  const int fixed = base.total * (int)sizeof(real) - col;
-  const int cap = (kLdsPerCu / occ - fixed - 64) / col;
-  return std::max(0, std::min(cap, occ == 1 ? kAccelMax1 : kAccelMax2));
-}
-
-// One workgroup per CU: if the double-buffered partial-tile slab leaves fewer than the compiled-in number of ring
-// columns, give one slab up (one more barrier per iteration buys a column: on the congested horizon-24 problems a
-// fourth / fifth column is worth 5x fewer iterations on the slowest instances)
-template <typename real>
-int accel_capacity_best(int NW, int MT, int CT, int NP, int K, int* pbuf_single) {
-  const int two = accel_capacity<real>(NW, MT, CT, NP, K, 1, 0);
-  const int one = accel_capacity<real>(NW, MT, CT, NP, K, 1, 1);
-  *pbuf_single = one > two ? 1 : 0;
-  return std::max(one, two);
-}
-
-template <typename real, int NW, int CT, int MT, int KS, int OCC>
-hipError_t launch_tiled_occ(const acnqp::TiledArgs& a, hipStream_t st) {
-  constexpr int AM = OCC == 1 ? kAccelMax1 : kAccelMax2;
-  const acnqp::TiledLds L(NW, MT, CT, a.NP, a.K, AM, std::min(a.accel_mem, AM), (int)sizeof(real), a.pbuf_single);
-  const size_t lds = (size_t)L.total * sizeof(real);
-  auto kern = &acnqp::admm_tiled_kernel<real, NW, CT, MT, KS, OCC, AM>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(kern, dim3(a.B), dim3(NW * 64), lds, st, a);
-  return hipGetLastError();
-}
-
-// Two register budgets of the same kernel.  The 256-register build lets two workgroups share a CU
-// (the second hides the first one's dependent-chain latency, and problems of a second batch on another
-// stream can move in while stragglers finish); it is taken whenever it exists for the shape and the
-// requested Anderson ring fits half the LDS -- a function of the shape only, never of the batch size,
-// so that a problem's result does not depend on what it is batched with.
-template <typename real, int NW, int CT, int MT, int KS>
-hipError_t launch_tiled(acnqp::TiledArgs a, int requested_accel, hipStream_t st) {
-  int single = 0;
-  const int cap1 = accel_capacity_best<real>(NW, MT, CT, a.NP, a.K, &single);
-  a.accel_mem = std::min(requested_accel, cap1);
-  a.pbuf_single = 0;
-  if constexpr (CT == 1 && MT <= 2 && KS == 1) {
-    if (a.accel_mem <= accel_capacity<real>(NW, MT, CT, a.NP, a.K, 2))
-      return launch_tiled_occ<real, NW, CT, MT, KS, 2>(a, st);
-  }
-  a.pbuf_single = (a.accel_mem > accel_capacity<real>(NW, MT, CT, a.NP, a.K, 1, 0)) ? single : 0;
-  return launch_tiled_occ<real, NW, CT, MT, KS, 1>(a, st);
-}
-
-template <typename real, int NW, int CT, int MT>
-hipError_t launch_k(const acnqp::TiledArgs& a, hipStream_t st) {
-  if (a.K == 1) return launch_tiled<real, NW, CT, MT, 1>(a, a.accel_mem, st);
-  return launch_tiled<real, NW, CT, MT, acnqp::kMaxK>(a, a.accel_mem, st);
-}
-
-template <typename real, int NW, int CT>
-hipError_t launch_mt(const acnqp::TiledArgs& a, hipStream_t st) {
-  switch (a.MR / 16) {
-    case 1: return launch_k<real, NW, CT, 1>(a, st);
-    case 2: return launch_k<real, NW, CT, 2>(a, st);
-    default: return launch_k<real, NW, CT, 3>(a, st);
-  }
-}
-
-template <typename real>
-hipError_t launch_any(const acnqp::TiledArgs& a, int NW, hipStream_t st) {
-  const int CT = (a.Tm + 15) / 16;
-  (void)NW;   // N <= 64: four waves; wider sites take the general-shape kernel
-  return CT == 1 ? launch_mt<real, 4, 1>(a, st) : launch_mt<real, 4, 2>(a, st);
-}
-
 // shapes the register-resident tiled kernel takes; everything else runs through the general-shape kernel
 // Small problems with two column tiles AND two row tiles (horizon 17 ... 32 on a site of 17 ... 32 padded rows, e.g. the
 // synthetic JPL site at horizon 24 of configs[2]) run through the LDS-resident variant of the long-horizon kernel: the
@@ -383,131 +299,11 @@ static bool stream_shape(const acnqp_handle* h, int t_max) {
   return h->N > 64 && t_max <= 48 && !h->has_max;
 }
 
-template <int CT, int MT, int NWV>
-static hipError_t launch_stream_nwv(const acnqp::StreamArgs& sa, hipStream_t st) {
-  const acnqp::StreamLds L(MT, CT, NWV);
-  const size_t lds = (size_t)L.total * sizeof(double);
-  auto kern = &acnqp::admm_stream_kernel<CT, MT, NWV>;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
-  return hipGetLastError();
-}
-
-// 4 waves per problem and two problems per CU when the batch can fill the chip twice over (throughput), 8 waves per
-// problem otherwise (latency); same bits either way (acn_qp_stream.hpp)
-template <int CT, int MT>
-static hipError_t launch_stream_one(const acnqp::StreamArgs& sa, hipStream_t st) {
-  return sa.t.B >= 384 ? launch_stream_nwv<CT, MT, 4>(sa, st) : launch_stream_nwv<CT, MT, 8>(sa, st);
-}
-
-static hipError_t launch_stream(const acnqp::StreamArgs& sa, hipStream_t st) {
-  const int CT = (sa.t.Tm + 15) / 16, MT = sa.t.MR / 16;
-  switch (CT * 10 + MT) {
-    case 11: return launch_stream_one<1, 1>(sa, st);
-    case 12: return launch_stream_one<1, 2>(sa, st);
-    case 13: return launch_stream_one<1, 3>(sa, st);
-    case 21: return launch_stream_one<2, 1>(sa, st);
-    case 22: return launch_stream_one<2, 2>(sa, st);
-    case 23: return launch_stream_one<2, 3>(sa, st);
-    case 31: return launch_stream_one<3, 1>(sa, st);
-    case 32: return launch_stream_one<3, 2>(sa, st);
-    default: return launch_stream_one<3, 3>(sa, st);
-  }
-}
-
 // shapes the long-horizon MFMA kernel takes (acn_qp_long.hpp): what the two kernels above leave, up to 288 periods
 // and two row tiles, no demand-charge row
-static int long_tiles(int t_max) { return t_max <= 32 ? 2 : (t_max <= 96 ? 6 : (t_max <= 144 ? 9 : 18)); }
 static bool long_shape(const acnqp_handle* h, int t_max, int k_sessions) {
   if (std::getenv("ACNQP_NO_LONG")) return false;   // diagnostic: the general-shape kernel instead
   return !tiled_shape(h, t_max, k_sessions) && !stream_shape(h, t_max) && t_max <= 288 && h->dev64.MR <= 32;
-}
-
-template <int CTL, int MT>
-static hipError_t launch_long_one(const acnqp::StreamArgs& sa, hipStream_t st) {
-  // 8 waves per problem: 256 registers per lane hold a row item of any supported horizon without scratch (16 waves
-  // at 128 registers spilled ~230 of them and ran slower)
-  constexpr int NWV = 8;
-  const size_t lds = (size_t)2 * MT * CTL * 256 * sizeof(double);   // e^, h^
-  auto kern = &acnqp::admm_long_kernel<CTL, MT, NWV>;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
-  return hipGetLastError();
-}
-
-// r0 / zh in LDS when the array fits next to e^, h^ (acn_qp_long.hpp, RZL): <= 156 KB of dynamic LDS
-template <int CTL, int MT>
-static hipError_t launch_long_rzl(const acnqp::StreamArgs& sa, hipStream_t st) {
-  constexpr int NWV = 8;
-  const int NE = sa.t.NP / 16;
-  const size_t lds = (size_t)256 * CTL * (2 * MT + NE) * sizeof(double);
-  auto kern = &acnqp::admm_long_kernel<CTL, MT, NWV, false, true>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
-  return hipGetLastError();
-}
-// ... and x as well (horizons up to 96: 2 x 48 KB next to e^, h^)
-template <int MT>
-static hipError_t launch_long_xsl(const acnqp::StreamArgs& sa, hipStream_t st) {
-  constexpr int NWV = 8, CTL = 6;
-  const int NE = sa.t.NP / 16;
-  const size_t lds = (size_t)256 * CTL * (2 * MT + 2 * NE) * sizeof(double);
-  auto kern = &acnqp::admm_long_kernel<CTL, MT, NWV, false, true, true>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
-  return hipGetLastError();
-}
-static bool xsl_fits(int CTL, int MT, int NP) {
-  static const bool off = std::getenv("ACNQP_NO_XSL") != nullptr || std::getenv("ACNQP_NO_RZL") != nullptr;   // diagnostics
-  return !off && CTL == 6 && (size_t)256 * CTL * (2 * MT + 2 * (NP / 16)) * sizeof(double) <= (size_t)156 * 1024;
-}
-static bool rzl_fits(int CTL, int MT, int NP) {
-  static const bool off = std::getenv("ACNQP_NO_RZL") != nullptr;   // diagnostic: r0 / zh in the workspace
-  return !off && (CTL == 6 || CTL == 9) && (size_t)256 * CTL * (2 * MT + NP / 16) * sizeof(double) <= (size_t)156 * 1024;
-}
-
-template <int CTL, int MT>
-static hipError_t launch_long_lds(const acnqp::StreamArgs& sa, hipStream_t st) {
-  constexpr int NWV = 8;
-  const int NE = sa.t.NP / 16;
-  const size_t lds = (size_t)256 * CTL * (5 * MT + 7 * NE) * sizeof(double);   // e^, h^, site rows; 7 iterate arrays
-  auto kern = &acnqp::admm_long_kernel<CTL, MT, NWV, true>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
-  return hipGetLastError();
-}
-
-static hipError_t launch_long(const acnqp::StreamArgs& sa, hipStream_t st, bool lds_resident) {
-  const int CTL = long_tiles(sa.t.Tm), MT = sa.t.MR / 16;
-  if (lds_resident) return launch_long_lds<2, 2>(sa, st);   // lds_long_shape: two column tiles, two row tiles
-  if (xsl_fits(CTL, MT, sa.t.NP)) return MT == 1 ? launch_long_xsl<1>(sa, st) : launch_long_xsl<2>(sa, st);
-  if (rzl_fits(CTL, MT, sa.t.NP)) {
-    switch (CTL * 10 + MT) {
-      case 61: return launch_long_rzl<6, 1>(sa, st);
-      case 62: return launch_long_rzl<6, 2>(sa, st);
-      case 91: return launch_long_rzl<9, 1>(sa, st);
-      default: return launch_long_rzl<9, 2>(sa, st);
-    }
-  }
-  switch (CTL * 10 + MT) {
-    case 21: return launch_long_one<2, 1>(sa, st);
-    case 22: return launch_long_one<2, 2>(sa, st);
-    case 61: return launch_long_one<6, 1>(sa, st);
-    case 62: return launch_long_one<6, 2>(sa, st);
-    case 91: return launch_long_one<9, 1>(sa, st);
-    case 92: return launch_long_one<9, 2>(sa, st);
-    case 181: return launch_long_one<18, 1>(sa, st);
-    default: return launch_long_one<18, 2>(sa, st);
-  }
 }
 
 }  // namespace
@@ -577,7 +373,7 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
     acnqp_destroy(h);
     return fail(ACNQP_ERR_HIP, msg);
   }
-  int rc = build_site_dev<double>(h, &h->dev64);   // the fp32 copy is built on first use
+  int rc = build_site_dev(h, &h->dev64);
   if (rc != ACNQP_OK) { acnqp_destroy(h); return rc; }
   *out = h;
   return ACNQP_OK;
@@ -587,7 +383,6 @@ void acnqp_destroy(acnqp_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   h->dev64.release();
-  h->dev32.release();
   for (int k = 0; k < acnqp_handle::kEvRing; ++k) {
     if (h->ev_start[k]) (void)hipEventDestroy(h->ev_start[k]);
     if (h->ev_stop[k]) (void)hipEventDestroy(h->ev_stop[k]);
@@ -676,7 +471,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   } else if (lng) {
     // long-horizon kernel: same workspace idea, one more array (r0 / zh)
     a.accel_mem = std::min(a.accel_mem, acnqp::kLongAccelMax);
-    sa.ws_per_problem = acnqp::long_workspace(h->NP, long_tiles(p->t_max), p->k_sessions, d->MR / 16, a.accel_mem);
+    sa.ws_per_problem = acnqp::long_workspace(h->NP, acnqp::long_tiles(p->t_max), p->k_sessions, d->MR / 16, a.accel_mem);
     DevBuf* wsb = h->workspace_for(st);
     const size_t need = (size_t)sa.ws_per_problem * p->batch * sizeof(double);
     if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));
@@ -706,23 +501,16 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   HIP_TRY(hipEventRecord(h->ev_start[evk], st));
   hipError_t e = hipSuccess;
   if (tiled) {
-    e = launch_any<double>(a, h->NW, st);
+    e = p->t_max <= 16 ? acnqp::launch_tiled_ct1(a, st) : acnqp::launch_tiled_ct2(a, st);
   } else if (stream) {
-    e = launch_stream(sa, st);
+    e = acnqp::launch_stream(sa, st);
   } else if (lng) {
-    e = launch_long(sa, st, lds_long_shape(h, p->t_max));
+    e = acnqp::launch_long(sa, st, lds_long_shape(h, p->t_max));
   } else {
     // workgroup size by problem size: the plain loops are latency-bound, more threads per problem hide more of it
     const long long nvar = (long long)h->N * p->t_max;
     const int nt = nvar <= 4096 ? 256 : (nvar <= 12288 ? 512 : 1024);
-    auto launch_general = [&](auto real_tag) {
-      using real = decltype(real_tag);
-      if (nt == 256) hipLaunchKernelGGL((acnqp::admm_general_kernel<real, 256>), dim3(a.B), dim3(256), 0, st, ga);
-      else if (nt == 512) hipLaunchKernelGGL((acnqp::admm_general_kernel<real, 512>), dim3(a.B), dim3(512), 0, st, ga);
-      else hipLaunchKernelGGL((acnqp::admm_general_kernel<real, 1024>), dim3(a.B), dim3(1024), 0, st, ga);
-    };
-    launch_general(double{});
-    e = hipGetLastError();
+    e = acnqp::launch_general(ga, nt, st);
   }
   if (e != hipSuccess) return fail(ACNQP_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   HIP_TRY(hipEventRecord(h->ev_stop[evk], st));
@@ -741,7 +529,7 @@ int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, 
   SiteDev* d = &h->dev64;
   const int CT = (t_max + 15) / 16, MT = d->MR / 16;
   int single = 0;
-  return std::min(requested, accel_capacity_best<double>(4, MT, CT, h->NP, k_sessions, &single));
+  return std::min(requested, acnqp::accel_capacity_best(4, MT, CT, h->NP, k_sessions, &single));
 }
 
 static float event_pair_ms(acnqp_handle* h, long long launch) {

@@ -1,0 +1,50 @@
+// Host-side launchers of the four kernel families.  Each family is instantiated in its own translation unit
+// (acn_qp_tiled_ct1.hip, acn_qp_tiled_ct2.hip, acn_qp_stream.hip, acn_qp_long.hip, acn_qp_general.hip) so that
+// adacharge_amd/build.py compiles them in parallel; acn_qp_api.hip (the C ABI) only sees these declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "acn_qp_tiled.hpp"
+#include "acn_qp_general.hpp"
+#include "acn_qp_stream.hpp"
+#include "acn_qp_long.hpp"
+
+namespace acnqp {
+
+// LDS one workgroup may use: the whole CU when alone, half of it when two share the CU
+constexpr int kLdsPerCu = 160 * 1024;
+constexpr int kAccelMax1 = 5, kAccelMax2 = 5;   // Anderson columns compiled into the OCC = 1 / OCC = 2 variants
+
+// Anderson columns that fit next to the solver's own LDS for this kernel shape with `occ` workgroups per CU
+inline int accel_capacity(int NW, int MT, int CT, int NP, int K, int occ, int pbuf_single = 0) {
+  const TiledLds base(NW, MT, CT, NP, K, occ == 1 ? kAccelMax1 : kAccelMax2, 1, 8, pbuf_single);
+  const int col = TiledLds::column_bytes(NW, MT, CT);
+  const int fixed = base.total * 8 - col;
+  const int cap = (kLdsPerCu / occ - fixed - 64) / col;
+  return std::max(0, std::min(cap, occ == 1 ? kAccelMax1 : kAccelMax2));
+}
+
+// One workgroup per CU: if the double-buffered partial-tile slab leaves fewer than the compiled-in number of ring
+// columns, give one slab up (one more barrier per iteration buys a column: on the congested horizon-24 problems a
+// fourth / fifth column is worth 5x fewer iterations on the slowest instances)
+inline int accel_capacity_best(int NW, int MT, int CT, int NP, int K, int* pbuf_single) {
+  const int two = accel_capacity(NW, MT, CT, NP, K, 1, 0);
+  const int one = accel_capacity(NW, MT, CT, NP, K, 1, 1);
+  *pbuf_single = one > two ? 1 : 0;
+  return std::max(one, two);
+}
+
+// register-resident kernel (acn_qp_tiled.hpp): N <= 64, one / two column tiles; a.accel_mem = columns requested
+hipError_t launch_tiled_ct1(const TiledArgs& a, hipStream_t st);
+hipError_t launch_tiled_ct2(const TiledArgs& a, hipStream_t st);
+// large-site kernel (acn_qp_stream.hpp)
+hipError_t launch_stream(const StreamArgs& sa, hipStream_t st);
+// long-horizon kernel (acn_qp_long.hpp); lds_resident: its LDS-resident variant for two column tiles x two row tiles
+int long_tiles(int t_max);
+hipError_t launch_long(const StreamArgs& sa, hipStream_t st, bool lds_resident);
+// general-shape kernel (acn_qp_general.hpp), `threads` in {256, 512, 1024}
+hipError_t launch_general(const GeneralArgs& ga, int threads, hipStream_t st);
+
+}  // namespace acnqp

@@ -1,0 +1,14 @@
+// Register-resident kernel, one column tile (horizons <= 16): instantiations and launcher.
+#include "acn_qp_tiled_launch.hpp"
+
+namespace acnqp {
+
+hipError_t launch_tiled_ct1(const TiledArgs& a, hipStream_t st) {
+  switch (a.MR / 16) {
+    case 1: return launch_k<4, 1, 1>(a, st);
+    case 2: return launch_k<4, 1, 2>(a, st);
+    default: return launch_k<4, 1, 3>(a, st);
+  }
+}
+
+}  // namespace acnqp
