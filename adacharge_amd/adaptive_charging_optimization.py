@@ -194,9 +194,10 @@ class AdaptiveChargingOptimization:
             HIP ADMM backend.  Backend options go in ``solver_options``.
         solver_options (dict): overrides of ``acnqp_options`` fields
             (eps_abs, eps_rel, max_iter, rho, reg_rel, precision, ...), plus
-            ``retry_stalled`` (default True): problems the adaptive first
-            pass leaves on a residual plateau are solved once more from a
-            cold start with a fixed penalty (``backend.SiteHandle.solve``).
+            ``retry_stalled`` (default True; False = ``retry_passes=0``):
+            problems the adaptive first pass leaves on a residual plateau
+            are solved again from a cold start with a fixed penalty, inside
+            the library (``acnqp_options.retry_passes``, include/acn_qp.h).
         device (int): HIP device ordinal.
     """
 
@@ -373,8 +374,9 @@ class AdaptiveChargingOptimization:
                     T = min(batch.Tm, x0.shape[1], y0.shape[1])
                     wx[b, :, :T], wy[b, :, :T] = x0[:, :T], y0[:, :T]
             warm = (wx, wy)
-        retry = bool(opts.pop("retry_stalled", True))   # not an acnqp_options field: second pass for stalled problems
-        res = handle.solve(batch, backend.default_options(**opts), warm=warm, want_y=True, retry_stalled=retry)
+        if not bool(opts.pop("retry_stalled", True)):   # shorthand kept from round 2: the passes live in the library now
+            opts["retry_passes"] = 0
+        res = handle.solve(batch, backend.default_options(**opts), warm=warm, want_y=True)
         self.last_result = res
         self.last_batch = batch   # the structured problems behind last_result (diagnostics, tests)
         return res, batch

@@ -106,6 +106,12 @@ class Options(C.Structure):
         ("reg_rel", C.c_double),
         ("precision", C.c_int32),
         ("accel_mem", C.c_int32),
+        ("stall_iters", C.c_int32),
+        ("retry_passes", C.c_int32),
+        ("retry_max_iter", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("retry_rho", C.c_double),
+        ("inaccurate_floor", C.c_double),
     ]
 
 
@@ -124,6 +130,7 @@ EXPORTED_SYMBOLS = (
     "acnqp_solve_batches",
     "acnqp_host_alloc",
     "acnqp_host_free",
+    "acnqp_launch_count",
 )
 
 _lib = None
@@ -183,6 +190,8 @@ def load_library():
     lib.acnqp_host_alloc.restype = C.c_void_p
     lib.acnqp_host_free.argtypes = [C.c_void_p]
     lib.acnqp_host_free.restype = None
+    lib.acnqp_launch_count.argtypes = [C.c_void_p]
+    lib.acnqp_launch_count.restype = C.c_int64
     _lib = lib
     return lib
 
@@ -274,6 +283,7 @@ class SiteHandle:
         h = C.c_void_p()
         _check(self._lib.acnqp_create(C.byref(desc), self.device, C.byref(h)), "acnqp_create")
         self._h = h
+        self._launches_seen = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -345,55 +355,21 @@ class SiteHandle:
         return res
 
     def solve(self, batch: ProblemBatch, options: Optional[Options] = None, pinned_results: bool = False,
-              warm=None, want_y: bool = False, retry_stalled: bool = False) -> BatchResult:
+              warm=None, want_y: bool = False) -> BatchResult:
         """acnqp_solve_batch: one batch, host buffers in and out, synchronous (pipelined in chunks inside).
         ``warm = (x0, y0)``: optional warm start (an earlier schedule (B, N, Tm) and its ``BatchResult.y`` (B, Mg, Tm),
         shifted by the caller); ``want_y``: also return the site-row multipliers ``y`` for a later warm start.
-        ``retry_stalled``: problems the first pass leaves SOLVED_INACCURATE / MAX_ITER are solved once more from a cold
-        start with a FIXED penalty (see ``_retry_stalled``)."""
+        Problems a pass leaves SOLVED_INACCURATE / MAX_ITER on a plateau are re-solved inside the library
+        (``options.retry_passes``, include/acn_qp.h) -- every entry point behaves the same."""
         self._check_site(batch)
         o = options if options is not None else default_options()
         p, r, res, keep = self._marshal(batch, pinned_results, warm=warm, want_y=want_y)
         self.kernel_times()   # forget earlier launches: kernel_ms below is the sum over THIS call's launches (chunks)
+        self._launches_seen = int(self._lib.acnqp_launch_count(self._h))
         _check(self._lib.acnqp_solve_batch(self._h, C.byref(p), C.byref(o), C.byref(r)), "acnqp_solve_batch")
         del keep
-        res.kernel_ms = float(sum(self.kernel_times()))
-        if retry_stalled and o.adapt_every > 0:
-            self._retry_stalled(batch, o, res, want_y)
+        res.kernel_ms = self._kernel_ms_of_call()
         return self._finish(batch, res)
-
-    # Second pass for stalled problems.  Traced on the C twin (DESIGN.md section 2): the congested instances that sit on
-    # a plateau of the primal residual do so because the penalty adaptation keeps kicking them (rho swings by 10x in the
-    # first hundreds of iterations and the iterate ends in a region it leaves only sub-linearly); from a cold start
-    # with ANY fixed rho in [0.3, 4] every one of them converges in 900 ... 4,400 iterations -- while a fixed rho from
-    # the start would double the iterations of the average problem.  So: adaptive first, fixed-rho retry for the few
-    # that stall.  A retry that does not reach SOLVED leaves the first answer in place.
-    RETRY_RHO = 0.5
-    RETRY_MAX_ITER = 8000
-    RETRY_MIN_ITERS = 3000   # = kStallIters of the kernels
-
-    def _retry_stalled(self, batch: ProblemBatch, o: Options, res: "BatchResult", want_y: bool) -> None:
-        # a problem that stopped before the stall window could have elapsed hit the caller's max_iter: not retried
-        bad = np.flatnonzero(((res.status == STATUS_SOLVED_INACCURATE) | (res.status == STATUS_MAX_ITER))
-                             & (res.iters >= self.RETRY_MIN_ITERS))
-        if bad.size == 0:
-            return
-        o2 = Options.from_buffer_copy(o)
-        o2.rho = self.RETRY_RHO
-        o2.adapt_every = 0
-        o2.max_iter = min(int(o.max_iter), self.RETRY_MAX_ITER)
-        sub = batch.subset(bad)
-        p, r, res2, keep = self._marshal(sub, False, want_y=want_y)
-        _check(self._lib.acnqp_solve_batch(self._h, C.byref(p), C.byref(o2), C.byref(r)), "acnqp_solve_batch (retry)")
-        del keep
-        res.kernel_ms += float(sum(self.kernel_times()))
-        res.iters[bad] += res2.iters
-        won = res2.status == STATUS_SOLVED
-        idx = bad[won]
-        for name in ("x", "status", "pri_res", "dua_res", "obj"):
-            getattr(res, name)[idx] = getattr(res2, name)[won]
-        if want_y and res.y is not None:
-            res.y[idx] = res2.y[won]
 
     def solve_many(self, batches, options: Optional[Options] = None, pinned_results: bool = True):
         """acnqp_solve_batches: several independent batches in ONE pipelined pass (shared launches, overlapped
@@ -450,6 +426,18 @@ class SiteHandle:
             self._lib.acnqp_solve_batch_device(self._h, C.byref(p), C.byref(o), C.byref(r), C.c_void_p(stream)),
             "acnqp_solve_batch_device",
         )
+
+    def _kernel_ms_of_call(self) -> float:
+        """Sum of the HIP-event durations of the launches since the previous ``kernel_times`` call; NaN when an event
+        could not be read or when the call made more launches than the library's 64-entry event ring holds (the sum
+        would silently under-report)."""
+        before = int(self._lib.acnqp_launch_count(self._h))
+        ms = self.kernel_times()
+        if any(m < 0 for m in ms) or before - self._launches_seen > len(ms):
+            self._launches_seen = before
+            return float("nan")
+        self._launches_seen = before
+        return float(sum(ms))
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.acnqp_last_kernel_ms(self._h))

@@ -328,6 +328,12 @@ void acnqp_default_options(acnqp_options* o) {
   o->reg_rel = 0.06;
   o->precision = 64;
   o->accel_mem = 5;
+  o->stall_iters = 3000;
+  o->retry_passes = 2;
+  o->retry_max_iter = 8000;
+  o->reserved_ = 0;
+  o->retry_rho = 0.5;
+  o->inaccurate_floor = 1e-5;
 }
 
 int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) {
@@ -416,7 +422,8 @@ static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, 
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: null result array");
   if (!(o->eps_abs >= 0) || !(o->eps_rel >= 0) || o->max_iter < 1 || o->check_every < 1 || !(o->rho > 0) ||
       !(o->sigma >= 0) || !(o->alpha > 0 && o->alpha < 2) || !(o->adapt_tol > 1) || !(o->reg_rel >= 0) ||
-      o->adapt_every < 0)
+      o->adapt_every < 0 || o->stall_iters < 0 || o->retry_passes < 0 || o->retry_passes > 8 || o->retry_max_iter < 1 ||
+      !(o->retry_rho > 0) || !(o->inaccurate_floor >= 0))
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: invalid option value");
   if (o->precision != 64)
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: precision must be 64 (the fp32 loop was removed: it missed the "
@@ -451,6 +458,8 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.max_iter = o->max_iter; a.check_every = o->check_every; a.adapt_every = o->adapt_every;
   a.peak_scale = d->peak_scale; a.flat_scale = d->flat_scale; a.max_scale = d->max_scale;
   a.accel_mem = std::max(0, o->accel_mem);
+  a.stall_iters = o->stall_iters; a.retry_passes = o->retry_passes; a.retry_max_iter = o->retry_max_iter;
+  a.retry_rho = o->retry_rho; a.inacc_floor = o->inaccurate_floor;
   a.pbuf_single = 0;
   const bool tiled = tiled_shape(h, p->t_max, p->k_sessions);
   const bool stream = !tiled && stream_shape(h, p->t_max);
@@ -539,6 +548,8 @@ static float event_pair_ms(acnqp_handle* h, long long launch) {
   if (hipEventElapsedTime(&ms, h->ev_start[k], h->ev_stop[k]) != hipSuccess) return -1.0f;
   return ms;
 }
+
+int64_t acnqp_launch_count(acnqp_handle* h) { return h ? (int64_t)h->launches : 0; }
 
 float acnqp_last_kernel_ms(acnqp_handle* h) {
   if (!h || h->launches == 0) return -1.0f;

@@ -46,11 +46,29 @@ __device__ inline real block_reduce_sum(real v, real* red, int tid) {
 }
 
 template <typename real, int kGenThreads>
-__global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const GeneralArgs GA) {
+__global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const GeneralArgs SA_kernarg) {
   using M = Mfma<real>;
-  const TiledArgs& A = GA.t;
   __shared__ real red[kGenThreads / 64];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ real aaH[kGenAccelMax * kGenAccelMax + kGenAccelMax];
+  __shared__ real aaG[kGenAccelMax];
+  // passes: pass 0 as the options state it, then cold fixed-penalty retries of a stalled problem (retry_wanted,
+  // acn_qp_tiled.hpp).  The WHOLE body is the pass, with the thread / block ids opaque and the argument block read
+  // through a per-pass opaque pointer to the kernarg segment: nothing of a pass is invariant across passes, so no
+  // pass-invariant address, predicate or argument is kept alive across the solver loop.
+  int it_total = 0, best_status = 0;
+  for (int pass = 0;; ++pass) {
+  typedef const __attribute__((address_space(4))) GeneralArgs* KernargP;
+  KernargP SAp = (KernargP)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(SAp));
+  const auto& GA = *SAp;
+  (void)SA_kernarg;
+  const auto& A = GA.t;
+  int b_ = blockIdx.x, tid = threadIdx.x;
+  asm volatile("" : "+v"(b_));
+  asm volatile("" : "+v"(tid));
+  const int b = __builtin_amdgcn_readfirstlane(b_);
+  const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
+  const int adapt_p = pass == 0 ? A.adapt_every : 0;
   const int N = A.N, T = A.Tm, NP = A.NP, MR = A.MR, K = A.K;
   const int n = N * T, mt = MR * T;
   real* W0 = static_cast<real*>(GA.work) + (size_t)b * GA.ws_per_problem;
@@ -70,8 +88,6 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   float* cprev = reinterpret_cast<float*>(fprev + D);
   float* ringF = cprev + D;
   float* ringG = ringF + (size_t)aa_m * D;
-  __shared__ real aaH[kGenAccelMax * kGenAccelMax + kGenAccelMax];
-  __shared__ real aaG[kGenAccelMax];
   const real* Gm = static_cast<const real*>(A.G);
   const real* Gh = static_cast<const real*>(A.Ghat);
   const real* Qm = static_cast<const real*>(A.Q);
@@ -123,11 +139,17 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
                                         (A.lf != nullptr && (real)A.lf[b] > (real)0) || dc_on);
   if (anybad > 0) {
     for (int k = tid; k < n; k += kGenThreads) A.x[(size_t)b * n + k] = 0;
+    if (A.y_out)
+      for (int k = tid; k < A.Mg * T; k += kGenThreads) A.y_out[(size_t)b * A.Mg * T + k] = 0;
     if (tid == 0) { A.status[b] = 4; A.iters[b] = 0; A.pri[b] = (double)M::big; A.dua[b] = (double)M::big; A.obj[b] = 0; }
     return;
   }
   const real sigma = (real)A.sigma, alpha = (real)A.alpha;
   real rho = (real)A.rho0;
+  if (pass > 0) {   // fixed penalty retry_rho * 4^(pass - 1)
+    rho = (real)A.retry_rho;
+    for (int k = 1; k < pass; ++k) rho *= (real)4;
+  }
   int status = 2, it = 0, n_adapt = 0, best_it = 0;
   real best_score = M::big;
   real pri = M::big, dua = M::big;
@@ -182,7 +204,7 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   // y1 = -(q + pd z1), z2 = G z1, y2 = 0
   // Warm start (optional; see acn_qp_tiled.hpp): z1 = Proj_B(warm_x), y2 = warm_y (caller's row order and units),
   // y1 = -(q + pd z1 + G' y2)
-  const bool warm = A.warm_x != nullptr && A.warm_y != nullptr;
+  const bool warm = pass == 0 && A.warm_x != nullptr && A.warm_y != nullptr;
   for (int k = tid; k < n; k += kGenThreads) {
     zh[k] = warm ? (real)A.warm_x[(size_t)b * n + k] : -(real)kStartGain * (real)qg[k];
     z1[k] = fmin(fmax(zh[k], (real)lbg[k]), ub[k]);
@@ -257,7 +279,7 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
       zh2[k] = alpha * zt + ((real)1 - alpha) * z2[k] + y2[k] * inv_rho;
     }
     __syncthreads();
-    const bool check = (it % A.check_every == 0) || it >= A.max_iter;
+    const bool check = (it % A.check_every == 0) || it >= max_iter_p;
     // ---- Anderson acceleration event (see acn_qp_tiled.hpp; u = (zh, zh2), block-uniform control flow) --------
     if (aa_m > 0 && it % kAaPeriod == 0) {
       auto g_at = [&](int k) -> real& { return k < n ? zh[k] : zh2[k - n]; };
@@ -509,14 +531,14 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
       const real score = fmax(pri / fmax((real)A.eps_abs + (real)A.eps_rel * npri, (real)1e-300),
                               dua / fmax((real)A.eps_abs + (real)A.eps_rel * ndua, (real)1e-300));
       if (score < (real)kStallGain * best_score) { best_score = score; best_it = it; }
-      const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel);
-      const bool stalled = it - best_it >= kStallIters && score <= (real)kStallNear * best_score;   // acn_qp_tiled.hpp
+      const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel, A.inacc_floor);
+      const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= (real)kStallNear * best_score;   // acn_qp_tiled.hpp
       if (done) {
-      } else if (it >= A.max_iter || stalled) {
+      } else if (it >= max_iter_p || stalled) {
         done = true;
         if (inacc) status = 5;   // solved, inaccurately
       }
-      else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
+      else if (adapt_p > 0 && it % adapt_p == 0) {
         const real sp = pri / fmax(npri, (real)1e-12), sd = dua / fmax(ndua, (real)1e-12);
         const real ratio = sqrt(sp / fmax(sd, (real)1e-30));
         const real tol_eff = (real)A.adapt_tol * ((real)1 + (real)n_adapt * (real)(1.0 / kAdaptWiden));
@@ -540,6 +562,10 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
       __syncthreads();
     }
   }
+  it_total += it;
+  __syncthreads();
+  if (pass == 0 || status_rank(status) > status_rank(best_status)) {   // block-uniform: this pass beats the earlier ones
+  best_status = status;
   real ol = 0;
   for (int k = tid; k < n; k += kGenThreads) {
     A.x[(size_t)b * n + k] = (double)z1[k];
@@ -558,8 +584,13 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   if (tid == 0) {
     real o = 0;
     for (int wv = 0; wv < kGenThreads / 64; ++wv) o += red[wv];
-    A.status[b] = status; A.iters[b] = it; A.pri[b] = (double)pri; A.dua[b] = (double)dua; A.obj[b] = (double)o;
+    A.status[b] = status; A.pri[b] = (double)pri; A.dua[b] = (double)dua; A.obj[b] = (double)o;
   }
+  }
+  if (tid == 0) A.iters[b] = it_total;
+  if (!retry_wanted(pass, A.retry_passes, status, it, A.stall_iters, A.adapt_every)) break;
+  __syncthreads();
+  }   // passes
 }
 
 }  // namespace acnqp

@@ -79,11 +79,10 @@ __host__ __device__ inline long long long_workspace(int NP, int CTL, int K, int 
 // both phases, 5 of 15) -- for problems whose one array fits next to e^, h^ (54 x 144: 72 + 18 KB).
 // XSL (with RZL): x too (3 passes) -- horizons up to 96 on a 64-EVSE site.
 template <int CTL, int MT, int NWV, bool LDSR = false, bool RZL = false, bool XSL = false>
-__global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs SA) {
+__global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs SA_kernarg) {
   using M = Mfma<double>;
   using vec4 = M::vec4;
   typedef double real;
-  const TiledArgs& A = SA.t;
   constexpr int AMX = kLongAccelMax;
   __shared__ real SC[NWV * 8 + 8];
   __shared__ real AaRedS[NWV * (AMX + 2)];
@@ -94,7 +93,24 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   real* EH = reinterpret_cast<real*>(smem_raw);   // e^ [MT][CTL][4][64]
   real* HH = EH + MT * CTL * 256;                 // h^ (start: Ghat z1)
 
-  const int b = blockIdx.x, tid = threadIdx.x;
+  // passes: pass 0 as the options state it, then cold fixed-penalty retries of a stalled problem (retry_wanted,
+  // acn_qp_tiled.hpp).  The WHOLE body is the pass, with the thread / block ids opaque and the argument block read
+  // through a per-pass opaque pointer to the kernarg segment: nothing of a pass is invariant across passes, so no
+  // pass-invariant address, predicate or argument is kept alive across the solver loop.
+  int it_total = 0, best_status = 0;
+  for (int pass = 0;; ++pass) {
+  typedef const __attribute__((address_space(4))) StreamArgs* KernargP;
+  KernargP SAp = (KernargP)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(SAp));
+  const auto& SA = *SAp;
+  (void)SA_kernarg;
+  const auto& A = SA.t;
+  int b_ = blockIdx.x, tid = threadIdx.x;
+  asm volatile("" : "+v"(b_));
+  asm volatile("" : "+v"(tid));
+  const int b = __builtin_amdgcn_readfirstlane(b_);
+  const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
+  const int adapt_p = pass == 0 ? A.adapt_every : 0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int lane = tid & 63;
   int g = lane >> 4, t = lane & 15;
@@ -279,12 +295,18 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     pd = effective_pdiag<real>(pd_user, A.reg_rel, qnorm, f[1], A.horizon[b], lfb > 0.0 || dcb > 0.0);
     if (f[2] > 0) {
       for (size_t k = tid; k < (size_t)N * Tm; k += NWV * 64) A.x[(size_t)b * N * Tm + k] = 0;
+      if (A.y_out)
+        for (size_t k = tid; k < (size_t)A.Mg * Tm; k += NWV * 64) A.y_out[(size_t)b * A.Mg * Tm + k] = 0;
       if (tid == 0) { A.status[b] = 4; A.iters[b] = 0; A.pri[b] = M::big; A.dua[b] = M::big; A.obj[b] = 0; }
       return;
     }
   }
 
   real rho = A.rho0;
+  if (pass > 0) {   // fixed penalty retry_rho * 4^(pass - 1)
+    rho = A.retry_rho;
+    for (int k = 1; k < pass; ++k) rho *= 4.0;
+  }
 
   // ---- projection of ONE register row (EVSE 16 e + rowof(g, r): its periods are the 16 lanes of a DPP row times the
   // CTL column registers) onto B = box + energy rows: the safeguarded Newton of the other kernels / the C port ------
@@ -494,7 +516,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
 
   // ---- start (see acn_qp_tiled.hpp): z1 = Proj_B(-kStartGain q), x = z1, y1 = -(q + pd z1); z2 = G z1 = Q (Ghat z1);
   // warm (optional): z1 = Proj_B(warm_x), y2 = warm_y, y1 = -(q + pd z1 + G' y2) -------------------------------------
-  const bool warm = A.warm_x != nullptr && A.warm_y != nullptr;
+#ifdef ACNQP_STAMPS
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
+  const bool warm = pass == 0 && A.warm_x != nullptr && A.warm_y != nullptr;
 #pragma unroll 1
   for (int ri = wave; ri < 4 * NE; ri += NWV) {
     RELANE();
@@ -589,16 +615,12 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   real fn_prev = 0;
   if (aa_m > 0)
     for (int k = lane; k < AMX * AMX + AMX; k += 64) AaH[k] = 0;
-#ifdef ACNQP_STAMPS
-  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
-#endif
 #pragma unroll 1
   while (!done) {
     ++it;
     const real a = sigma + pd + rho, inv_a = 1.0 / a, inv_rho = 1.0 / rho;
     const real quad = rho / (rho + lfb);
-    const bool check = (it % A.check_every == 0) || it >= A.max_iter;
+    const bool check = (it % A.check_every == 0) || it >= max_iter_p;
     // an offset the compiler cannot see through keeps the loads of loop-invariant site data inside the loop (L1 / L2
     // hits) instead of pinning registers across it
     unsigned zoff = 0;
@@ -1106,13 +1128,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       }
       const real score = fmax(pri / fmax(eps_p, 1e-300), dua / fmax(eps_d, 1e-300));
       if (score < kStallGain * best_score) { best_score = score; best_it = it; }
-      const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel);
-      const bool stalled = it - best_it >= kStallIters && score <= kStallNear * best_score;   // acn_qp_tiled.hpp
+      const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel, A.inacc_floor);
+      const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= kStallNear * best_score;   // acn_qp_tiled.hpp
       if (done) {
-      } else if (it >= A.max_iter || stalled) {
+      } else if (it >= max_iter_p || stalled) {
         done = true;
         if (inacc) status = 5;
-      } else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
+      } else if (adapt_p > 0 && it % adapt_p == 0) {
         const real sp = pri / fmax(npri, 1e-12), sd = dua / fmax(ndua, 1e-12);
         const real ratio = sqrt(sp / fmax(sd, 1e-30));
         const real tol_eff = A.adapt_tol * (1.0 + (real)n_adapt * (1.0 / kAdaptWiden));
@@ -1138,12 +1160,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     }
     STAMP(8);   // residual check (amortised)
   }
-#ifdef ACNQP_STAMPS
-  if (lane == 0 && b < 1024 && wave < 16)
-    for (int k = 0; k < 12; ++k) g_stamps[(b * 16 + wave) * 12 + k] = st_acc[k];
-#endif
-
-  // ---- results: the feasible iterate z1 is the schedule --------------------------------------------------------
+  // ---- results of this pass: the feasible iterate z1 is the schedule (kept if it beats the earlier passes) ------
+  it_total += it;
+  __syncthreads();
+  if (pass == 0 || status_rank(status) > status_rank(best_status)) {   // block-uniform
+  best_status = status;
   real ol = 0;
 #pragma unroll 1
   for (int q = wave; q < n_tile; q += NWV) {
@@ -1180,8 +1201,17 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   if (tid == 0) {
     real o = 0;
     for (int wv = 0; wv < NWV; ++wv) o += SC[wv];
-    A.status[b] = status; A.iters[b] = it; A.pri[b] = pri; A.dua[b] = dua; A.obj[b] = o;
+    A.status[b] = status; A.pri[b] = pri; A.dua[b] = dua; A.obj[b] = o;
   }
+  }
+  if (tid == 0) A.iters[b] = it_total;
+#ifdef ACNQP_STAMPS
+  if (lane == 0 && b < 1024 && wave < 16)
+    for (int k = 0; k < 12; ++k) g_stamps[(b * 16 + wave) * 12 + k] = st_acc[k];
+#endif
+  if (!retry_wanted(pass, A.retry_passes, status, it, A.stall_iters, A.adapt_every)) break;
+  __syncthreads();
+  }   // passes
 }
 
 #undef RELANE

@@ -78,12 +78,11 @@ __device__ inline void stream_block_max(double (&v)[NV], double* S, int lane, in
 }
 
 template <int CT, int MT, int NWV>
-__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel(const StreamArgs SA) {
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel(const StreamArgs SA_kernarg) {
   constexpr int kStreamWaves = NWV;
   using M = Mfma<double>;
   using vec4 = M::vec4;
   typedef double real;
-  const TiledArgs& A = SA.t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   real* sm = reinterpret_cast<real*>(smem_raw);
   const StreamLds L(MT, CT, NWV);
@@ -92,7 +91,24 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   real* WE = sm + L.we;
   real* SC = sm + L.scal;
 
-  const int b = blockIdx.x, tid = threadIdx.x;
+  // passes: pass 0 as the options state it, then cold fixed-penalty retries of a stalled problem (retry_wanted,
+  // acn_qp_tiled.hpp).  The WHOLE body is the pass, with the thread / block ids opaque and the argument block read
+  // through a per-pass opaque pointer to the kernarg segment: nothing of a pass is invariant across passes, so no
+  // pass-invariant address, predicate or argument is kept alive across the solver loop.
+  int it_total = 0, best_status = 0;
+  for (int pass = 0;; ++pass) {
+  typedef const __attribute__((address_space(4))) StreamArgs* KernargP;
+  KernargP SAp = (KernargP)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(SAp));
+  const auto& SA = *SAp;
+  (void)SA_kernarg;
+  const auto& A = SA.t;
+  int b_ = blockIdx.x, tid = threadIdx.x;
+  asm volatile("" : "+v"(b_));
+  asm volatile("" : "+v"(tid));
+  const int b = __builtin_amdgcn_readfirstlane(b_);
+  const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
+  const int adapt_p = pass == 0 ? A.adapt_every : 0;
   // wave index as a scalar: tile bases become SGPR addresses (global_load saddr + lane offset) instead of one 64-bit
   // VGPR address per array, column tile and register
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -176,12 +192,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
     pd = effective_pdiag<real>(pd_user, A.reg_rel, qnorm, f[1], A.horizon[b], lfb > 0.0);
     if (f[2] > 0) {
       for (size_t k = tid; k < (size_t)N * Tm; k += kStreamWaves * 64) A.x[(size_t)b * N * Tm + k] = 0;
+      if (A.y_out)
+        for (size_t k = tid; k < (size_t)A.Mg * Tm; k += kStreamWaves * 64) A.y_out[(size_t)b * A.Mg * Tm + k] = 0;
       if (tid == 0) { A.status[b] = 4; A.iters[b] = 0; A.pri[b] = M::big; A.dua[b] = M::big; A.obj[b] = 0; }
       return;
     }
   }
 
   real rho = A.rho0;
+  if (pass > 0) {   // fixed penalty retry_rho * 4^(pass - 1)
+    rho = A.retry_rho;
+    for (int k = 1; k < pass; ++k) rho *= 4.0;
+  }
   // P = Ghat r0 (or Ghat z1 during the start): this wave's accumulators for the output tiles (m, c) it owns
   // wave m (< MT) owns the output tiles (m, c) of all column tiles c: a Ghat fragment is then fetched once per
   // iteration and row tile, not once per column tile as well (the fragments are the only re-read data of the kernel)
@@ -318,7 +340,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
 
   // ---- start (see acn_qp_tiled.hpp): z1 = Proj_B(-kStartGain q), x = z1, y1 = -(q + pd z1); z2 = G z1 = Q (Ghat z1);
   // warm (optional): z1 = Proj_B(warm_x), y2 = warm_y, y1 = -(q + pd z1 + G' y2) -------------------------------------
-  const bool warm = A.warm_x != nullptr && A.warm_y != nullptr;
+  const bool warm = pass == 0 && A.warm_x != nullptr && A.warm_y != nullptr;
   zero_pown();
 #pragma unroll 1
   for (int rd = 0; rd < n_rounds; ++rd) {
@@ -417,7 +439,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   while (!done) {
     ++it;
     const real a = sigma + pd + rho, inv_a = 1.0 / a, inv_rho = 1.0 / rho;
-    const bool check = (it % A.check_every == 0) || it >= A.max_iter;
+    const bool check = (it % A.check_every == 0) || it >= max_iter_p;
     // an offset the compiler cannot see through keeps the loads of loop-invariant site data (Q fragments, row
     // constants) inside the loop, where they hit L1 / L2, instead of pinning ~150 registers across it
     unsigned zoff = 0;
@@ -586,13 +608,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       const real eps_p = A.eps_abs + A.eps_rel * npri, eps_d = A.eps_abs + A.eps_rel * ndua;
       const real score = fmax(pri / fmax(eps_p, 1e-300), dua / fmax(eps_d, 1e-300));
       if (score < kStallGain * best_score) { best_score = score; best_it = it; }
-      const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel);
-      const bool stalled = it - best_it >= kStallIters && score <= kStallNear * best_score;   // acn_qp_tiled.hpp
+      const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel, A.inacc_floor);
+      const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= kStallNear * best_score;   // acn_qp_tiled.hpp
       if (pri <= eps_p && dua <= eps_d) { status = 1; done = true; }
-      else if (it >= A.max_iter || stalled) {
+      else if (it >= max_iter_p || stalled) {
         done = true;
         if (inacc) status = 5;
-      } else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
+      } else if (adapt_p > 0 && it % adapt_p == 0) {
         const real sp = pri / fmax(npri, 1e-12), sd = dua / fmax(ndua, 1e-12);
         const real ratio = sqrt(sp / fmax(sd, 1e-30));
         const real tol_eff = A.adapt_tol * (1.0 + (real)n_adapt * (1.0 / kAdaptWiden));
@@ -606,8 +628,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
     }
   }
 
-  // ---- results: the feasible iterate z1 is the schedule --------------------------------------------------------
+  // ---- results of this pass: the feasible iterate z1 is the schedule (kept if it beats the earlier passes) ------
+  it_total += it;
   __syncthreads();
+  if (pass == 0 || status_rank(status) > status_rank(best_status)) {   // block-uniform
+  best_status = status;
   real ol = 0;
 #pragma unroll 1
   for (int e = wave; e < NE; e += kStreamWaves)
@@ -642,8 +667,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   if (tid == 0) {
     real o = 0;
     for (int wv = 0; wv < kStreamWaves; ++wv) o += SC[wv];
-    A.status[b] = status; A.iters[b] = it; A.pri[b] = pri; A.dua[b] = dua; A.obj[b] = o;
+    A.status[b] = status; A.pri[b] = pri; A.dua[b] = dua; A.obj[b] = o;
   }
+  }
+  if (tid == 0) A.iters[b] = it_total;
+  if (!retry_wanted(pass, A.retry_passes, status, it, A.stall_iters, A.adapt_every)) break;
+  __syncthreads();
+  }   // passes
 }
 
 #undef RELANE

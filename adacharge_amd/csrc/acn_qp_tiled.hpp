@@ -85,8 +85,13 @@ struct TiledArgs {
   double peak_scale, flat_scale, max_scale;   // host-side row equilibration of the prox rows
   int max_iter, check_every, adapt_every;
   int accel_mem;   // Anderson-acceleration columns actually used (<= the kernel's AM, fits its LDS); 0 = off
+  // acnqp_options.stall_iters / inaccurate_floor / retry_* (include/acn_qp.h)
+  int stall_iters, retry_passes, retry_max_iter;
+  double inacc_floor, retry_rho;
   int pbuf_single; // 1: one partial-tile slab instead of two (one more barrier per iteration, LDS for one more ring column)
 };
+
+typedef const __attribute__((address_space(4))) TiledArgs* KernargPtr;   // the kernel's own argument block
 
 template <typename real> struct Mfma;
 template <> struct Mfma<double> {
@@ -216,12 +221,25 @@ __host__ __device__ inline real effective_pdiag(real pd_user, real reg_rel, real
 // stall rule ends a problem with both residuals within kInaccurate x the requested tolerance, or within the tolerance
 // cvxpy hands OSQP by default (eps_abs = eps_rel = 1e-5), whichever is looser.
 constexpr double kInaccurate = 100.0;
-constexpr double kInaccFloor = 1e-5;
 template <typename real>
-__host__ __device__ inline bool inaccurate_ok(real pri, real dua, real npri, real ndua, double eps_abs, double eps_rel) {
-  const real ea = (real)(kInaccurate * eps_abs > kInaccFloor ? kInaccurate * eps_abs : kInaccFloor);
-  const real er = (real)(kInaccurate * eps_rel > kInaccFloor ? kInaccurate * eps_rel : kInaccFloor);
+__host__ __device__ inline bool inaccurate_ok(real pri, real dua, real npri, real ndua, double eps_abs, double eps_rel, double floor_) {
+  const real ea = (real)(kInaccurate * eps_abs > floor_ ? kInaccurate * eps_abs : floor_);
+  const real er = (real)(kInaccurate * eps_rel > floor_ ? kInaccurate * eps_rel : floor_);
   return pri <= ea + er * npri && dua <= ea + er * ndua;
+}
+// Retry passes (acnqp_options.retry_passes): a problem that ends a pass MAX_ITER / SOLVED_INACCURATE after at least
+// retry_min_iters(stall_iters) iterations is solved again, inside the same kernel, from a cold start with a FIXED
+// penalty retry_rho * 4^(pass - 1) (no adaptation) and at most retry_max_iter iterations.  Why: traced on the C twin
+// (DESIGN.md section 2), the congested instances that sit on a plateau of the primal residual do so because the penalty
+// adaptation swings rho by 10x several times in the first few hundred iterations and the iterate ends in a region it
+// leaves only sub-linearly; from a cold start with a fixed rho in [0.3, 4] every one of them converges in 900 ... 4,400
+// iterations -- while a fixed rho for everybody would double the iterations of the average problem.  The answer of
+// the best pass is the one returned (SOLVED beats SOLVED_INACCURATE beats MAX_ITER; the first of equals), iters is
+// the total over the passes.
+__host__ __device__ inline int retry_min_iters(int stall_iters) { return stall_iters > 0 ? stall_iters : 3000; }
+__host__ __device__ inline int status_rank(int st) { return st == 1 ? 3 : (st == 5 ? 2 : (st == 2 ? 1 : 0)); }
+__host__ __device__ inline bool retry_wanted(int pass, int retry_passes, int status, int it, int stall_iters, int adapt_every0) {
+  return pass < retry_passes && (status == 2 || status == 5) && it >= retry_min_iters(stall_iters) && adapt_every0 > 0;
 }
 // Stall rule: a problem whose residual score max(pri / eps_pri, dua / eps_dua) has not improved by 10 % for
 // kStallIters iterations and sits within kStallNear of its best score (i.e. on the plateau, not in the transient after
@@ -230,8 +248,7 @@ __host__ __device__ inline bool inaccurate_ok(real pri, real dua, real npri, rea
 // wait that long between improvements (longest wait seen on solved instances of every shape in tools/ and tests/:
 // 1,240 iterations, a caltech54 x 12 LINEAR LP); the ones that do are the tangentially degenerate congested instances of DESIGN.md section 6, which
 // otherwise burn max_iter iterations on a plateau and end with the same status.
-constexpr double kStallGain = 0.9, kStallNear = 1.25;
-constexpr int kStallIters = 3000;
+constexpr double kStallGain = 0.9, kStallNear = 1.25;   // the window is acnqp_options.stall_iters (default 3000, 0 = off)
 constexpr double kAdaptWiden = 8.0;   // rho adaptation band: adapt_tol (1 + adaptations / kAdaptWiden): no limit cycles
 constexpr int kAaPeriod = 5;
 constexpr double kAaReg = 1e-4, kAaSafe = 1.2, kAaDrift = 1e-3;
@@ -296,14 +313,32 @@ __device__ inline void block_max(real (&v)[NV], real* Red, int lane, int wave, i
 
 // ---------------------------------------------------------------------------------------
 template <typename real, int NW, int CT, int MT, int KS, int OCC, int AM>
-__global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArgs A) {
+__global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArgs A_kernarg) {
   using M = Mfma<real>;
   using vec4 = typename M::vec4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   real* sm = reinterpret_cast<real*>(smem_raw);
 
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x;
+  // ---- passes: pass 0 is the solve as the options state it; a problem it leaves MAX_ITER / SOLVED_INACCURATE on a
+  // plateau is solved again from a cold start with a fixed penalty (retry_wanted, above).  The WHOLE body, loads
+  // included, is the pass: with the thread and block ids opaque at the top nothing of a pass is invariant across
+  // passes, so the compiler keeps no pass-invariant value (addresses, predicates) alive across the solver loop.
+  int it_total = 0, best_status = 0;
+  for (int pass = 0;; ++pass) {
+  int b_ = blockIdx.x;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(b_));
+  asm volatile("" : "+v"(tid));
+  const int b = __builtin_amdgcn_readfirstlane(b_);
+  // ... and the argument block is read through a per-pass opaque pointer to the kernarg segment (the by-value struct
+  // sits at its offset 0): scalar loads from constant memory, hoisted freely inside a pass, never across passes
+  // (otherwise every argument the loads and the start use stays in a scalar register through the solver loop)
+  KernargPtr Ap = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(Ap));
+  const auto& A = *Ap;
+  (void)A_kernarg;
+  const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
+  const int adapt_p = pass == 0 ? A.adapt_every : 0;
   const int lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, t = lane & 15;
   const int N = A.N, Tm = A.Tm, NP = A.NP, MR = A.MR;
@@ -421,6 +456,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   real tau_max = 0;   // warm start of the demand-charge level
   const real sigma = (real)A.sigma, alpha = (real)A.alpha;
   real rho = (real)A.rho0;
+  if (pass > 0) {   // fixed penalty retry_rho * 4^(pass - 1)
+    rho = (real)A.retry_rho;
+    for (int k = 1; k < pass; ++k) rho *= (real)4;
+  }
   real qnorm, pd;
   {
     real f[3];
@@ -442,6 +481,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           const int tt = 16 * c + t, ev = 16 * wave + M::rowof(g, r);
           if (evact[r] && tt < Tm) A.x[((size_t)b * N + ev) * Tm + tt] = 0;
         }
+      if (A.y_out)
+        for (int k = tid; k < A.Mg * Tm; k += NW * 64) A.y_out[(size_t)b * A.Mg * Tm + k] = 0;
       if (tid == 0) {
         A.status[b] = 4; A.iters[b] = 0;
         A.pri[b] = (double)M::big; A.dua[b] = (double)M::big; A.obj[b] = 0;
@@ -450,6 +491,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     }
   }
 
+#ifdef ACNQP_STAMPS
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
   // site-row state, replicated in every wave (identical instruction stream => identical bits)
   real z2[MT][CT][4], y2[MT][CT][4], gx[MT][CT][4];
 #pragma unroll
@@ -514,10 +559,6 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     }
   }
 
-#ifdef ACNQP_STAMPS
-  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
-#endif
   // ---- projection onto B (energy rows), used by the start and by every iteration; `between` is work that is
   // independent of the water-filling and is placed inside it to share a basic block with the first Newton pass
   auto project_B = [&](const real (&zin)[CT][4], auto&& between) __attribute__((always_inline)) {
@@ -659,7 +700,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   // congested closed loops: -25..-40 % iterations against the cold start; starting from the old y1 instead is worse
   // than cold, because the cost vector q changes with the horizon at every MPC step.)
   {
-    const bool warm = A.warm_x != nullptr && A.warm_y != nullptr;   // block-uniform
+    const bool warm = pass == 0 && A.warm_x != nullptr && A.warm_y != nullptr;   // block-uniform; a retry pass starts cold
     real zs[CT][4];
 #pragma unroll
     for (int c = 0; c < CT; ++c)
@@ -843,7 +884,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           zhr[mo][c][r] = alpha * zt[r] + ((real)1 - alpha) * z2[mo][c][r] + y2[mo][c][r] * inv_rho;
         }
       }
-    const bool check = (it % A.check_every == 0) || it >= A.max_iter;
+    const bool check = (it % A.check_every == 0) || it >= max_iter_p;
 
     STAMP(3);   // x~ MFMA, Q h^ MFMA
     // ---- Anderson acceleration event: u = (zh, zhr) is the state of the fixed-point map; every
@@ -1311,14 +1352,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
       }
       const real score = fmax(pri / fmax(eps_p, (real)1e-300), dua / fmax(eps_d, (real)1e-300));
       if (score < (real)kStallGain * best_score) { best_score = score; best_it = it; }
-      const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel);
-      const bool stalled = it - best_it >= kStallIters && score <= (real)kStallNear * best_score;
+      const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel, A.inacc_floor);
+      const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= (real)kStallNear * best_score;
       if (done) {
-      } else if (it >= A.max_iter || stalled) {
+      } else if (it >= max_iter_p || stalled) {
         done = true;
         if (inacc) status = 5;   // solved, inaccurately
       }
-      else if (A.adapt_every > 0 && it % A.adapt_every == 0) {
+      else if (adapt_p > 0 && it % adapt_p == 0) {
         const real sp = pri / fmax(npri, (real)1e-12);
         const real sd = dua / fmax(ndua, (real)1e-12);
         const real ratio = sqrt(sp / fmax(sd, (real)1e-30));
@@ -1352,12 +1393,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     }
     STAMP(6);   // residual check (amortised)
   }
-#ifdef ACNQP_STAMPS
-  if (lane == 0 && b < 1024)
-    for (int k = 0; k < 12; ++k) g_stamps[(b * 16 + wave) * 12 + k] = st_acc[k];
-#endif
-
-  // ---- results: the feasible iterate z1 is the schedule ------------------------------------
+  it_total += it;
+  // ---- results of this pass: the feasible iterate z1 is the schedule (kept if it beats the earlier passes) -----
+  if (pass == 0 || status_rank(status) > status_rank(best_status)) {   // block-uniform
+  best_status = status;
   real ol = 0;
   int lane_o = lane;   // opaque copy: the store predicates are evaluated here, not kept alive across the loop
   asm volatile("" : "+v"(lane_o));
@@ -1393,11 +1432,19 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     real o = 0;
     for (int wv = 0; wv < NW; ++wv) o += Red[wv * kNumRed];
     A.status[b] = status;
-    A.iters[b] = it;
     A.pri[b] = (double)pri;
     A.dua[b] = (double)dua;
     A.obj[b] = (double)o;
   }
+  __syncthreads();   // Red is reused by the next pass
+  }
+  if (tid == 0) A.iters[b] = it_total;
+#ifdef ACNQP_STAMPS
+  if (lane == 0 && b < 1024)
+    for (int k = 0; k < 12; ++k) g_stamps[(b * 16 + wave) * 12 + k] = st_acc[k];
+#endif
+  if (!retry_wanted(pass, A.retry_passes, status, it, A.stall_iters, A.adapt_every)) break;
+  }   // passes
 }
 
 }  // namespace acnqp

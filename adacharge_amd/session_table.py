@@ -68,6 +68,17 @@ class SessionTable:
                    np.asarray(off, np.int64), np.asarray(rem, np.int64), np.asarray(dem, float), np.asarray(arr, np.int64),
                    seg, cat(mins), cat(maxs), ids)
 
+    def take(self, idx) -> "SessionTable":
+        """The sessions ``idx`` (in that order) as a new table: a permutation and / or a selection."""
+        idx = np.asarray(idx, np.int64)
+        lens = np.diff(self.seg)[idx]
+        seg = np.zeros(len(idx) + 1, dtype=np.int64)
+        np.cumsum(lens, out=seg[1:])
+        src = np.repeat(self.seg[:-1][idx] - seg[:-1], lens) + np.arange(seg[-1])   # gather of the ragged rate vectors
+        return SessionTable(self.B, self.N, self.prob[idx], self.evse[idx], self.off[idx], self.rem[idx], self.demand[idx],
+                            self.arrival[idx], seg, self.min_rates[src], self.max_rates[src],
+                            None if self.session_ids is None else [self.session_ids[k] for k in idx])
+
     def owner(self) -> np.ndarray:
         """Session index of every entry of the ragged rate arrays."""
         return np.repeat(np.arange(self.S), np.diff(self.seg))
@@ -119,11 +130,16 @@ def apply_minimum_charging_rate(table: SessionTable, infrastructure, period, ove
     """acn.apply_minimum_charging_rate for every snapshot at once: in arrival order, a session gets its EVSE's
     minimum pilot as min_rates[0] when it still needs that much and the network carries it on top of the earlier
     arrivals; otherwise its first period is pinned to zero.  The greedy walk is sequential inside a snapshot, so the
-    loop runs over the arrival RANK and every step is one array operation over all snapshots."""
+    loop runs over the arrival RANK and every step is one array operation over all snapshots.
+    Like its twin -- which returns ``sorted(sessions, key=arrival)`` (stable) without the sessions whose
+    ``remaining_time <= 0`` -- the table comes back in (snapshot, arrival) order without those sessions: the order is
+    what breaks ties between equal rounding losses in ``diff_based_reallocation`` (post.py:214-218)."""
     out = table.copy()
+    alive = np.flatnonzero(out.rem > 0)
+    perm = alive[np.lexsort((out.arrival[alive], out.prob[alive]))]     # stable: by snapshot, then arrival, then list order
     live = np.flatnonzero((out.rem > 0) & (np.diff(out.seg) > 0))
     if len(live) == 0:
-        return out
+        return out.take(perm)
     order = live[np.lexsort((out.arrival[live], out.prob[live]))]        # stable: by snapshot, then arrival
     p = out.prob[order]
     start = np.r_[0, np.flatnonzero(np.diff(p)) + 1]
@@ -147,4 +163,4 @@ def apply_minimum_charging_rate(table: SessionTable, infrastructure, period, ove
         out.min_rates[first[~ok]] = 0.0
         out.max_rates[first[~ok]] = 0.0
     _reconcile(out, np.concatenate(raised))
-    return out
+    return out.take(perm)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define ACNQP_ABI_VERSION 6
+#define ACNQP_ABI_VERSION 7
 
 /* cone of the infrastructure rows (constraint_type at aco.py:35, 151, 165) */
 #define ACNQP_CONE_LINEAR 0
@@ -52,14 +52,14 @@ extern "C" {
 #define ACNQP_STATUS_UNSET 0
 #define ACNQP_STATUS_SOLVED 1             /* cp.OPTIMAL                     */
 #define ACNQP_STATUS_MAX_ITER 2           /* residuals above tolerance at max_iter, or stalled above the
-                                             SOLVED_INACCURATE level (no 10 % progress for 3000 iterations) */
+                                             SOLVED_INACCURATE level (no 10 % progress for options.stall_iters
+                                             iterations), in every pass (options.retry_passes)              */
 #define ACNQP_STATUS_PRIMAL_INFEASIBLE 3  /* ADMM certificate (cp.INFEASIBLE) */
 #define ACNQP_STATUS_EMPTY_SET 4          /* a session's bounds cannot meet its energy row */
-#define ACNQP_STATUS_SOLVED_INACCURATE 5   /* max_iter or the stall rule (no 10 % progress of the residuals for
-                                             3000 iterations) ended the problem with both residuals
-                                             within 100x their tolerance, or within the tolerance cvxpy gives
-                                             OSQP by default (1e-5), whichever is looser: cp.OPTIMAL_INACCURATE,
-                                             which the reference accepts (aco.py:319)              */
+#define ACNQP_STATUS_SOLVED_INACCURATE 5   /* max_iter or the stall rule ended every pass short of the tolerance,
+                                             the best one with both residuals within 100x their tolerance or
+                                             within options.inaccurate_floor, whichever is looser:
+                                             cp.OPTIMAL_INACCURATE, which the reference accepts (aco.py:319) */
 
 /* return codes (never C++ exceptions across the ABI) */
 #define ACNQP_OK 0
@@ -157,6 +157,26 @@ typedef struct {
                             history requested (0 = plain ADMM).  The kernels use
                             min(accel_mem, what fits their LDS for the problem shape);
                             acnqp_accel_columns reports that number                */
+  /* -- ABI v7 ------------------------------------------------------------------------------------------ */
+  int32_t stall_iters;   /* stall rule: a pass whose residual score max(pri / eps_pri, dua / eps_dua) has not
+                            improved by 10 % for this many iterations, and sits within 1.25x of its best, ends
+                            (SOLVED_INACCURATE if it qualifies, MAX_ITER otherwise) instead of burning max_iter
+                            iterations on a plateau.  0 = off.  Default 3000 (the longest wait between two
+                            improvements seen on any converging instance of tools/ and tests/ is 1,240)     */
+  int32_t retry_passes;  /* a problem whose pass ends MAX_ITER / SOLVED_INACCURATE after >= stall_iters (3000 if
+                            the stall rule is off) iterations is solved again from a COLD start with a FIXED
+                            penalty retry_rho * 4^(pass - 1) -- inside the same kernel launch, for every entry
+                            point -- up to this many times; the best pass is returned (SOLVED > SOLVED_INACCURATE
+                            > MAX_ITER, the first of equals), iters is the total.  0 = single pass.  Default 2.
+                            Only when adapt_every > 0 (a caller who fixed the penalty gets that penalty only).
+                            Why it works: DESIGN.md section 2 (the plateau is the adaptive penalty's doing)  */
+  int32_t retry_max_iter;/* iteration limit of a retry pass (min with max_iter).  Default 8000            */
+  int32_t reserved_;     /* must be 0                                                                     */
+  double retry_rho;      /* penalty of the first retry pass.  Default 0.5                                 */
+  double inaccurate_floor; /* residual tolerance (absolute and relative) below which a pass that ran out of
+                            iterations still counts as SOLVED_INACCURATE even when 100x the requested tolerance
+                            is tighter.  Default 1e-5 (what cvxpy hands OSQP as eps_abs = eps_rel).  0 = the
+                            100x rule alone                                                               */
 } acnqp_options;
 
 /* acnqp_create -- uploads the site once.  Replaces the per-call rebuilding of
@@ -219,6 +239,10 @@ float acnqp_last_kernel_ms(acnqp_handle* h);
  * flight on several streams).  Blocks until those launches have finished.
  * Returns the number of values written.                                      */
 int32_t acnqp_kernel_times(acnqp_handle* h, float* out_ms, int32_t capacity);
+
+/* Kernel launches made through this handle since it was created (acnqp_kernel_times keeps the 64 most recent
+ * durations: a caller that sums them can tell from this count whether any were dropped).                    */
+int64_t acnqp_launch_count(acnqp_handle* h);
 
 /* Anderson columns the kernels will actually use for problems of this shape
  * (t_max periods, k_sessions slots) at the given precision when `requested`

@@ -27,6 +27,10 @@ typedef struct {
   double eps_abs, eps_rel, rho, sigma, alpha, adapt_tol, reg_rel;
   int max_iter, check_every, adapt_every;
   int accel_mem;   /* Anderson-acceleration memory (columns); 0 = plain ADMM */
+  /* acnqp_options of ABI v7 (include/acn_qp.h): stall window (0 = off), retry passes, their iteration limit,
+   * the first retry's fixed penalty, the SOLVED_INACCURATE floor */
+  int stall_iters, retry_passes, retry_max_iter;
+  double retry_rho, inaccurate_floor;
 } port_opts;
 
 static double clip(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -87,7 +91,6 @@ static const int kAaPeriod = 5;
  * kStallIters iterations with the score within kStallNear of its best end the problem (SOLVED_INACCURATE if the
  * residuals are good enough for it, MAX_ITER otherwise) */
 static const double kStallGain = 0.9, kStallNear = 1.25;
-static const int kStallIters = 3000;
 static const double kAaReg = 1e-4, kAaSafe = 1.2, kAaDrift = 1e-3;
 
 /* solve (H + eta I) gamma = b for the valid columns (LDL', no pivoting: H is a Gram matrix) */
@@ -446,9 +449,9 @@ static int solve_one(const port_site* S, const port_opts* O, int horizon, const 
       const double score = fmax(pri / fmax(O->eps_abs + O->eps_rel * npri, 1e-300), dua / fmax(O->eps_abs + O->eps_rel * ndua, 1e-300));
       if (score < kStallGain * best_score) { best_score = score; best_it = it; }
       /* solved, inaccurately: within 100 x the tolerance, or within cvxpy's OSQP default 1e-5, whichever is looser */
-      const double ea = fmax(100.0 * O->eps_abs, 1e-5), er = fmax(100.0 * O->eps_rel, 1e-5);
+      const double ea = fmax(100.0 * O->eps_abs, O->inaccurate_floor), er = fmax(100.0 * O->eps_rel, O->inaccurate_floor);
       const int inacc = pri <= ea + er * npri && dua <= ea + er * ndua;
-      const int stalled = it - best_it >= kStallIters && score <= kStallNear * best_score;
+      const int stalled = O->stall_iters > 0 && it - best_it >= O->stall_iters && score <= kStallNear * best_score;
       if (done) {
       } else if (it >= O->max_iter || stalled) {
         done = 1;
@@ -500,7 +503,37 @@ int admm_port_solve_batch(const port_site* S, const port_opts* O, int B, const i
                           s_cap + b * ns, s_eq[b] != 0, peak ? peak + (size_t)b * S->Tm : 0, x + b * nv, &it,
                           pri + b, dua + b, obj + b, warm_x ? warm_x + b * nv : 0,
                           warm_y ? warm_y + (size_t)b * S->Mg * S->Tm : 0, y_out ? y_out + (size_t)b * S->Mg * S->Tm : 0);
-    iters[b] = it;
+    int total = it, last_status = status[b], last_it = it;
+    /* retry passes of the device kernels (retry_wanted, acn_qp_tiled.hpp): a problem a pass leaves MAX_ITER /
+     * SOLVED_INACCURATE after at least stall_iters (3000 if the rule is off) iterations is solved again from a cold
+     * start with the fixed penalty retry_rho * 4^(pass - 1); the best pass is kept (SOLVED > SOLVED_INACCURATE >
+     * MAX_ITER, the first of equals), iters is the total */
+    for (int pass = 0; pass < O->retry_passes && (last_status == 2 || last_status == 5) &&
+                       last_it >= (O->stall_iters > 0 ? O->stall_iters : 3000) && O->adapt_every > 0; ++pass) {
+      port_opts O2 = *O;
+      O2.rho = O->retry_rho;
+      for (int k = 0; k < pass; ++k) O2.rho *= 4.0;
+      O2.adapt_every = 0;
+      O2.max_iter = O->max_iter < O->retry_max_iter ? O->max_iter : O->retry_max_iter;
+      double* x2 = (double*)malloc(sizeof(double) * (nv + (size_t)S->Mg * S->Tm));
+      double* y2 = x2 + nv;
+      double pri2, dua2, obj2;
+      int it2 = 0;
+      const int st2 = solve_one(S, &O2, horizon[b], lb + b * nv, ub + b * nv, q + b * nv, pdiag[b], lf ? lf[b] : 0.0, dc ? dc[b] : 0.0, dfloor ? dfloor[b] : 0.0,
+                                s_off + b * ns, s_len + b * ns, s_cap + b * ns, s_eq[b] != 0, peak ? peak + (size_t)b * S->Tm : 0, x2, &it2,
+                                &pri2, &dua2, &obj2, 0, 0, y_out ? y2 : 0);
+      total += it2;
+      const int rank_new = st2 == 1 ? 3 : (st2 == 5 ? 2 : (st2 == 2 ? 1 : 0));
+      const int rank_old = status[b] == 1 ? 3 : (status[b] == 5 ? 2 : (status[b] == 2 ? 1 : 0));
+      if (rank_new > rank_old) {
+        memcpy(x + b * nv, x2, sizeof(double) * nv);
+        if (y_out) memcpy(y_out + (size_t)b * S->Mg * S->Tm, y2, sizeof(double) * S->Mg * S->Tm);
+        status[b] = st2; pri[b] = pri2; dua[b] = dua2; obj[b] = obj2;
+      }
+      free(x2);
+      last_status = st2; last_it = it2;
+    }
+    iters[b] = total;
   }
   return 0;
 }

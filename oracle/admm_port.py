@@ -15,8 +15,8 @@ class _Site(C.Structure):
 
 class _Opts(C.Structure):
     _fields_ = [(k, C.c_double) for k in ("eps_abs", "eps_rel", "rho", "sigma", "alpha", "adapt_tol", "reg_rel")] + [
-        (k, C.c_int) for k in ("max_iter", "check_every", "adapt_every", "accel_mem")
-    ]
+        (k, C.c_int) for k in ("max_iter", "check_every", "adapt_every", "accel_mem", "stall_iters", "retry_passes", "retry_max_iter")
+    ] + [(k, C.c_double) for k in ("retry_rho", "inaccurate_floor")]
 
 
 _lib = None
@@ -72,7 +72,8 @@ def equilibrated(site):
 
 
 def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.02, sigma=1e-6, alpha=1.4, adapt_tol=3.0,
-                reg_rel=0.06, max_iter=20000, check_every=20, adapt_every=20, accel_mem=0, warm_x=None, warm_y=None):
+                reg_rel=0.06, max_iter=20000, check_every=20, adapt_every=20, accel_mem=0, warm_x=None, warm_y=None,
+                stall_iters=3000, retry_passes=2, retry_max_iter=8000, retry_rho=0.5, inaccurate_floor=1e-5):
     """Solve a builder.ProblemBatch-like object on the CPU; same defaults as
     acnqp_default_options.  Returns dict of arrays."""
     lib = _load()
@@ -81,7 +82,8 @@ def solve_batch(batch, threads=1, eps_abs=1e-8, eps_rel=1e-8, rho=0.02, sigma=1e
     Ge, Ghe, Qe, lame, lime, pk_s, fl_s, mx_s = equilibrated(site)
     keep = [np.ascontiguousarray(a, np.float64) for a in (Ge, Ghe, Qe, lame, lime)]
     S = _Site(site.N, batch.Tm, batch.K, site.Mg, site.M, int(site.cone), int(site.has_peak), int(getattr(site, 'has_flat', False)), int(getattr(site, 'has_max', False)), *[p(a) for a in keep])
-    O = _Opts(eps_abs, eps_rel, rho, sigma, alpha, adapt_tol, reg_rel, max_iter, check_every, adapt_every, int(accel_mem))
+    O = _Opts(eps_abs, eps_rel, rho, sigma, alpha, adapt_tol, reg_rel, max_iter, check_every, adapt_every, int(accel_mem),
+              int(stall_iters), int(retry_passes), int(retry_max_iter), float(retry_rho), float(inaccurate_floor))
     B, N, Tm = batch.B, site.N, batch.Tm
     arrs = [np.ascontiguousarray(batch.T, np.int32), np.ascontiguousarray(batch.lb, np.float64), np.ascontiguousarray(batch.ub, np.float64),
             np.ascontiguousarray(batch.q, np.float64), np.ascontiguousarray(batch.pdiag, np.float64),

@@ -89,10 +89,19 @@ def load_wide():
     return np.load(WIDE, allow_pickle=False)
 
 
+STALLED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stalled.npz")
+
+
+def load_stalled():
+    """tools/make_golden_stalled.py: certified optima of instances that end the adaptive first pass on a plateau."""
+    return np.load(STALLED, allow_pickle=False)
+
+
 def wide_case(g, name):
-    """Rebuild fixture ``name`` of wide.npz (tools/make_golden_wide.py): returns
+    """Rebuild fixture ``name`` of wide.npz / stalled.npz (tools/make_golden_wide.py, make_golden_stalled.py): returns
     (sessions, infrastructure, interface, meta dict, peak_limit, expected dict)."""
-    infra = getattr(sites, str(g[f"{name}_site"]))()
+    site_tag = str(g[f"{name}_site"])
+    infra = sites.eight_sites()[int(site_tag.split(":")[1])] if site_tag.startswith("eight:") else getattr(sites, site_tag)()
     iface = Interface({"infrastructure_info": infra, "period": 5})
     st, arr, dep = g[f"{name}_station"], g[f"{name}_arrival"], g[f"{name}_departure"]
     minr, maxr = g[f"{name}_minr"], g[f"{name}_maxr"]

@@ -372,16 +372,17 @@ def test_config4_stochastic_mpc_1024_scenarios_times_8_sites():
         f = rng.lognormal(0.0, 0.25, size=(S, base.K, base.N))   # demand scaled per session per scenario
         batch = scenario_batch(base, f)
         h = SiteHandle(batch.site, 0)
-        first = h.solve(batch, default_options())
+        first = h.solve(batch, default_options(retry_passes=0))
         # On the most congested synthetic site ~3 % of the scenarios sit on a plateau of the primal residual after the
-        # adaptive first pass: the stall rule ends them as SOLVED_INACCURATE (residuals below
+        # adaptive pass: the stall rule ends them as SOLVED_INACCURATE (residuals below
         # cvxpy's OSQP default 1e-5, above the 1e-8 asked for) -- reported as such, never as SOLVED, none fails ...
         assert np.isin(first.status, (1, 5)).all() and (first.status == 1).mean() >= 0.96, (k, np.unique(first.status, return_counts=True))
         assert first.iters.max() <= 12000
-        # ... and the binding's second pass (cold start, fixed penalty) solves them to the 1e-8 asked for (all but at
-        # most one in a thousand, which keeps its first answer)
-        res = h.solve(batch, default_options(), retry_stalled=True)
-        assert np.isin(res.status, (1, 5)).all() and (res.status == 1).mean() >= 0.998, (k, np.unique(res.status, return_counts=True))
+        # ... and the library's retry passes (acnqp_options.retry_passes, default 2: cold start, fixed penalty, inside
+        # the same launch) solve them to the 1e-8 asked for: EVERY scenario of every site SOLVED at the C ABI
+        res = h.solve(batch, default_options())
+        assert (res.status == 1).all(), (k, np.unique(res.status, return_counts=True), res.iters[res.status != 1])
+        assert np.array_equal(res.x[first.status == 1], first.x[first.status == 1])   # a solved problem is never touched again
         assert (res.x <= batch.ub + 1e-9).all() and (res.x >= batch.lb - 1e-9).all()
         e = np.zeros((S, base.N))
         for i in range(base.N):
@@ -396,12 +397,12 @@ def test_config4_stochastic_mpc_1024_scenarios_times_8_sites():
         # determinism and batch-composition independence: the first 64 scenarios alone give the same bits
         sb = batch.subset(slice(0, 64))
         again = h.solve(sb, default_options())
-        assert np.array_equal(again.x, first.x[:64]) and np.array_equal(again.iters, first.iters[:64])
+        assert np.array_equal(again.x, res.x[:64]) and np.array_equal(again.iters, res.iters[:64])
         m_eff = h.accel_columns(batch.Tm, batch.K, default_options())
         ref = admm_port.solve_batch(sb, threads=8, accel_mem=m_eff)
         both = (ref["status"] == 1) & (again.status == 1)
         assert both.sum() >= 60
-        assert np.abs(ref["x"][both] - first.x[:64][both]).max() <= 5e-4
+        assert np.abs(ref["x"][both] - res.x[:64][both]).max() <= 5e-4
         total += S
         h.close()
     assert total == 8192
@@ -463,6 +464,38 @@ def test_adaptive_scheduling_algorithm_schedule_and_batch():
     assert iface.is_feasible({k: v[:1] for k, v in qs.items()})
     with pytest.raises(ValueError):
         AdaptiveSchedulingAlgorithm(obj, reallocate=True)
+
+
+def test_schedule_batch_equals_schedule_with_uninterrupted_quantize_reallocate_on_tied_rates():
+    """with uninterrupted_charging + quantize + reallocate the order in which equal rounding losses are
+    served (post.py:214-218, stable sort) is the order apply_minimum_charging_rate returns -- sorted by arrival.  Every
+    active EVSE ends at the same continuous rate here (equal_share on a congested site, shuffled arrivals), so any
+    difference in that order shows up in the first-period pilots."""
+    from adacharge_amd import AdaptiveSchedulingAlgorithm
+    from adacharge_amd.acn import Interface, SessionInfo
+
+    infra = sites.caltech54()
+    ids = infra.station_ids
+    rng = np.random.default_rng(11)
+    snaps = []
+    for b in range(12):
+        n = int(rng.integers(30, 50))
+        ev = rng.choice(54, size=n, replace=False)
+        arr = rng.permutation(n) - n          # distinct arrivals in the past, shuffled against the list order
+        snaps.append([SessionInfo(ids[int(i)], f"b{b}s{k}", 30.0, 0.0, int(arr[k]), 12, current_time=0, max_rates=32.0)
+                      for k, i in enumerate(ev)])
+    iface = Interface({"infrastructure_info": infra, "period": 5, "active_sessions": snaps[0], "current_time": 0})
+    obj = [ObjectiveComponent(quick_charge, 1e-6), ObjectiveComponent(equal_share, 1.0)]
+    alg = AdaptiveSchedulingAlgorithm(obj, uninterrupted_charging=True, quantize=True, reallocate=True)
+    alg.register_interface(iface)
+    many = alg.schedule_batch(snaps)
+    differ = 0
+    for b, sl in enumerate(snaps):
+        one = alg.schedule(sl)
+        for sid in ids:
+            assert np.isin(one[sid], infra.allowable_pilots[ids.index(sid)]).all()
+            differ += int(one[sid][0] != many[b][sid][0])
+    assert differ == 0
 
 
 def test_offline_algorithm_single_ev():   # shape of t_int.py:311-347

@@ -67,8 +67,24 @@ def test_apply_minimum_charging_rate_matches_per_session(site_name, seed):
     assert any((s.max_rates[0] == 0 and s.min_rates[0] == 0) for sl in want for s in sl)   # the network refusal path is exercised
     assert any(s.min_rates[0] == 8.0 for sl in want for s in sl)
     _assert_same(got, want, infra)
+    # same ORDER as the per-session function (sorted by arrival, stable; remaining_time <= 0 dropped): the order breaks
+    # ties in diff_based_reallocation
+    ref = _table_of(want, infra)
+    assert got.session_ids == ref.session_ids and np.array_equal(got.prob, ref.prob) and np.array_equal(got.seg, ref.seg)
     got = st.apply_minimum_charging_rate(_table_of(lists, infra), infra, 5, override=4.0)
     _assert_same(got, [acn.apply_minimum_charging_rate(sl, infra, 5, override=4.0) for sl in lists], infra)
+
+
+def test_apply_minimum_charging_rate_drops_finished_sessions_and_sorts_by_arrival():
+    infra = sites.caltech54()
+    ids = infra.station_ids
+    mk = lambda i, sid, arr, dep: acn.SessionInfo(ids[i], sid, 5.0, 0.0, arr, dep, current_time=3, max_rates=32.0)
+    lists = [[mk(0, "late", 3, 9), mk(1, "gone", 0, 3), mk(2, "early", 1, 8), mk(3, "tie", 3, 7)]]
+    got = st.apply_minimum_charging_rate(_table_of(lists, infra), infra, 5)
+    want = acn.apply_minimum_charging_rate(lists[0], infra, 5)
+    assert [s.session_id for s in want] == ["early", "late", "tie"]
+    assert got.session_ids == ["early", "late", "tie"] and got.S == 3
+    _assert_same(got, [want], infra)
 
 
 @pytest.mark.parametrize("two", [False, True])
