@@ -53,6 +53,8 @@ def parse(argv=None):
     ap.add_argument("--precision", type=int, default=64, choices=[64])
     ap.add_argument("--pageable", action="store_true", help="problem / result arrays in pageable host memory")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the legs that time the other BASELINE.json configurations after the headline (N = 1 only)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device rehearses the N > 1 path on a single-GPU box")
@@ -86,9 +88,173 @@ def algorithmic_bytes(B, N, Tm, K, site):
 
 
 def flops_per_iteration(N, Tm, site):
-    """ALGORITHMIC flops of one ADMM iteration."""
+    """Flops one ADMM iteration EXECUTES with G and Q dense (what the MFMA chains do), per problem."""
     Mg = site.Mg
     return 4 * Mg * N * Tm + 4 * Mg * Mg * Tm + 20 * N * Tm + 12 * Mg * Tm
+
+
+def flops_per_iteration_sparse(batch):
+    """ALGORITHMIC flops of one ADMM iteration: F_iter = 4 nnz(A) + 12 (n + m) + F_solve with
+    nnz(A) = n + sum_s len_s + T nnz(G) (+ T N for a peak row), m = n + S + Mg T rows, and the matrix-free solve
+    F_solve = 4 Mg^2 T (the two Mg x Mg products per period).  Mean over the batch's problems."""
+    import numpy as np
+
+    site = batch.site
+    N, Tm = batch.N, batch.Tm
+    T = np.asarray(batch.T, float)
+    n = N * T
+    nnzG = float(np.count_nonzero(site.G))
+    sess = (batch.s_len > 0).reshape(batch.B, -1).sum(axis=1).astype(float)
+    slen = batch.s_len.reshape(batch.B, -1).sum(axis=1).astype(float)
+    nnzA = n + slen + T * nnzG
+    m = n + sess + site.Mg * T
+    return float(np.mean(4 * nnzA + 12 * (n + m) + 4 * site.Mg * site.Mg * T))
+
+
+def streamed_bytes_per_iteration(batch):
+    """SURVEY.md section 8d B_iter = w (3 n + 6 m) for kernels whose state is not on-chip (read x, q, z, y, l, u;
+    write x, z, y), m = n + S + Mg T rows; mean over the batch."""
+    import numpy as np
+
+    T = np.asarray(batch.T, float)
+    n = batch.N * T
+    sess = (batch.s_len > 0).reshape(batch.B, -1).sum(axis=1).astype(float)
+    m = n + sess + batch.site.Mg * T
+    return float(np.mean(8 * (3 * n + 6 * m)))
+
+
+# ---- the other BASELINE.json configurations (timed outside the headline region, reported in the same JSON line) -----
+def other_workloads():
+    """name -> builder returning (batch, options, streamed, note).  `streamed`: the kernel that serves the shape keeps its
+    iterates in HBM / L2 (large-site and long-horizon kernels), so the roofline counts B_iter per iteration; otherwise
+    the state is on chip and only the compulsory I/O counts."""
+    import numpy as np
+
+    from adacharge_amd import ObjectiveComponent, equal_share, load_flattening, quick_charge, sites
+    from adacharge_amd.acn import Interface
+    from adacharge_amd.backend import default_options
+    from adacharge_amd.builder import ProblemBatch, build_batch, scenario_batch
+
+    qc_es = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+
+    def cfg2(site_name):
+        infra = getattr(sites, site_name)()
+        iface = Interface({"infrastructure_info": infra, "period": 5})
+        batch = build_batch(sites.snapshot_batch(infra, 24, 4096, seed=31), infra, iface, qc_es, "SOC")
+        return batch, default_options(), False, "configs[2]: horizon 24, batch 4096, fp64 (fp32 is refused: DESIGN.md 3.5)"
+
+    def cfg3_site(k):
+        infra = sites.eight_sites()[k]
+        iface = Interface({"infrastructure_info": infra, "period": 5})
+        rng = np.random.default_rng(500 + k)
+        base = build_batch([sites.random_sessions(infra, 12, rng)], infra, iface, qc_es, "SOC")
+        batch = scenario_batch(base, rng.lognormal(0.0, 0.25, size=(1024, base.K, base.N)))
+        return batch, default_options(), False, f"configs[3]: site {k} of the 8 ({infra.num_stations} EVSE), 1024 demand scenarios, horizon 12"
+
+    def cfg4():
+        # 512 EVSE x 48, load flattening of an external load profile with the sessions' energy DELIVERED (equalities,
+        # t_int.py:350-403 style): the site rows bind (utilisation 0.99-1.0) and the default tolerances need hundreds of
+        # iterations (round 2 timed a workload whose optimum was the all-zero schedule: 20 iterations, nothing binding)
+        infra = sites.synth512()
+        iface = Interface({"infrastructure_info": infra, "period": 5})
+        T = 48
+        ext = 150.0 + 100.0 * np.cos(np.arange(T) / T * 2 * np.pi)
+        obj = [ObjectiveComponent(load_flattening, 1.0, {"external_signal": ext})]
+        rng = np.random.default_rng(5)
+        snaps = [sites.random_sessions_general(infra, T, rng, False, False, demand_scale=0.15) for _ in range(8)]
+        base = build_batch(snaps, infra, iface, obj, "SOC", True)
+        batch = ProblemBatch.concatenate([scenario_batch(base, rng.lognormal(0.0, 0.1, size=256), problem=p) for p in range(8)])
+        return batch, default_options(), True, "configs[4] shape: synthetic 512 EVSE x 48, load_flattening + energy equalities, 8 snapshots x 256 demand scenarios, default tolerances"
+
+    def stress144():
+        infra = sites.caltech54()
+        iface = Interface({"infrastructure_info": infra, "period": 5})
+        obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
+        batch = build_batch(sites.snapshot_batch(infra, 144, 256, seed=144, demand_range=(5.0, 60.0)), infra, iface, obj, "SOC")
+        return batch, default_options(), True, "the reference's stress shape (t_aco.py:286-466): 54 EVSE x 144 periods, batch 256"
+
+    return {
+        "cfg2_caltech54_T24_b4096": lambda: cfg2("caltech54"),
+        "cfg2_jpl52_T24_b4096": lambda: cfg2("jpl52"),
+        "cfg3_site3_T12_b1024": lambda: cfg3_site(3),
+        "cfg3_site0_T12_b1024": lambda: cfg3_site(0),
+        "cfg4_synth512_T48_b2048": cfg4,
+        "stress_caltech54_T144_b256": stress144,
+    }
+
+
+def time_device_launch(batch, opts, dev, reps=2):
+    """One device-resident launch of `batch` (acnqp_solve_batch_device), HIP events around it; returns the leg's record."""
+    import numpy as np
+    import torch
+
+    from adacharge_amd.backend import DeviceBatch, SiteHandle
+
+    h = SiteHandle(batch.site, dev.index or 0)
+    db = DeviceBatch(batch, dev)
+    st = torch.cuda.current_stream().cuda_stream
+    ms = []
+    for _ in range(reps + 1):   # the first launch also allocates the kernel's workspace
+        h.solve_device(db, opts, stream=st)
+        torch.cuda.synchronize()
+        ms.append(h.last_kernel_ms())
+    ms = ms[1:]
+    it = db.iters.cpu().numpy()
+    stt = db.status.cpu().numpy()
+    cols = h.accel_columns(batch.Tm, batch.K, opts)
+    h.close()
+    del db
+    return min(ms), it, stt, cols
+
+
+def other_configs_leg(dev, only=None):
+    import numpy as np
+
+    out = {}
+    for name, build in other_workloads().items():
+        if only and name not in only:
+            continue
+        t0 = time.perf_counter()
+        batch, opts, streamed, note = build()
+        t_build = time.perf_counter() - t0
+        ms, it, stt, cols = time_device_launch(batch, opts, dev)
+        N, Tm, K = batch.N, batch.Tm, batch.K
+        _, per_qp, _ = algorithmic_bytes(1, N, Tm, K, batch.site)
+        b_iter = streamed_bytes_per_iteration(batch) if streamed else 0.0
+        abytes = batch.B * (per_qp + float(it.mean()) * b_iter)
+        fl = flops_per_iteration_sparse(batch)
+        tf = float(it.sum()) * fl / (ms * 1e-3) / 1e12
+        out[name] = {
+            "note": note, "batch": batch.B, "n_evse": N, "horizon": Tm, "site_rows": batch.site.Mg,
+            "kernel_ms": ms, "qps": batch.B / (ms * 1e-3),
+            "iters_mean": float(it.mean()), "iters_max": int(it.max()),
+            "solved": int((stt == 1).sum()), "inaccurate": int((stt == 5).sum()), "failed": int(np.isin(stt, (2, 3, 4)).sum()),
+            "anderson_columns": cols, "state": "streamed (HBM / L2)" if streamed else "on chip",
+            "algorithmic_bytes_per_launch": abytes, "hbm_GBs": abytes / (ms * 1e-3) / 1e9,
+            "hbm_frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "flops_per_iteration_sparse": fl, "fp64_TFs": tf, "fp64_frac": tf / FP64_VALU_PEAK_TF,
+            "build_s": t_build,
+        }
+    return out
+
+
+def strict_batch256_leg(handle, batch, opts, calls=40):
+    """BASELINE.json configs[1] to the letter: ONE batch of 256 snapshots per acnqp_solve_batch call, host buffers in,
+    host buffers out, nothing else in flight -- the latency-bound way to use the library."""
+    import numpy as np
+
+    handle.solve(batch, opts, pinned_results=True)
+    t, k = [], []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        r = handle.solve(batch, opts, pinned_results=True)
+        t.append(time.perf_counter() - t0)
+        k.append(r.kernel_ms)
+    med = float(np.median(t))
+    return {"note": "configs[1] strict: one acnqp_solve_batch call per 256-snapshot batch, end to end (H2D + kernel + D2H), "
+                    "nothing overlapped; includes the binding's result allocation",
+            "batch": batch.B, "calls": calls, "ms_per_call_median": 1e3 * med, "ms_per_call_min": 1e3 * float(np.min(t)),
+            "qps": batch.B / med, "kernel_ms_median": float(np.median(k))}
 
 
 def cpu_baseline_leg(batch, gpu_x, gpu_status, target_seconds, snaps, infra, iface, accel_mem=0):
@@ -191,7 +357,7 @@ def main():
     from adacharge_amd import ObjectiveComponent, equal_share, quick_charge, sites
     from adacharge_amd.acn import Interface
     from adacharge_amd.backend import SiteHandle, default_options, pinned_empty
-    from adacharge_amd.builder import build_batch, make_site
+    from adacharge_amd.builder import ProblemBatch, build_batch, make_site
 
     infra = sites.caltech54()
     iface = Interface({"infrastructure_info": infra, "period": 5})
@@ -290,7 +456,6 @@ def main():
     kernel_only = None
     if rank == 0:
         from adacharge_amd.backend import DeviceBatch
-        from adacharge_amd.builder import ProblemBatch
 
         dbig = DeviceBatch(ProblemBatch.concatenate(batches), dev)
         ms = []
@@ -309,9 +474,7 @@ def main():
         # roofline is stated per MEAN launch -- mean problems per launch over mean launch duration
         launch_b = per_step * args.steps / max(len(kernel_ms), 1)
         k_avg_ms = float(np.mean(kernel_ms))
-        k_sum_ms = float(np.sum(kernel_ms))
-        abytes, per_qp, site_bytes = algorithmic_bytes(launch_b, N, Tm, K, batch.site)
-        achieved = abytes / (k_avg_ms * 1e-3) / 1e9
+        _, per_qp, _ = algorithmic_bytes(launch_b, N, Tm, K, batch.site)
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tfile):   # committed result of the separate rocprofv3 --pmc passes (same command)
@@ -321,9 +484,17 @@ def main():
                 traffic = tj["hbm_bytes_per_problem"] * launch_b if tj.get("hbm_bytes_per_problem") else tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        fl = flops_per_iteration(N, Tm, batch.site)
-        valu_peak = FP64_VALU_PEAK_TF if args.precision == 64 else 157.3
-        valu_tf = float(iters_all.mean()) * per_step * args.steps * fl / elapsed / 1e12
+        fl_dense = flops_per_iteration(N, Tm, batch.site)
+        whole = ProblemBatch.concatenate(batches)
+        fl_sparse = flops_per_iteration_sparse(whole)
+        it_sum = float(iters_all.sum())
+        # the dominant kernel is timed WITHOUT neighbours: one launch over the step's problems (kernel_only, HIP events on
+        # the launch stream); the pipelined launches of the timed region overlap on four streams, so their durations
+        # include the CUs they cede to each other and are reported beside it (pipelined_*)
+        lone_ms = kernel_only["launch_ms"]
+        abytes1, _, _ = algorithmic_bytes(per_step, N, Tm, K, batch.site)
+        tf_sparse = it_sum * fl_sparse / (lone_ms * 1e-3) / 1e12
+        tf_dense = it_sum * fl_dense / (lone_ms * 1e-3) / 1e12
         host_bytes = per_step * (per_qp - 0)   # H2D of the inputs + D2H of the results = the algorithmic bytes per QP
         out = {
             "metric": "MPC QP solves/sec whole-node, 54 EVSE x horizon 12; max rate residual vs cvxpy",
@@ -349,18 +520,26 @@ def main():
                 "parallelism": f"dp{world} (own snapshots per GPU" + (", one RCCL all-gather of schedules per step)" if world > 1 else ")"),
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "acnqp::admm_tiled_kernel<%s, 4, 1, 1, 1, 2, 5>" % ("double" if args.precision == 64 else "float"),
-                "kernel_avg_ms": k_avg_ms, "launches_timed": len(kernel_ms), "problems_per_launch": launch_b,
-                "algorithmic_bytes_per_launch": abytes, "bytes_per_qp": per_qp,
-                "note": "LDS/register-resident iterative solver: HBM is touched once per problem, so the HBM fraction is "
-                        "small by construction (SURVEY.md H8); launches of successive chunks overlap on the GPU, so a "
-                        "launch's duration includes the share of the CUs it cedes to its neighbours; `valu` is the roof that binds",
-            },
-            "valu": {
-                "achieved": valu_tf, "peak": valu_peak, "unit": "TFLOP/s", "frac": valu_tf / valu_peak,
-                "flops_per_iteration": fl, "iterations_mean": float(iters_all.mean()), "iterations_max": int(iters_all.max()),
+                # register / LDS-resident iterative solver: HBM is touched once per problem, so the roof that
+                # can bind is the fp64 arithmetic one (vector = matrix peak on MI355X); the HBM view is reported beside it
+                "bound": "mfma", "achieved": tf_sparse, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                "frac": tf_sparse / FP64_VALU_PEAK_TF,
+                "traffic": None if traffic is None else traffic / launch_b * per_step,
+                "kernel": "acnqp::admm_tiled_kernel<double, 4, 1, 1, 1, 2, 5>",
+                "launch_ms": lone_ms, "problems_per_launch": per_step,
+                "flops_per_iteration_sparse": fl_sparse, "flops_per_iteration_dense": fl_dense,
+                "achieved_dense_count": tf_dense, "frac_dense_count": tf_dense / FP64_VALU_PEAK_TF,
+                "iterations_mean": float(iters_all.mean()), "iterations_max": int(iters_all.max()),
+                "hbm": {"algorithmic_bytes_per_launch": abytes1, "bytes_per_qp": per_qp,
+                        "achieved_GBs": abytes1 / (lone_ms * 1e-3) / 1e9, "peak_GBs": HBM_PEAK_GBS,
+                        "frac": abytes1 / (lone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "traffic_bytes_per_launch": None if traffic is None else traffic / launch_b * per_step},
+                "pipelined": {"launches_timed": len(kernel_ms), "problems_per_launch_mean": launch_b, "kernel_avg_ms": k_avg_ms,
+                              "note": "launches of the timed region overlap on four streams: a launch's duration includes the "
+                                      "CUs it cedes to its neighbours"},
+                "note": "achieved = ALGORITHMIC flops (SURVEY.md 8d: 4 nnz(A) + 12 (n + m) + 4 Mg^2 T per iteration, sparse G) x "
+                        "iterations run / the duration of ONE non-overlapped launch over the step's problems; the dense count "
+                        "is what the MFMA chains execute (G and Q dense)",
             },
             "kernel_only": kernel_only,
             "pcie": {"host_bytes_per_step_per_gpu": int(host_bytes), "achieved_GBs_per_gpu": host_bytes * args.steps / elapsed / 1e9},
@@ -375,6 +554,9 @@ def main():
                                           accel_mem=handle.accel_columns(Tm, K, opts))
             out["cpu_baseline"] = cb
             out["parity"] = parity
+        if world == 1 and not args.no_other_configs:
+            out["strict_batch256"] = strict_batch256_leg(handle, batches[0], opts)
+            out["other_configs"] = other_configs_leg(dev)
         print(json.dumps(out), file=json_out, flush=True)
     if collective:
         dist.barrier()

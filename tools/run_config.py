@@ -1,17 +1,20 @@
 """One device-resident launch of a BASELINE.json configuration other than the bench's (profiling target):
 
-    python3 tools/run_config.py cfg2-caltech|cfg2-jpl|cfg4|cfg5|stress144 [batch]
+    python3 tools/run_config.py cfg2-caltech|cfg2-jpl|cfg3-site0|cfg3-site3|cfg5|stress144|cfg4 [scenarios]
 
-cfg2: horizon 24, batch 4096, fp64 (tiled kernel, two column tiles); cfg5: synthetic 512 EVSE x 48, load_flattening
-(large-site MFMA kernel); stress144: the reference's N = 54 x T = 144 stress LP shape (general-shape kernel).
-Prints one JSON line with the kernel's HIP-event duration, QP/s, iterations and the algorithmic bytes."""
+Everything but `cfg4` is one of bench.py's `other_configs` legs (bench.other_workloads: one definition for the driver's
+JSON line and for the profiles): cfg2 = horizon 24, batch 4096; cfg3-siteK = 1024 demand scenarios of one site of
+configs[3]; cfg5 = configs[4] shape (synthetic 512 EVSE x 48, load flattening with energy equalities, large-site MFMA
+kernel); stress144 = the reference's 54 x 144 stress shape (long-horizon kernel).  `cfg4` = all 8 sites of configs[3] one
+after the other on this GPU.  Prints one JSON line with the kernel's HIP-event duration, QP/s, iterations, algorithmic
+bytes / flops and the fractions of the roofs."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from adacharge_amd import ObjectiveComponent, equal_share, load_flattening, quick_charge, total_energy, sites
+from adacharge_amd import ObjectiveComponent, equal_share, quick_charge, sites
 from adacharge_amd.acn import Interface
 from adacharge_amd.backend import DeviceBatch, SiteHandle, default_options
-from adacharge_amd.builder import ProblemBatch, build_batch, scenario_batch
+from adacharge_amd.builder import build_batch, scenario_batch
 
 which = sys.argv[1]
 reps = 3
@@ -41,54 +44,10 @@ if which == "cfg4":
         h.close()
     print(json.dumps(dict(config="cfg4", scenarios_per_site=S, problems=tot_n, kernel_ms_total=tot_ms, qps=tot_n / tot_ms * 1e3, sites=rows)))
     raise SystemExit(0)
-if which.startswith("cfg2"):
-    infra = sites.caltech54() if which.endswith("caltech") else sites.jpl52()
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-    iface = Interface({"infrastructure_info": infra, "period": 5})
-    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
-    batch = build_batch(sites.snapshot_batch(infra, 24, B, seed=31), infra, iface, obj, "SOC")
-    opts = default_options()
-elif which == "cfg5":
-    infra = sites.synth512()
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-    iface = Interface({"infrastructure_info": infra, "period": 5})
-    T = 48
-    ext = 150.0 + 100.0 * np.cos(np.arange(T) / T * 2 * np.pi)
-    obj = [ObjectiveComponent(load_flattening, 1.0, {"external_signal": ext}), ObjectiveComponent(total_energy, 600.0),
-           ObjectiveComponent(equal_share, 1e-3)]
-    base = build_batch(sites.snapshot_batch(infra, T, 8, seed=512, min_sessions=200), infra, iface, obj, "SOC")
-    rng = np.random.default_rng(0)
-    batch = ProblemBatch.concatenate([scenario_batch(base, rng.lognormal(0, 0.25, size=B // 8), problem=p) for p in range(8)])
-    opts = default_options(eps_abs=1e-6, eps_rel=1e-6)
-elif which == "stress144":
-    infra = sites.caltech54()
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-    iface = Interface({"infrastructure_info": infra, "period": 5})
-    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
-    batch = build_batch(sites.snapshot_batch(infra, 144, B, seed=144, demand_range=(5.0, 60.0)), infra, iface, obj, "SOC")
-    opts = default_options()
-else:
+ALIASES = {"cfg2-caltech": "cfg2_caltech54_T24_b4096", "cfg2-jpl": "cfg2_jpl52_T24_b4096", "cfg5": "cfg4_synth512_T48_b2048",
+           "stress144": "stress_caltech54_T144_b256", "cfg3-site3": "cfg3_site3_T12_b1024", "cfg3-site0": "cfg3_site0_T12_b1024"}
+import bench   # the workloads are bench.py's `other_configs` legs (one definition for the driver's line and the profiles)
+name = ALIASES.get(which, which)
+if name not in bench.other_workloads():
     raise SystemExit(__doc__)
-h = SiteHandle(batch.site, 0)
-dev = DeviceBatch(batch, "cuda:0")
-st = torch.cuda.current_stream().cuda_stream
-ms = []
-for _ in range(reps):
-    h.solve_device(dev, opts, stream=st)
-    torch.cuda.synchronize()
-    ms.append(h.last_kernel_ms())
-it = dev.iters.cpu().numpy(); s = dev.status.cpu().numpy()
-N, Tm, K = batch.N, batch.Tm, batch.K
-n = N * Tm
-per_qp_io = 8 * 4 * n + 16 * K * N + 45
-out = dict(config=which, batch=batch.B, n_evse=N, horizon=Tm, site_rows=batch.site.Mg, kernel_ms=min(ms), qps=batch.B / min(ms) * 1e3,
-           iters_mean=float(it.mean()), iters_max=int(it.max()), solved=int((s == 1).sum()), inaccurate=int((s == 5).sum()),
-           anderson_columns=h.accel_columns(Tm, K, opts), io_bytes_per_qp=per_qp_io)
-if which == "cfg5":   # streamed state: SURVEY 8d B_iter = w (3 n + 6 m), m = n + S + R + K rows
-    S_rows = int((batch.s_len[0] > 0).sum()); R = 2 * batch.site.M * Tm
-    b_iter = 8 * (3 * n + 6 * (n + S_rows + R))
-    kernel_iter = 9 * 8 * (16 * ((N + 15) // 16)) * (16 * ((Tm + 15) // 16))   # what the kernel moves: 9 padded arrays
-    alg = batch.B * (per_qp_io + float(it.mean()) * b_iter)
-    out.update(b_iter_bytes=b_iter, kernel_stream_bytes_per_iter=kernel_iter, algorithmic_bytes_per_launch=alg,
-               achieved_GBs=alg / (min(ms) * 1e-3) / 1e9, hbm_frac_of_8TBs=alg / (min(ms) * 1e-3) / 8e12)
-print(json.dumps(out))
+print(json.dumps({name: bench.other_configs_leg(torch.device("cuda", 0), only=[name])[name]}))
