@@ -23,7 +23,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libacn_qp_hip.so")
 UNITS = ("acn_qp_api", "acn_qp_tiled_ct1", "acn_qp_tiled_ct2", "acn_qp_stream", "acn_qp_long", "acn_qp_general")
 SOURCES = [os.path.join(CSRC, u + ".hip") for u in UNITS]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans", "-mno-amdgpu-ieee", "-ffp-contract=on", "-fPIC"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans", "-mno-amdgpu-ieee", "-fPIC"]
 
 _INCLUDE = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
 

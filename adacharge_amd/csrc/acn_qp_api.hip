@@ -125,11 +125,33 @@ struct acnqp_handle {
   struct Slot { hipStream_t st = nullptr; DevBuf in, out; } slot[kSlots];
   // workspaces of the general-shape kernel, one per launch stream: launches on different streams never share
   // (or regrow) each other's state, and a stream's own launches are ordered by the stream
-  std::vector<std::pair<hipStream_t, DevBuf>> work;
+  struct Work { hipStream_t st; DevBuf buf; long long used; };
+  std::vector<Work> work;
+  long long work_clock = 0;
+  static constexpr size_t kMaxCallerWorkspaces = 4;   // beyond the handle's own kSlots streams
   DevBuf* workspace_for(hipStream_t st) {
-    for (auto& w : work) if (w.first == st) return &w.second;
-    work.emplace_back(st, DevBuf());
-    return &work.back().second;
+    for (auto& w : work) if (w.st == st) { w.used = ++work_clock; return &w.buf; }
+    // a caller that keeps creating streams must not grow the handle without bound: evict the least recently used
+    // workspace of a caller stream (after the device has drained: that stream may be gone)
+    bool own = false;
+    for (auto& sl : slot) own = own || sl.st == st;
+    if (!own) {
+      size_t callers = 0, lru = work.size();
+      for (size_t k = 0; k < work.size(); ++k) {
+        bool mine = false;
+        for (auto& sl : slot) mine = mine || sl.st == work[k].st;
+        if (mine) continue;
+        ++callers;
+        if (lru == work.size() || work[k].used < work[lru].used) lru = k;
+      }
+      if (callers >= kMaxCallerWorkspaces) {
+        (void)hipDeviceSynchronize();
+        work[lru].buf.release();
+        work.erase(work.begin() + (long)lru);
+      }
+    }
+    work.push_back(Work{st, DevBuf(), ++work_clock});
+    return &work.back().buf;
   }
 };
 
@@ -278,19 +300,20 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
   return ACNQP_OK;
 }
 
-// shapes the register-resident tiled kernel takes; everything else runs through the general-shape kernel
-// Small problems with two column tiles AND two row tiles (horizon 17 ... 32 on a site of 17 ... 32 padded rows, e.g. the
-// synthetic JPL site at horizon 24 of configs[2]) run through the LDS-resident variant of the long-horizon kernel: the
-// register-resident kernel replicates the site-row state in every wave and spills 359+ registers at that shape
-// (measured on 4,096 jpl52 x 24 problems: 189 ms tiled, 128 ms here; every other small shape is faster tiled).
-// ACNQP_LDS_LONG=0 switches it off (diagnostic).
+// Shapes the register-resident tiled kernel takes: N <= 64, one column tile with any number of row tiles, or two
+// column tiles with ONE row tile.  Two column tiles x two / three row tiles (horizon 17 ... 32 on a site of more than 16
+// padded rows, e.g. the synthetic JPL site at horizon 24 of configs[2]) are not register-resident -- every wave would
+// carry the whole site-row state redundantly (430-1,100 spilled registers; those instantiations are gone): two row
+// tiles run through the LDS-resident variant of the long-horizon kernel (measured on 4,096 jpl52 x 24 problems: 189 ms
+// tiled, 70 ms there), or its workspace variant with a demand-charge row / ACNQP_LDS_LONG=0 (diagnostic); three row
+// tiles through the general-shape kernel.
 static bool lds_long_shape(const acnqp_handle* h, int t_max) {
   const char* e = std::getenv("ACNQP_LDS_LONG");
   if (e && std::atoi(e) == 0) return false;
   return h->N <= 64 && t_max > 16 && t_max <= 32 && !h->has_max && h->dev64.MR == 32;
 }
 static bool tiled_shape(const acnqp_handle* h, int t_max, int k_sessions) {
-  if (lds_long_shape(h, t_max)) return false;
+  if (t_max > 16 && h->dev64.MR > 16) return false;   // two column tiles x two / three row tiles: not register-resident
   return h->N <= 64 && t_max <= 32 && k_sessions <= acnqp::kMaxK;
 }
 
@@ -398,9 +421,12 @@ void acnqp_destroy(acnqp_handle* h) {
     sl.in.release();
     sl.out.release();
   }
-  for (auto& w : h->work) w.second.release();
+  for (auto& w : h->work) w.buf.release();
   delete h;
 }
+
+// doubles of per-problem workspace the kernel that serves this shape needs (0: register / LDS resident)
+static long long workspace_doubles(const acnqp_handle* h, int t_max, int k_sessions, int accel_req);
 
 static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, const acnqp_options* o,
                                 const acnqp_results* r) {
@@ -490,11 +516,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   } else if (!tiled) {
     // general-shape fallback: state streamed through a global workspace (not graph-capturable: it may allocate)
     const size_t rsz = 8;
-    const long long n = (long long)h->N * p->t_max, mt = (long long)d->MR * p->t_max;
-    const int gm = std::min(a.accel_mem, acnqp::kGenAccelMax);
-    const long long Dn = n + mt;
-    // solver state, the certificate's dual snapshot, the Anderson vectors (u, f: reals; correction and rings: floats)
-    ga.ws_per_problem = 7 * n + 8 * mt + 3LL * p->k_sessions * h->N + 8 + 2 * Dn + ((1 + 2LL * gm) * Dn * 4 + (long long)rsz - 1) / (long long)rsz + 2;
+    ga.ws_per_problem = workspace_doubles(h, p->t_max, p->k_sessions, a.accel_mem);
     DevBuf* wsb = h->workspace_for(st);
     const size_t need = (size_t)ga.ws_per_problem * p->batch * rsz;
     if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));   // an earlier launch on this stream may still use the old buffer
@@ -525,6 +547,18 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   HIP_TRY(hipEventRecord(h->ev_stop[evk], st));
   ++h->launches;
   return ACNQP_OK;
+}
+
+static long long workspace_doubles(const acnqp_handle* h, int t_max, int k_sessions, int accel_req) {
+  const SiteDev* d = &h->dev64;
+  if (tiled_shape(h, t_max, k_sessions)) return 0;
+  if (stream_shape(h, t_max)) return acnqp::stream_workspace(h->NP, (t_max + 15) / 16, k_sessions, d->MR / 16);
+  if (long_shape(h, t_max, k_sessions))
+    return acnqp::long_workspace(h->NP, acnqp::long_tiles(t_max), k_sessions, d->MR / 16, std::min(std::max(0, accel_req), acnqp::kLongAccelMax));
+  const long long n = (long long)h->N * t_max, mt = (long long)d->MR * t_max, Dn = n + mt;
+  const int gm = std::min(std::max(0, accel_req), acnqp::kGenAccelMax);
+  // solver state, the certificate's dual snapshot, the Anderson vectors (u, f: reals; correction and rings: floats)
+  return 7 * n + 8 * mt + 3LL * k_sessions * h->N + 8 + 2 * Dn + ((1 + 2LL * gm) * Dn * 4 + 7) / 8 + 2;
 }
 
 int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, int32_t precision, int32_t requested) {
@@ -607,6 +641,9 @@ struct ChunkLayout {
   }
 };
 
+// per_problem_bytes: inputs + results staged per problem AND the kernel's per-problem workspace (the long-horizon and
+// large-site kernels keep their iterates there: 1.6 MB per problem at 54 x 144, far more than the inputs) -- every one
+// of the kSlots pipeline slots holds a chunk of each, so a chunk is capped at 1 GiB of the sum
 long long chunk_problems(size_t per_problem_bytes) {
   long long want = 2048;   // problems per launch: large enough that the launch tail (its slowest problems) is short
   if (const char* e = std::getenv("ACNQP_CHUNK")) { const long long v = std::atoll(e); if (v > 0) want = v; }
@@ -632,7 +669,8 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
       if (chunks.empty() || (int)Tm != cur_T || (int)K != cur_K || opt != cur_opt || fill >= cap) {
         chunks.emplace_back();
         cur_T = (int)Tm; cur_K = (int)K; cur_opt = opt; fill = 0;
-        cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96);
+        cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96 +
+                             (size_t)workspace_doubles(h, (int)Tm, (int)K, o->accel_mem) * 8);
         // ramp: the first kernel cannot start before its chunk's H2D has landed, and nothing overlaps that copy -- a
         // quarter-size first chunk (then a half-size one) shortens the exposed head of the pipeline
         static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;

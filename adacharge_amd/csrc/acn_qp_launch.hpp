@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "acn_qp_tiled.hpp"
 #include "acn_qp_general.hpp"

@@ -32,7 +32,8 @@ hipError_t launch_tiled(TiledArgs a, int requested_accel, hipStream_t st) {
   a.accel_mem = std::min(requested_accel, cap1);
   a.pbuf_single = 0;
   if constexpr (CT == 1 && MT <= 2 && KS == 1) {
-    if (a.accel_mem <= accel_capacity(NW, MT, CT, a.NP, a.K, 2))
+    static const bool occ1 = std::getenv("ACNQP_OCC1") != nullptr;   // diagnostic: the one-workgroup-per-CU build
+    if (!occ1 && a.accel_mem <= accel_capacity(NW, MT, CT, a.NP, a.K, 2))
       return launch_tiled_occ<NW, CT, MT, KS, 2>(a, st);
   }
   a.pbuf_single = (a.accel_mem > accel_capacity(NW, MT, CT, a.NP, a.K, 1, 0)) ? single : 0;

@@ -62,3 +62,67 @@ def solve_sharded(
          for r in range(world)]
     )
     return xg[keep], sg[keep]
+
+
+def site_major_layout(batch_sizes: Sequence[int]):
+    """Problem offsets of a site-major job (BASELINE.json configs[3]: S demand scenarios x K sites, all problems of
+    site k contiguous): ``offsets[k] .. offsets[k + 1]`` are site k's problems."""
+    off = np.zeros(len(batch_sizes) + 1, dtype=np.int64)
+    np.cumsum(np.asarray(batch_sizes, np.int64), out=off[1:])
+    return off
+
+
+def solve_sites_sharded(site_batches, solve_site: Callable = None, options=None, group=None, device=None, local_device: int = 0):
+    """configs[3] as a sharded job: ``site_batches[k]`` is the ProblemBatch of site k (its own site matrix and EVSE
+    count, one horizon for all).  The job's problems are ordered site-major and cut into contiguous rank shards
+    (``shard_range``): with as many ranks as sites every rank owns exactly one site and its site matrix stays resident
+    on that GPU; with fewer ranks a rank owns several whole or partial sites, each through its own ``SiteHandle``.
+    No collective on the data path; ONE all-gather of the schedules, padded to the widest site (N_max) so that every
+    rank ends with ``x (total, N_max, Tm)`` and ``status (total,)``.
+
+    ``solve_site(k, sub_batch) -> (x (n, N_k, Tm), status (n,))`` (tensors on the collective's device, or arrays);
+    default: the HIP path -- ``acnqp_solve_batch_device`` on HBM-resident buffers of GPU ``local_device``, the result
+    tensor going into the all-gather as it is."""
+    import torch
+
+    sizes = [b.B for b in site_batches]
+    off = site_major_layout(sizes)
+    n_max = max(b.N for b in site_batches)
+    t_max = max(b.Tm for b in site_batches)
+    handles = {}
+
+    def hip_site(k, sub):
+        from .backend import DeviceBatch, SiteHandle, default_options
+
+        if k not in handles:
+            handles[k] = SiteHandle(sub.site, local_device)
+        dev = DeviceBatch(sub, torch.device("cuda", local_device))
+        handles[k].solve_device(dev, options if options is not None else default_options(),
+                                stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return dev.x, dev.status
+
+    solve_site = solve_site or hip_site
+
+    def solve_local(lo, hi):
+        xs, ss = [], []
+        for k, b in enumerate(site_batches):
+            a, e = max(lo, int(off[k])), min(hi, int(off[k + 1]))
+            if a >= e:
+                continue
+            x, st = solve_site(k, b.subset(slice(a - int(off[k]), e - int(off[k]))))
+            x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x))
+            st = st if torch.is_tensor(st) else torch.from_numpy(np.ascontiguousarray(st))
+            pad = torch.zeros((e - a, n_max, t_max), dtype=torch.float64, device=x.device)
+            pad[:, : x.shape[1], : x.shape[2]] = x
+            xs.append(pad)
+            ss.append(st.to(torch.int32))
+        if not xs:
+            return np.zeros((0, n_max, t_max)), np.zeros(0, np.int32)
+        return torch.cat(xs), torch.cat(ss)
+
+    try:
+        return solve_sharded(int(off[-1]), solve_local, group=group, device=device)
+    finally:
+        for h in handles.values():
+            h.close()

@@ -530,3 +530,27 @@ def solve_certified(prob, tol=1e-9, verbose=False):
     if cert.worst < 1e-7:
         return prob.rates_of(r1), res, cert
     return r0, res, cert
+
+
+def aggregate_range_on_optimal_face(prob, fstar, t, rel=1e-8):
+    """ORACLE (test infrastructure).  quick_charge's cost depends only on the per-period aggregates, and its weights
+    (T - t) / T are equally spaced: moving one ampere one period earlier gains 1 / T wherever it happens, so the optimal
+    FACE of the LP often spans a range of aggregates in a given period (SURVEY.md H2 assumed the aggregate unique; it is
+    only so on instances like KAT-4).  Returns (min, max) of sum_i x[i, t] over {x feasible, q'x <= fstar + rel |fstar|},
+    two HiGHS solves: the yardstick for "which optimal point did the regularised solver pick"."""
+    from scipy.optimize import linprog
+    import scipy.sparse as sp
+
+    assert not prob.soc
+    N, T = prob.N, prob.T
+    e = np.zeros((N, T))
+    e[:, t] = 1.0
+    A = sp.vstack([prob.A_ub, sp.csr_matrix(prob.q.reshape(1, -1))]).tocsr()
+    b = np.concatenate([prob.b_ub, [fstar + rel * abs(fstar)]])
+    out = []
+    for sign in (1.0, -1.0):
+        r = linprog(sign * e.reshape(-1), A_ub=A, b_ub=b, A_eq=prob.A_eq if prob.A_eq.shape[0] else None,
+                    b_eq=prob.b_eq if prob.A_eq.shape[0] else None, bounds=(None, None), method="highs")
+        assert r.status == 0, r.message
+        out.append(sign * r.fun)
+    return out[0], out[1]

@@ -803,10 +803,12 @@ def test_long_horizon_kernel_many_sessions_per_evse_and_warm_start():
     h.close()
 
 
-def test_long_horizon_kernel_same_bits_with_arrays_in_lds_or_workspace(tmp_path):
+def test_long_horizon_kernel_same_answer_with_arrays_in_lds_or_workspace(tmp_path):
     """Where the r0 / zh array (and x, up to 96 periods) lives -- LDS or the workspace -- is a placement, not an
-    algorithm: a child process with ACNQP_NO_RZL=1 (read once per process) must return the same iterations and the
-    same bits."""
+    algorithm: a child process with ACNQP_NO_RZL=1 (read once per process) must return the same statuses and the same
+    optimum.  (Round 2 asserted the same BITS; the two placements are two template instantiations, and which a * b + c
+    the compiler contracts into an fma is its choice per instantiation -- forcing -ffp-contract=on to pin that down
+    changed trajectories everywhere, so the claim is the optimum, not the rounding.)"""
     import subprocess
     import sys
 
@@ -823,7 +825,7 @@ def test_long_horizon_kernel_same_bits_with_arrays_in_lds_or_workspace(tmp_path)
         "for T in (96, 144):\n"
         "    batch = build_batch(sites.snapshot_batch(infra, T, 4, seed=100 + T, demand_range=(5.0, 60.0)), infra, iface, obj, 'SOC')\n"
         "    h = SiteHandle(batch.site, 0); r = h.solve(batch, default_options()); h.close()\n"
-        "    out['x%%d' %% T] = r.x; out['it%%d' %% T] = r.iters\n"
+        "    out['x%%d' %% T] = r.x; out['it%%d' %% T] = r.iters; out['st%%d' %% T] = r.status\n"
         "np.savez(sys.argv[1], **out)\n"
     ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     files = {}
@@ -833,8 +835,9 @@ def test_long_horizon_kernel_same_bits_with_arrays_in_lds_or_workspace(tmp_path)
         subprocess.run([sys.executable, "-c", code, files[tag]], check=True, env=e, timeout=600)
     a, b = np.load(files["lds"]), np.load(files["ws"])
     for T in (96, 144):
-        assert np.array_equal(a[f"it{T}"], b[f"it{T}"])
-        assert np.array_equal(a[f"x{T}"], b[f"x{T}"])
+        assert np.array_equal(a[f"st{T}"], b[f"st{T}"]) and (a[f"st{T}"] == 1).all()
+        assert np.abs(a[f"x{T}"] - b[f"x{T}"]).max() <= 1e-5
+        assert np.abs(a[f"it{T}"] - b[f"it{T}"]).max() <= 0.5 * a[f"it{T}"].max()
 
 
 @pytest.mark.parametrize("ct", ["LINEAR", "SOC"])
@@ -1028,3 +1031,62 @@ def test_two_ranks_shard_a_batch_and_gather_the_schedules():
         assert x.shape == (24, 54, 12) and (st == 1).all()
         # a problem's result does not depend on what it is batched with: bitwise the single-process answer
         assert np.array_equal(x[:, :, : batch.Tm], whole.x)
+
+
+# ---- BASELINE.json configs[3] as a SHARDED job: site-major, one SiteHandle per site a rank owns -----------------------
+def _cfg3_site_batches(n_sites=4, scenarios=48):
+    from adacharge_amd.acn import Interface
+    from adacharge_amd.builder import scenario_batch
+
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    out = []
+    for k, infra in enumerate(sites.eight_sites()[:n_sites]):   # 54, 52, 30, 36 EVSEs: ragged widths
+        iface = Interface({"infrastructure_info": infra, "period": 5})
+        rng = np.random.default_rng(500 + k)
+        base = build_batch([sites.random_sessions(infra, 12, rng)], infra, iface, obj, "SOC")
+        out.append(scenario_batch(base, rng.lognormal(0.0, 0.25, size=(scenarios, base.K, base.N))))
+    return out
+
+
+def _cfg3_rank(rank, world, port, q):
+    import torch.distributed as dist
+
+    from adacharge_amd.distributed import solve_sites_sharded
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x, st = solve_sites_sharded(_cfg3_site_batches(), device="cpu")   # HIP path per site; x leaves HBM for the gloo gather
+    q.put((rank, x, st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_config4_as_a_sharded_job_two_ranks_times_two_sites():
+    """2 ranks x 2 sites on the one test GPU (gloo carries the all-gather): every rank ends with the whole job's
+    schedules, padded to the widest site, bitwise what the sites solved one after the other give."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 300
+    procs = [ctx.Process(target=_cfg3_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    batches = _cfg3_site_batches()
+    n_max = max(b.N for b in batches)
+    want, o = np.zeros((sum(b.B for b in batches), n_max, 12)), 0
+    for b in batches:
+        h = SiteHandle(b.site, 0)
+        r = h.solve(b, default_options())
+        h.close()
+        assert (r.status == 1).all()
+        want[o:o + b.B, : b.N, : b.Tm] = r.x
+        o += b.B
+    for rank, x, st in got:
+        assert x.shape == want.shape and (st == 1).all()
+        assert np.array_equal(x, want)
