@@ -809,11 +809,4 @@ void acnqp_host_free(void* p) {
   if (p) (void)hipHostFree(p);
 }
 
-#ifdef ACNQP_STAMPS
-/* diagnostic build only: copy the per-phase cycle counters to the host */
-int acnqp_debug_read_stamps(unsigned long long* out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(acnqp::g_stamps), sizeof(unsigned long long) * n);
-}
-#endif
-
 }  // extern "C"

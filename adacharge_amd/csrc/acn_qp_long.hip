@@ -92,3 +92,10 @@ hipError_t launch_long(const StreamArgs& sa, hipStream_t st, bool lds_resident) 
 }
 
 }  // namespace acnqp
+
+#ifdef ACNQP_STAMPS
+/* diagnostic build only: the long-horizon kernel's per-phase cycle counters (this unit's copy of g_stamps) */
+extern "C" int acnqp_debug_read_stamps_long(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(acnqp::g_stamps), sizeof(unsigned long long) * n);
+}
+#endif

@@ -461,15 +461,24 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     for (int k = 1; k < pass; ++k) rho *= (real)4;
   }
   real qnorm, pd;
+  bool plain_windows = false;   // KS == 1: every period outside the session window has lb = ub = 0 (what aco.py:61-79 builds)
   {
-    real f[3];
+    real f[4];
     f[0] = empty_set ? (real)1 : (real)0;
-    f[1] = 0; f[2] = 0;
+    f[1] = 0; f[2] = 0; f[3] = 0;
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { f[1] = fmax(f[1], fabs(qv[c][r])); f[2] = fmax(f[2], ubv[c][r]); }
-    block_max<real, 3>(f, Red, lane, wave, NW);
+    if constexpr (KS == 1) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+          if (!((swm[0] >> (4 * c + tt)) & 1u)) f[3] = fmax(f[3], fmax(fabs(slb[c][tt]), fabs(sub[c][tt])));
+    }
+    block_max<real, 4>(f, Red, lane, wave, NW);
+    plain_windows = KS == 1 && f[3] == (real)0;
     qnorm = f[1];
     // scale-free Tikhonov floor reg_rel * |q|_inf / (max(ub) * T_b), LP-like problems only (effective_pdiag)
     pd = effective_pdiag<real>(pd_user, (real)A.reg_rel, qnorm, f[2], A.horizon[b], lfb > (real)0 || dcb > (real)0);
@@ -605,19 +614,29 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
             st_acc[5] += 1000;   // diagnostic build: slot 5 counts water-filling passes (x1000)
 #endif
 
-            real gl = 0, lo_l = M::big, hi_l = -M::big;
+            real gl = 0;
             float nl = 0.f;
+            if (plain_windows) {   // block-uniform.  Outside the window lb = ub = 0: the clip is 0 and the period never
+                                   // counts as interior, so the sums need no window mask (same bits as the masked form)
 #pragma unroll
-            for (int c = 0; c < CT; ++c)
+              for (int c = 0; c < CT; ++c)
 #pragma unroll
-              for (int tt = 0; tt < 4; ++tt) {
-                const bool inw = (swm[k] >> (4 * c + tt)) & 1u;
-                const real v = szh[c][tt] - m;
-                gl += inw ? fmin(fmax(v, slb[c][tt]), sub[c][tt]) : (real)0;
-                nl += (inw && v > slb[c][tt] && v < sub[c][tt]) ? 1.f : 0.f;
-                lo_l = inw ? fmin(lo_l, szh[c][tt] - sub[c][tt]) : lo_l;
-                hi_l = inw ? fmax(hi_l, szh[c][tt] - slb[c][tt]) : hi_l;
-              }
+                for (int tt = 0; tt < 4; ++tt) {
+                  const real v = szh[c][tt] - m;
+                  gl += fmin(fmax(v, slb[c][tt]), sub[c][tt]);
+                  nl += ((v > slb[c][tt]) & (v < sub[c][tt])) ? 1.f : 0.f;
+                }
+            } else {
+#pragma unroll
+              for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                  const bool inw = (swm[k] >> (4 * c + tt)) & 1u;
+                  const real v = szh[c][tt] - m;
+                  gl += inw ? fmin(fmax(v, slb[c][tt]), sub[c][tt]) : (real)0;
+                  nl += (inw && v > slb[c][tt] && v < sub[c][tt]) ? 1.f : 0.f;
+                }
+            }
             const real gs = quarter_sum<real>(gl);
             const float nf = quarter_sum<float>(nl);
             const real d = gs - cap;
@@ -627,7 +646,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
             hi = (need && !(d > 0)) ? m : hi;
             // flat piece with an open bracket (rare): fetch the true bracket ends so the fallback bisects
             const bool open = need && nf <= 0.f && !(lo > -M::big && hi < M::big);
-            if (__any(open)) {
+            if (__any(open)) {   // the bracket ends are only ever needed here
+              real lo_l = M::big, hi_l = -M::big;
+#pragma unroll
+              for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                  const bool inw = (swm[k] >> (4 * c + tt)) & 1u;
+                  lo_l = inw ? fmin(lo_l, szh[c][tt] - sub[c][tt]) : lo_l;
+                  hi_l = inw ? fmax(hi_l, szh[c][tt] - slb[c][tt]) : hi_l;
+                }
               const real lo0 = quarter_min<real>(lo_l), hi0 = quarter_max<real>(hi_l);
               lo = open ? fmax(lo, lo0) : lo;
               hi = open ? fmin(hi, hi0) : hi;

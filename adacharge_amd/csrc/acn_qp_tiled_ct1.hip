@@ -12,3 +12,11 @@ hipError_t launch_tiled_ct1(const TiledArgs& a, hipStream_t st) {
 }
 
 }  // namespace acnqp
+
+#ifdef ACNQP_STAMPS
+/* diagnostic build only: copy the per-phase cycle counters of THIS translation unit's kernels (the headline shapes:
+ * one column tile) to the host -- every unit that includes acn_qp_tiled.hpp has its own g_stamps */
+extern "C" int acnqp_debug_read_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(acnqp::g_stamps), sizeof(unsigned long long) * n);
+}
+#endif

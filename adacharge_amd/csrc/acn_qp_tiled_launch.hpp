@@ -31,7 +31,10 @@ hipError_t launch_tiled(TiledArgs a, int requested_accel, hipStream_t st) {
   const int cap1 = accel_capacity_best(NW, MT, CT, a.NP, a.K, &single);
   a.accel_mem = std::min(requested_accel, cap1);
   a.pbuf_single = 0;
-  if constexpr (CT == 1 && MT <= 2 && KS == 1) {
+  // one column tile x one row tile x one session slot (the headline shape) is the only one whose five-column ring fits
+  // half the LDS; with two row tiles the ring needs the whole CU anyway, so that two-workgroup build (380 spilled
+  // registers) was never launched with the default options and is gone
+  if constexpr (CT == 1 && MT == 1 && KS == 1) {
     static const bool occ1 = std::getenv("ACNQP_OCC1") != nullptr;   // diagnostic: the one-workgroup-per-CU build
     if (!occ1 && a.accel_mem <= accel_capacity(NW, MT, CT, a.NP, a.K, 2))
       return launch_tiled_occ<NW, CT, MT, KS, 2>(a, st);

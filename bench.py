@@ -153,17 +153,18 @@ def other_workloads():
 
     def cfg4():
         # 512 EVSE x 48, load flattening of an external load profile with the sessions' energy DELIVERED (equalities,
-        # t_int.py:350-403 style): the site rows bind (utilisation 0.99-1.0) and the default tolerances need hundreds of
-        # iterations (round 2 timed a workload whose optimum was the all-zero schedule: 20 iterations, nothing binding)
+        # t_int.py:350-403 style): the site rows bind (utilisation 0.96-1.0, every scenario feasible: C twin) and the
+        # default tolerances need hundreds of iterations (round 2 timed a workload whose optimum was the all-zero
+        # schedule: 20 iterations, nothing binding)
         infra = sites.synth512()
         iface = Interface({"infrastructure_info": infra, "period": 5})
         T = 48
         ext = 150.0 + 100.0 * np.cos(np.arange(T) / T * 2 * np.pi)
         obj = [ObjectiveComponent(load_flattening, 1.0, {"external_signal": ext})]
         rng = np.random.default_rng(5)
-        snaps = [sites.random_sessions_general(infra, T, rng, False, False, demand_scale=0.15) for _ in range(8)]
+        snaps = [sites.random_sessions_general(infra, T, rng, False, False, demand_scale=0.12) for _ in range(8)]
         base = build_batch(snaps, infra, iface, obj, "SOC", True)
-        batch = ProblemBatch.concatenate([scenario_batch(base, rng.lognormal(0.0, 0.1, size=256), problem=p) for p in range(8)])
+        batch = ProblemBatch.concatenate([scenario_batch(base, rng.lognormal(0.0, 0.05, size=256), problem=p) for p in range(8)])
         return batch, default_options(), True, "configs[4] shape: synthetic 512 EVSE x 48, load_flattening + energy equalities, 8 snapshots x 256 demand scenarios, default tolerances"
 
     def stress144():

@@ -836,7 +836,7 @@ def test_long_horizon_kernel_same_answer_with_arrays_in_lds_or_workspace(tmp_pat
     a, b = np.load(files["lds"]), np.load(files["ws"])
     for T in (96, 144):
         assert np.array_equal(a[f"st{T}"], b[f"st{T}"]) and (a[f"st{T}"] == 1).all()
-        assert np.abs(a[f"x{T}"] - b[f"x{T}"]).max() <= 1e-5
+        assert np.abs(a[f"x{T}"] - b[f"x{T}"]).max() <= RATE_TOL   # LP-like problems: the split is pinned by the Tikhonov floor only
         assert np.abs(a[f"it{T}"] - b[f"it{T}"]).max() <= 0.5 * a[f"it{T}"].max()
 
 

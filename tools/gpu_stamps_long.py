@@ -21,7 +21,7 @@ for T in [int(x) for x in os.environ.get("HORIZONS", "48,144,288").split(",")]:
     res = h.solve(batch, default_options(accel_mem=int(os.environ.get("AA", "5"))))
     lib = load_library()
     buf = (C.c_ulonglong * (1024 * 16 * 12))()
-    lib.acnqp_debug_read_stamps(buf, 1024 * 16 * 12)
+    lib.acnqp_debug_read_stamps_long(buf, 1024 * 16 * 12)
     nw = 8
     NS = min(NB, 1024)   # the stamp buffer covers the first 1024 workgroups
     st = np.array(buf, dtype=np.float64).reshape(1024, 16, 12)[:NS, :nw]
