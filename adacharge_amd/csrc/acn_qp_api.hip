@@ -317,9 +317,9 @@ static bool tiled_shape(const acnqp_handle* h, int t_max, int k_sessions) {
   return h->N <= 64 && t_max <= 32 && k_sessions <= acnqp::kMaxK;
 }
 
-// shapes the large-site MFMA kernel takes (acn_qp_stream.hpp): wide sites, up to three column tiles, no demand-charge row
+// shapes the large-site MFMA kernel takes (acn_qp_stream.hpp): wide sites, up to three column tiles
 static bool stream_shape(const acnqp_handle* h, int t_max) {
-  return h->N > 64 && t_max <= 48 && !h->has_max;
+  return h->N > 64 && t_max <= 48;
 }
 
 // shapes the long-horizon MFMA kernel takes (acn_qp_long.hpp): what the two kernels above leave, up to 288 periods
@@ -495,13 +495,13 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   if (stream) {
     // large-site kernel: iterates streamed through a per-problem workspace in MFMA fragment order
     const int CT = (p->t_max + 15) / 16;
-    sa.ws_per_problem = acnqp::stream_workspace(h->NP, CT, p->k_sessions, d->MR / 16);
+    a.accel_mem = std::min(a.accel_mem, acnqp::kStreamAccelMax);
+    sa.ws_per_problem = acnqp::stream_workspace(h->NP, CT, p->k_sessions, d->MR / 16, a.accel_mem);
     DevBuf* wsb = h->workspace_for(st);
     const size_t need = (size_t)sa.ws_per_problem * p->batch * sizeof(double);
     if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(wsb->reserve(need));
     sa.work = static_cast<double*>(wsb->p);
-    a.accel_mem = 0;
     sa.t = a;
   } else if (lng) {
     // long-horizon kernel: same workspace idea, one more array (r0 / zh)
@@ -552,7 +552,8 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
 static long long workspace_doubles(const acnqp_handle* h, int t_max, int k_sessions, int accel_req) {
   const SiteDev* d = &h->dev64;
   if (tiled_shape(h, t_max, k_sessions)) return 0;
-  if (stream_shape(h, t_max)) return acnqp::stream_workspace(h->NP, (t_max + 15) / 16, k_sessions, d->MR / 16);
+  if (stream_shape(h, t_max))
+    return acnqp::stream_workspace(h->NP, (t_max + 15) / 16, k_sessions, d->MR / 16, std::min(std::max(0, accel_req), acnqp::kStreamAccelMax));
   if (long_shape(h, t_max, k_sessions))
     return acnqp::long_workspace(h->NP, acnqp::long_tiles(t_max), k_sessions, d->MR / 16, std::min(std::max(0, accel_req), acnqp::kLongAccelMax));
   const long long n = (long long)h->N * t_max, mt = (long long)d->MR * t_max, Dn = n + mt;
@@ -565,7 +566,7 @@ int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, 
   if (!h || t_max < 1 || k_sessions < 1 || requested <= 0) return 0;
   if (precision != 64) return 0;
   if (!tiled_shape(h, t_max, k_sessions)) {
-    if (stream_shape(h, t_max)) return 0;                // large-site kernel: plain ADMM
+    if (stream_shape(h, t_max)) return std::min(requested, acnqp::kStreamAccelMax);   // ring in its workspace
     if (long_shape(h, t_max, k_sessions)) return std::min(requested, acnqp::kLongAccelMax);   // ring in its workspace
     return std::min(requested, acnqp::kGenAccelMax);     // general-shape kernel: ring in its workspace
   }

@@ -21,8 +21,12 @@
 // reduction, and a fixed summation order (deterministic).  The <= 48 x 48 site-row state (z2, y2, G x, e^, h^)
 // lives in LDS and is advanced by the same owner waves.
 //
-// Not in this kernel (the general-shape kernel keeps them): Anderson acceleration, the infeasibility certificate,
-// the demand-charge row.  acn_qp_api.hip routes accordingly.
+// Anderson acceleration (type II, the other kernels' rule: an event every fifth iteration, ring and u / f / g in the
+// workspace): an event iteration splits the fused pass in two -- pass A computes every tile's pre-projection point,
+// stores it and accumulates the event's dot products; after the block-wide reduction and the small solve, pass B
+// extrapolates the stored points and runs the projection / y1 / new r0 half of the fused pass (eleven more array passes
+// per event, i.e. +25 % bytes per iteration on average, for 2-3x fewer iterations on congested problems).  The primal
+// infeasibility certificate and the demand-charge row (one wave, after the site tiles) are the long-horizon kernel's.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -41,10 +45,14 @@ struct StreamArgs {
   long long ws_per_problem;
 };
 
-// doubles of workspace one problem needs
-__host__ __device__ inline long long stream_workspace(int NP, int CT, int K, int MT) {
-  const long long NT = (long long)(NP / 16) * CT * 256;
-  return 6 * NT + (long long)K * NP + 3LL * MT * CT * 256 + 64;
+constexpr int kStreamAccelMax = 5;   // Anderson columns (the ring lives in the workspace)
+
+// doubles of workspace one problem needs (accel = Anderson columns in use)
+__host__ __device__ inline long long stream_workspace(int NP, int CT, int K, int MT, int accel) {
+  const long long NT = (long long)(NP / 16) * CT * 256, MS = (long long)MT * CT * 256, DU = NT + MS;
+  long long w = 6 * NT + (long long)K * NP + 3 * MS + (DU + 1) / 2 + 64;   // + the certificate's dual snapshot (floats)
+  if (accel > 0) w += DU + 3 * DU + (2LL * accel * DU * 4 + 7) / 8;         // zh / zhr of the event; u, f, g; the float rings
+  return w;
 }
 
 // LDS carve-up (doubles)
@@ -86,6 +94,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   real* sm = reinterpret_cast<real*>(smem_raw);
   const StreamLds L(MT, CT, NWV);
+  constexpr int AMX = kStreamAccelMax;
+  __shared__ real AaRedS[NWV * (AMX + 2)];               // per-wave partial dot products of an Anderson event
+  __shared__ real AaHS[NWV * (AMX * AMX + AMX)];         // every wave's own copy of the Gram matrix and rhs
   real* RED = sm + L.red;
   real* G0H = sm + L.g0h;
   real* WE = sm + L.we;
@@ -128,6 +139,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   real* Z2 = MU + (size_t)K * NP;
   real* Y2 = Z2 + MT * CT * 256;
   real* GX = Y2 + MT * CT * 256;
+  const long long MS = (long long)MT * CT * 256, DU = NT + MS;
+  float* Y1P = reinterpret_cast<float*>(GX + MS);      // duals at the previous residual check (certificate), floats
+  float* Y2P = Y1P + NT;
+  const int aa_m = min(A.accel_mem, kStreamAccelMax);
+  // Anderson state (acn_qp_tiled.hpp): u = (zh of every EVSE tile, zhr of every site tile), index uo = tile index, the
+  // site part after the NT tile entries
+  real* ZHs = GX + MS + (DU + 1) / 2;                   // the event's pre-projection points: [NT] then [MS]
+  real* UP = ZHs + DU;                                  // u after the previous event
+  real* FP = UP + DU;                                   // f = g - u at the previous event
+  real* GP = FP + DU;                                   // g at the previous event
+  float* HF = reinterpret_cast<float*>(GP + DU);        // dF ring [aa_m][DU]
+  float* HG = HF + (size_t)aa_m * DU;                   // dG ring
   const real* FG = static_cast<const real*>(A.fragG);
   const real* FQ = static_cast<const real*>(A.fragQ);
   const real* Gm = static_cast<const real*>(A.G);
@@ -136,6 +159,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   const bool eq = A.s_eq[b] != 0;
   const real sigma = A.sigma, alpha = A.alpha;
   const real lfb = A.lf ? A.lf[b] / (A.flat_scale * A.flat_scale) : 0.0;
+  // demand charge (acn_qp_tiled.hpp): weight, floor and the padded index of the "max" row (uniform)
+  const real dcb = A.dc ? A.dc[b] / A.max_scale : 0.0;
+  const real dfl = A.dfloor ? A.dfloor[b] * A.max_scale : 0.0;
+  int jdc = -1;
+  if (dcb > 0.0)
+    for (int j = 0; j < 16 * MT; ++j) jdc = A.rowtype[j] == kRowMax ? j : jdc;
+  const bool dc_on = jdc >= 0;
 
   auto fidx = [&](int e, int c, int r) -> size_t { return ((size_t)(e * CT + c) * 4 + r) * 64 + lane; };
 
@@ -189,7 +219,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
     real f[3] = {qn, um, bad};
     stream_block_max<3, NWV>(f, SC, lane, wave);
     qnorm = f[0];
-    pd = effective_pdiag<real>(pd_user, A.reg_rel, qnorm, f[1], A.horizon[b], lfb > 0.0);
+    pd = effective_pdiag<real>(pd_user, A.reg_rel, qnorm, f[1], A.horizon[b], lfb > 0.0 || dcb > 0.0);
     if (f[2] > 0) {
       for (size_t k = tid; k < (size_t)N * Tm; k += kStreamWaves * 64) A.x[(size_t)b * N * Tm + k] = 0;
       if (A.y_out)
@@ -431,15 +461,201 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
     for (int k = 0; k < NOWN; ++k) pown[k] = pown[k] * a0;
   }
 
+  // u of the Anderson map from the current (z, y): after the start and after every rho change
+  auto reset_u = [&]() __attribute__((always_inline)) {
+    if (aa_m <= 0) return;
+    const real ir = 1.0 / rho;
+#pragma unroll 1
+    for (int e = wave; e < NE; e += kStreamWaves) {
+      RELANE();
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const size_t i = fidx(e, c, r); UP[i] = Z1s[i] + Y1s[i] * ir; }
+    }
+#pragma unroll 1
+    for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
+      RELANE();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int i = (tl * 4 + r) * 64 + lane; UP[NT + i] = Z2[i] + Y2[i] * ir; }
+    }
+  };
+  reset_u();
+
   int status = 2, it = 0, n_adapt = 0, best_it = 0;
   real best_score = M::big;
   real pri = M::big, dua = M::big;
-  bool done = false;
+  bool done = false, have_prev = false;
+  // Anderson state (block-uniform scalars, every wave keeps its own identical copy)
+  int aa_cnt = 0, aa_head = 0, aa_cool = 0, aa_pen = 1;
+  unsigned aa_valid = 0;
+  bool aa_have_prev = false, aa_was = false;
+  real fn_prev = 0;
+  real* AaH = AaHS + (size_t)wave * (AMX * AMX + AMX);
+  if (aa_m > 0)
+    for (int k = lane; k < AMX * AMX + AMX; k += 64) AaH[k] = 0;
+  real sv0 = 0, sv2 = 0;   // |G x - z2|_inf, max(|G x|, |z2|): the site-row share of the residuals, per iteration
+
+  // ---- projection of one site-row tile onto C from its pre-projection point: z2, y2, the tile's residual terms ------
+  auto site_project = [&](int mo, int c, const real (&zhr)[4], const real* RLi, const int32_t* RTi) __attribute__((always_inline)) {
+    const int tt = 16 * c + t;
+    real pk = M::big;
+    if (A.peak && tt < Tm) { const double pv = A.peak[(size_t)b * Tm + tt]; pk = pv < M::big ? pv * A.peak_scale : M::big; }
+    int ty[4];
+    real lim[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int j = 16 * mo + M::rowof(g, r); ty[r] = RTi[j]; lim[r] = RLi[j]; }
+    real scl[2] = {1.0, 1.0};
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+      if (ty[2 * pr] == kRowSocRe) {
+        const real re = zhr[2 * pr], im = zhr[2 * pr + 1];
+        const real n2 = re * re + im * im;
+        if (n2 > lim[2 * pr] * lim[2 * pr]) scl[pr] = lim[2 * pr] / sqrt(n2);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
+      real zn = zhr[r];
+      if (ty[r] == kRowBox) zn = fmin(zn, lim[r]);
+      else if (ty[r] == kRowPeak) zn = fmin(zn, pk);
+      else if (ty[r] == kRowQuad) zn = zn * (rho / (rho + lfb));
+      else if (ty[r] == kRowSocRe || ty[r] == kRowSocIm) zn = zn * scl[r >> 1];
+      // kRowMax: zn = zhr here; the horizon-wide prox (dc_row) follows once every column tile is through
+      Y2[i] = rho * (zhr[r] - zn);
+      Z2[i] = zn;
+      if (!(dc_on && ty[r] == kRowMax)) {
+        sv0 = fmax(sv0, fabs(GX[i] - zn));
+        sv2 = fmax(sv2, fmax(fabs(GX[i]), fabs(zn)));
+      }
+    }
+  };
+  // ---- demand charge (acn_qp_tiled.hpp): z_t = min(zh_t, max(tau, floor)), tau = root of sum_t (zh_t - tau)+ = dc / rho,
+  // over the whole horizon of the "max" row: ONE wave, after every site tile has left its pre-projection point of the
+  // row in Z2.  The row's periods are the 16 lanes of one lane group (g = jdc & 3) x the column tiles.
+  auto dc_row = [&]() __attribute__((always_inline)) {
+    const int mo = jdc >> 4, rr = jdc & 15, gd = rr & 3, rd_ = rr >> 2;   // rowof(g, r) = g + 4 r
+    real zv[CT], gxv[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) { const int i = ((mo * CT + c) * 4 + rd_) * 64 + lane; zv[c] = Z2[i]; gxv[c] = GX[i]; }
+    const real cw = dcb / rho;
+    real vmax_l = -M::big;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) vmax_l = (16 * c + t < Tm) ? fmax(vmax_l, zv[c]) : vmax_l;
+    const real vmax = row_max<real>(vmax_l);
+    real tau = vmax - cw;
+    bool need = g == gd;
+    int guard = 0;
+    while (__any(need)) {
+      ++guard;
+      real sl = 0, nl = 0;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const real dd = zv[c] - tau;
+        const bool on = (16 * c + t < Tm) && dd > 0.0;
+        sl += on ? dd : 0.0;
+        nl += on ? 1.0 : 0.0;
+      }
+      const real S = row_sum<real>(sl), nn = row_sum<real>(nl);
+      const real f = S - cw;
+      const real tn = nn > 0.0 ? tau + f / nn : vmax - cw;
+      const bool fin = fabs(f) <= M::proj_tol * fmax(1.0, cw) * 16.0 || tn == tau || guard > 200;
+      tau = (need && !fin) ? tn : tau;
+      need = need && !fin;
+    }
+    const real lev = fmax(tau, dfl);
+    if (g == gd) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int i = ((mo * CT + c) * 4 + rd_) * 64 + lane;
+        const real zn = (16 * c + t < Tm) ? fmin(zv[c], lev) : zv[c];
+        Y2[i] = rho * (zv[c] - zn);
+        Z2[i] = zn;
+        sv0 = fmax(sv0, fabs(gxv[c] - zn));
+        sv2 = fmax(sv2, fmax(fabs(gxv[c]), fabs(zn)));
+      }
+    }
+  };
+  // ---- the two halves of the fused tile pass.  front: load (x, z1, y1, q), r0, x~ (MFMA, e^ from LDS), relaxation ->
+  // the pre-projection point zh and sq = sigma x_new - q (all the new r0 still needs of x and q); x_new is stored.
+  auto tile_front = [&](int e, real inv_a, real inv_rho, real (&zh)[4][CT], real (&sq)[4][CT]) __attribute__((always_inline)) {
+    const real* fg = FG + (size_t)e * MT * 2 * 4 * 64;
+    real fx[MT][4];              // A fragments of the x~ product: requested with the state, used after it arrived
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) fx[m][s] = fg[((m * 2 + 1) * 4 + s) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      real xv[4], z1o[4], y1o[4], qv[4];
+      vec4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t i = fidx(e, c, r);
+        xv[r] = __builtin_nontemporal_load(&Xs[i]); z1o[r] = __builtin_nontemporal_load(&Z1s[i]); y1o[r] = __builtin_nontemporal_load(&Y1s[i]); qv[r] = __builtin_nontemporal_load(&Qs[i]);
+        acc[r] = sigma * xv[r] - qv[r] + rho * z1o[r] - y1o[r];
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          acc = M::mma(fx[m][s], WE[((m * CT + c) * 4 + s) * 64 + lane], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const real xn = acc[r] * inv_a;
+        zh[r][c] = alpha * xn + (1.0 - alpha) * z1o[r] + y1o[r] * inv_rho;
+        const real xnew = alpha * xn + (1.0 - alpha) * xv[r];
+        __builtin_nontemporal_store(xnew, &Xs[fidx(e, c, r)]);
+        sq[r][c] = sigma * xnew - qv[r];
+      }
+    }
+  };
+  // back: box + energy-row projection of zh one register row at a time, z1 and y1 stored, the tile's NEW r0 left in zh
+  auto tile_back = [&](int e, real (&zh)[4][CT], const real (&sq)[4][CT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      real lbv[CT], ubv[CT], z1[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) { const size_t i = fidx(e, c, r); lbv[c] = __builtin_nontemporal_load(&LBs[i]); ubv[c] = __builtin_nontemporal_load(&UBs[i]); }
+      project_row(e, r, zh[r], lbv, ubv, z1, false);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const size_t i = fidx(e, c, r);
+        const real y1n = rho * (zh[r][c] - z1[c]);
+        __builtin_nontemporal_store(z1[c], &Z1s[i]); __builtin_nontemporal_store(y1n, &Y1s[i]);
+        zh[r][c] = sq[r][c] + rho * z1[c] - y1n;   // the new r0, in zh's registers
+      }
+    }
+  };
+  real v0, v1, v2, v4, v5;   // residual terms of the iteration's check
+  auto tile_residuals = [&](int e) __attribute__((always_inline)) {
+    // residual terms of this tile (state re-read: L2-hot); (G' y2) tile by MFMA with the un-rotated site matrix
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      vec4 gty = {0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          gty = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], Y2[((m * CT + c) * 4 + s) * 64 + lane], gty);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const size_t i = fidx(e, c, r);
+        const real xk = Xs[i], qk = Qs[i], yk = Y1s[i], zk = Z1s[i];
+        v0 = fmax(v0, fabs(xk - zk));
+        v1 = fmax(v1, fabs(pd * xk + qk + yk + gty[r]));
+        v2 = fmax(v2, fmax(fabs(xk), fabs(zk)));
+        v4 = fmax(v4, fabs(pd * xk));
+        v5 = fmax(v5, fabs(yk + gty[r]));
+      }
+    }
+  };
 #pragma unroll 1
   while (!done) {
     ++it;
     const real a = sigma + pd + rho, inv_a = 1.0 / a, inv_rho = 1.0 / rho;
     const bool check = (it % A.check_every == 0) || it >= max_iter_p;
+    const bool ev_it = aa_m > 0 && it % kAaPeriod == 0;   // Anderson event: the projections follow the extrapolation
     // an offset the compiler cannot see through keeps the loads of loop-invariant site data (Q fragments, row
     // constants) inside the loop, where they hit L1 / L2, instead of pinning ~150 registers across it
     unsigned zoff = 0;
@@ -448,6 +664,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
     const real* Lmi = Lm + zoff;
     const real* RLi = RL + zoff;
     const int32_t* RTi = A.rowtype + zoff;
+    sv0 = 0; sv2 = 0;
     // ---- eigen space, by the wave that owns each 16 x 16 site tile (its accumulator holds Ghat r0 for that tile):
     // e^ -> WE, h^ -> G0H ---------------------------------------------------------------------------------------
 #pragma unroll
@@ -474,8 +691,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       }
     }
     __syncthreads();
-    // ---- site rows: G x~ = Q h^, relaxation, projection onto C, y2 (owner waves) ---------------------------------
-    real sv0 = 0, sv2 = 0;   // |G x - z2|_inf, max(|G x|, |z2|): the site-row share of the residuals
+    // ---- site rows: G x~ = Q h^, relaxation; projection onto C and y2 (owner waves) -- after the event on event iterations
 #pragma unroll 1
     for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
       RELANE();
@@ -486,132 +702,383 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
 #pragma unroll
         for (int s = 0; s < 4; ++s)
           zt = M::mma(FQi[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane], G0H[((mi * CT + c) * 4 + s) * 64 + lane], zt);
-      real zhr[4], lim[4];
-      int ty[4];
-      const int tt = 16 * c + t;
-      real pk = M::big;
-      if (A.peak && tt < Tm) { const double pv = A.peak[(size_t)b * Tm + tt]; pk = pv < M::big ? pv * A.peak_scale : M::big; }
+      real zhr[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
-        const int j = 16 * mo + M::rowof(g, r);
-        ty[r] = RTi[j]; lim[r] = RLi[j];
         GX[i] = alpha * zt[r] + (1.0 - alpha) * GX[i];
         zhr[r] = alpha * zt[r] + (1.0 - alpha) * Z2[i] + Y2[i] * inv_rho;
       }
-      real scl[2] = {1.0, 1.0};
+      if (ev_it) {
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr)
-        if (ty[2 * pr] == kRowSocRe) {
-          const real re = zhr[2 * pr], im = zhr[2 * pr + 1];
-          const real n2 = re * re + im * im;
-          if (n2 > lim[2 * pr] * lim[2 * pr]) scl[pr] = lim[2 * pr] / sqrt(n2);
-        }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
-        real zn = zhr[r];
-        if (ty[r] == kRowBox) zn = fmin(zn, lim[r]);
-        else if (ty[r] == kRowPeak) zn = fmin(zn, pk);
-        else if (ty[r] == kRowQuad) zn = zn * (rho / (rho + lfb));
-        else if (ty[r] == kRowSocRe || ty[r] == kRowSocIm) zn = zn * scl[r >> 1];
-        Y2[i] = rho * (zhr[r] - zn);
-        Z2[i] = zn;
-        sv0 = fmax(sv0, fabs(GX[i] - zn));
-        sv2 = fmax(sv2, fmax(fabs(GX[i]), fabs(zn)));
+        for (int r = 0; r < 4; ++r) ZHs[NT + ((mo * CT + c) * 4 + r) * 64 + lane] = zhr[r];
+      } else {
+        site_project(mo, c, zhr, RLi, RTi);
       }
     }
     __syncthreads();
-    // ---- the fused pass over this wave's EVSE tiles -------------------------------------------------------------
-    real v0 = sv0, v1 = 0, v2 = sv2, v4 = 0, v5 = 0;
-    zero_pown();
+    v0 = 0; v1 = 0; v2 = 0; v4 = 0; v5 = 0;
+    if (!ev_it) {
+      if (dc_on && wave == kStreamWaves - 1) { RELANE(); dc_row(); }
+      // ---- the fused pass over this wave's EVSE tiles -----------------------------------------------------------
+      zero_pown();
 #pragma unroll 1
-    for (int rd = 0; rd < n_rounds; ++rd) {
-      RELANE();
-      const int e = rd * kStreamWaves + wave;
-      const bool have = e < NE;
-      real zh[4][CT], sq[4][CT];   // sq = sigma x_new - q: all the new r0 still needs of x and q
-      if (have) {
-      const real* fg = FG + (size_t)e * MT * 2 * 4 * 64;
-      real fx[MT][4];              // A fragments of the x~ product: requested with the state, used after it arrived
+      for (int rd = 0; rd < n_rounds; ++rd) {
+        RELANE();
+        const int e = rd * kStreamWaves + wave;
+        const bool have = e < NE;
+        real zh[4][CT], sq[4][CT];
+        if (have) {
+          tile_front(e, inv_a, inv_rho, zh, sq);
+          tile_back(e, zh, sq);
+          if (check) tile_residuals(e);
+        }
+        p_round(rd, have, zh);   // the tile's new r0 joins next iteration's P
+      }
+    } else {
+      // ================= Anderson event (type II; acn_qp_tiled.hpp / oracle/admm_port.c) ============================
+      // u = (zh, zhr) is the state of the fixed-point map.  Pass A: every tile's zh -> ZHs, the new column pair
+      // (dF, dG) -> ring slot, the dot products dF_new . dF_j, dF_new . f, f . f.
+      const bool col = aa_have_prev;
+      const int slot = aa_head;
+      real d[AMX + 2];
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int j = 0; j < AMX + 2; ++j) d[j] = 0;
+      // the four registers of one tile column: g = gv[r], state index uo + 64 r
+      auto aa_tile = [&](const real (&gv)[4], size_t uo) __attribute__((always_inline)) {
+        real hv[AMX][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) fx[m][s] = fg[((m * 2 + 1) * 4 + s) * 64 + lane];
+        for (int j = 0; j < AMX; ++j)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        real xv[4], z1o[4], y1o[4], qv[4];
-        vec4 acc;
+          for (int r = 0; r < 4; ++r) hv[j][r] = (((aa_valid >> j) & 1u) && j != slot) ? (real)HF[(size_t)j * DU + uo + 64 * r] : 0.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const size_t i = fidx(e, c, r);
-          xv[r] = __builtin_nontemporal_load(&Xs[i]); z1o[r] = __builtin_nontemporal_load(&Z1s[i]); y1o[r] = __builtin_nontemporal_load(&Y1s[i]); qv[r] = __builtin_nontemporal_load(&Qs[i]);
-          acc[r] = sigma * xv[r] - qv[r] + rho * z1o[r] - y1o[r];
+          const size_t i = uo + 64 * r;
+          const real f = gv[r] - UP[i];
+          d[AMX + 1] += f * f;
+          const float cq = (float)(f - FP[i]);
+          const float cg = (float)(gv[r] - GP[i]);
+#pragma unroll
+          for (int j = 0; j < AMX; ++j) d[j] += (real)cq * (j == slot ? (real)cq : hv[j][r]);
+          d[AMX] += (real)cq * f;
+          if (col) { HF[(size_t)slot * DU + i] = cq; HG[(size_t)slot * DU + i] = cg; }
+          FP[i] = f; GP[i] = gv[r];
         }
+      };
+#pragma unroll 1
+      for (int rd = 0; rd < n_rounds; ++rd) {
+        RELANE();
+        const int e = rd * kStreamWaves + wave;
+        if (e < NE) {
+          real zh[4][CT], sq[4][CT];
+          tile_front(e, inv_a, inv_rho, zh, sq);
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int c = 0; c < CT; ++c) {
+            real gv[4];
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc = M::mma(fx[m][s], WE[((m * CT + c) * 4 + s) * 64 + lane], acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const real xn = acc[r] * inv_a;
-          zh[r][c] = alpha * xn + (1.0 - alpha) * z1o[r] + y1o[r] * inv_rho;
-          const real xnew = alpha * xn + (1.0 - alpha) * xv[r];
-          __builtin_nontemporal_store(xnew, &Xs[fidx(e, c, r)]);
-          sq[r][c] = sigma * xnew - qv[r];
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        real lbv[CT], ubv[CT], z1[CT];
-#pragma unroll
-        for (int c = 0; c < CT; ++c) { const size_t i = fidx(e, c, r); lbv[c] = __builtin_nontemporal_load(&LBs[i]); ubv[c] = __builtin_nontemporal_load(&UBs[i]); }
-        project_row(e, r, zh[r], lbv, ubv, z1, false);
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          const size_t i = fidx(e, c, r);
-          const real y1n = rho * (zh[r][c] - z1[c]);
-          __builtin_nontemporal_store(z1[c], &Z1s[i]); __builtin_nontemporal_store(y1n, &Y1s[i]);
-          zh[r][c] = sq[r][c] + rho * z1[c] - y1n;   // the new r0, in zh's registers
-        }
-      }
-      if (check) {   // residual terms of this tile (state re-read: L2-hot); (G' y2) tile by MFMA with the un-rotated site matrix
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          vec4 gty = {0, 0, 0, 0};
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-              gty = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], Y2[((m * CT + c) * 4 + s) * 64 + lane], gty);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const size_t i = fidx(e, c, r);
-            const real xk = Xs[i], qk = Qs[i], yk = Y1s[i], zk = Z1s[i];
-            v0 = fmax(v0, fabs(xk - zk));
-            v1 = fmax(v1, fabs(pd * xk + qk + yk + gty[r]));
-            v2 = fmax(v2, fmax(fabs(xk), fabs(zk)));
-            v4 = fmax(v4, fabs(pd * xk));
-            v5 = fmax(v5, fabs(yk + gty[r]));
+            for (int r = 0; r < 4; ++r) { gv[r] = zh[r][c]; ZHs[fidx(e, c, r)] = zh[r][c]; }
+            aa_tile(gv, fidx(e, c, 0));
           }
         }
       }
-      }   // have
-      p_round(rd, have, zh);   // the tile's new r0 joins next iteration's P
+#pragma unroll 1
+      for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
+        RELANE();
+        real gv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) gv[r] = ZHs[NT + (tl * 4 + r) * 64 + lane];
+        aa_tile(gv, (size_t)NT + (size_t)tl * 256 + lane);
+      }
+#pragma unroll
+      for (int j = 0; j < AMX + 2; ++j) d[j] = wave_sum<real>(d[j]);
+      if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < AMX + 2; ++j) AaRedS[wave * (AMX + 2) + j] = d[j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < AMX + 2; ++j) {
+        real sw = 0;
+        for (int wv = 0; wv < kStreamWaves; ++wv) sw += AaRedS[wv * (AMX + 2) + j];
+        d[j] = sw;
+      }
+      const real fn = sqrt(d[AMX + 1]);
+      bool keep = col;
+      if (aa_was && fn > kAaSafe * fn_prev) {
+        // the accelerated step made the residual worse: clear the ring, back off exponentially
+        aa_cnt = 0; aa_head = 0; aa_valid = 0; keep = false;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < AMX * AMX + AMX; k += 64) AaH[k] = 0;
+        aa_cool = aa_pen;
+        aa_pen = aa_pen < 64 ? 2 * aa_pen : 64;
+      } else if (aa_cool > 0) --aa_cool;
+      if (keep) {
+        aa_valid |= 1u << slot;
+        if (lane == 0) {
+#pragma unroll
+          for (int j = 0; j < AMX; ++j) {
+            if (!((aa_valid >> j) & 1u)) continue;
+            AaH[slot * AMX + j] = d[j];
+            AaH[j * AMX + slot] = d[j];
+            if (j != slot) AaH[AMX * AMX + j] += d[j];   // dF_j . f_k = dF_j . f_(k-1) + dF_j . dF_slot
+          }
+          AaH[AMX * AMX + slot] = d[AMX];
+        }
+        aa_head = slot + 1 == aa_m ? 0 : slot + 1;
+        aa_cnt = aa_cnt < aa_m ? aa_cnt + 1 : aa_m;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      aa_have_prev = true; fn_prev = fn; aa_was = false;
+      real dself = 0;   // |dF_new|^2
+#pragma unroll
+      for (int j = 0; j < AMX; ++j) dself = j == slot ? d[j] : dself;
+      real gam[AMX];
+#pragma unroll
+      for (int j = 0; j < AMX; ++j) gam[j] = 0;
+      // no extrapolation while the map drifts (|dF_new| <= kAaDrift |f|): the differences are rounding noise
+      const bool ext = aa_cnt > 0 && aa_cool == 0 && !check && dself > (kAaDrift * kAaDrift) * d[AMX + 1];
+      if (ext) {
+        // gamma = (H + eta I)^-1 b: Gauss-Jordan on the augmented system spread over the wave, lane 8 i + j holding
+        // entry (i, j) (regularised Gram matrix: no pivoting)
+        static_assert(AMX <= 7, "one 8 x 8 lane tile holds the augmented system");
+        const int gi = lane >> 3, gj = lane & 7;
+        real tr = 0;
+#pragma unroll
+        for (int i = 0; i < AMX; ++i) tr += AaH[i * AMX + i];          // dead slots hold zeros
+        const real eta = kAaReg * tr + 1e-300;
+        real ae = 0;
+        if (gi < AMX && gj <= AMX) ae = gj < AMX ? AaH[gi * AMX + gj] : AaH[AMX * AMX + gi];
+        if (gi < AMX && gi == gj) ae = ((aa_valid >> gi) & 1u) ? ae + eta : 1.0;
+#pragma unroll
+        for (int k = 0; k < AMX; ++k) {
+          const real piv = __shfl(ae, 9 * k);
+          const real rk = __shfl(ae, 8 * k + gj);
+          const real ck = __shfl(ae, 8 * gi + k);
+          const real rs = rk / piv;
+          ae = gi == k ? rs : ae - ck * rs;
+        }
+#pragma unroll
+        for (int j = 0; j < AMX; ++j) gam[j] = __shfl(ae, 8 * j + AMX);
+        aa_was = true;
+      }
+      // u = g - sum_j gamma_j dG_j for the four registers at uo; stored as the new u
+      auto aa_apply = [&](real (&out)[4], size_t uo) __attribute__((always_inline)) {
+        if (ext) {
+#pragma unroll
+          for (int j = 0; j < AMX; ++j) {
+            if (!((aa_valid >> j) & 1u)) continue;   // uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[r] -= gam[j] * (real)HG[(size_t)j * DU + uo + 64 * r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) UP[uo + 64 * r] = out[r];
+      };
+      // ---- the site rows are projected from their (extrapolated) point ------------------------------------------
+#pragma unroll 1
+      for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
+        RELANE();
+        const int mo = tl / CT, c = tl - mo * CT;
+        real zhr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) zhr[r] = ZHs[NT + (tl * 4 + r) * 64 + lane];
+        aa_apply(zhr, (size_t)NT + (size_t)tl * 256 + lane);
+        site_project(mo, c, zhr, RLi, RTi);
+      }
+      __syncthreads();
+      if (dc_on && wave == kStreamWaves - 1) { RELANE(); dc_row(); }
+      // ---- pass B: the extrapolated zh of every tile -> projection, y1, the new r0 -> P ----------------------------
+      zero_pown();
+#pragma unroll 1
+      for (int rd = 0; rd < n_rounds; ++rd) {
+        RELANE();
+        const int e = rd * kStreamWaves + wave;
+        const bool have = e < NE;
+        real zh[4][CT], sq[4][CT];
+        if (have) {
+#pragma unroll
+          for (int c = 0; c < CT; ++c) {
+            real o4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o4[r] = ZHs[fidx(e, c, r)];
+            aa_apply(o4, fidx(e, c, 0));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const size_t i = fidx(e, c, r);
+              zh[r][c] = o4[r];
+              sq[r][c] = sigma * Xs[i] - Qs[i];   // x_new was stored by pass A
+            }
+          }
+          tile_back(e, zh, sq);
+          if (check) tile_residuals(e);
+        }
+        p_round(rd, have, zh);
+      }
     }
     if (check) {
-      real v[5] = {v0, v1, v2, v4, v5};
+      real v[5] = {fmax(v0, sv0), v1, fmax(v2, sv2), v4, v5};
       stream_block_max<5, NWV>(v, SC, lane, wave);
       pri = v[0]; dua = v[1];
       const real npri = v[2], ndua = fmax(fmax(v[3], v[4]), qnorm);
       const real eps_p = A.eps_abs + A.eps_rel * npri, eps_d = A.eps_abs + A.eps_rel * ndua;
+      if (pri <= eps_p && dua <= eps_d) { status = 1; done = true; }
+      if (!done && have_prev) {
+        // ---- primal infeasibility certificate (OSQP's, generalised to the sets B and C; acn_qp_tiled.hpp) ----------
+        // v = y - y(previous check).  If A'v ~ 0 and the support function of B x C at v is negative, no point of
+        // B x C satisfies A r = z.  For B the support function of a session is bounded above by
+        // phi(l) = l cap + sum_t [ub (v_t - l)+ + lb (v_t - l)-] for any admissible l.
+        real w6[2] = {0, 0};   // |v|, |v1 + G'v2|
+#pragma unroll 1
+        for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
+          RELANE();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int i = (tl * 4 + r) * 64 + lane; w6[0] = fmax(w6[0], fabs(Y2[i] - (real)Y2P[i])); }
+        }
+#pragma unroll 1
+        for (int e = wave; e < NE; e += kStreamWaves) {
+          RELANE();
+#pragma unroll
+          for (int c = 0; c < CT; ++c) {
+            vec4 gtv = {0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+                const int i = ((m * CT + c) * 4 + s) * 64 + lane;
+                gtv = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * e + t], Y2[i] - (real)Y2P[i], gtv);
+              }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const size_t i = fidx(e, c, r);
+              const real v1_ = Y1s[i] - (real)Y1P[i];
+              w6[0] = fmax(w6[0], fabs(v1_));
+              w6[1] = fmax(w6[1], fabs(v1_ + gtv[r]));
+            }
+          }
+        }
+        stream_block_max<2, NWV>(w6, SC, lane, wave);
+        const real vn = w6[0];
+        const real vtol = 1e-4 * vn;
+        if (vn > 1e-12 * fmax(1.0, qnorm) && w6[1] <= vtol) {   // block-uniform
+          real ssum = 0, badv = 0;
+#pragma unroll 1
+          for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {   // site rows
+            RELANE();
+            const int m = tl / CT, c = tl - m * CT;
+            const int tt = 16 * c + t;
+            real pk = M::big;
+            if (A.peak && tt < Tm) { const double pv = A.peak[(size_t)b * Tm + tt]; pk = pv < M::big ? pv * A.peak_scale : M::big; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = (tl * 4 + r) * 64 + lane;
+              const int j = 16 * m + M::rowof(g, r);
+              const real v2_ = Y2[i] - (real)Y2P[i];
+              const int ty = RTi[j];
+              if (ty == kRowBox) { ssum += RLi[j] * fmax(v2_, 0.0); if (v2_ < -vtol) badv = 1; }
+              else if (ty == kRowPeak) {
+                if (pk < M::big) ssum += pk * fmax(v2_, 0.0); else if (v2_ > vtol) badv = 1;
+                if (v2_ < -vtol) badv = 1;
+              } else if (ty == kRowSocRe) {
+                const int i2 = (tl * 4 + ((r + 1) & 3)) * 64 + lane;
+                const real vi = Y2[i2] - (real)Y2P[i2];
+                ssum += RLi[j] * sqrt(v2_ * v2_ + vi * vi);
+              } else if (ty == kRowSocIm) {
+              } else if (fabs(v2_) > vtol) badv = 1;   // free / prox rows admit no ray
+            }
+          }
+          // sessions (one register row at a time): bound each session's support function; periods outside every
+          // window are pinned to lb = ub: support lb * v
+#pragma unroll 1
+          for (int ri = wave; ri < 4 * NE; ri += kStreamWaves) {
+            RELANE();
+            const int e = ri >> 2, r = ri & 3;
+            const int ev = 16 * e + M::rowof(g, r);
+            real vv[CT], lbv[CT], ubv[CT];
+            bool cov[CT];
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+              const size_t i = fidx(e, c, r);
+              vv[c] = Y1s[i] - (real)Y1P[i]; lbv[c] = LBs[i]; ubv[c] = UBs[i]; cov[c] = false;
+            }
+#pragma unroll 1
+            for (int k = 0; k < K; ++k) {
+              const size_t sidx = ((size_t)b * K + k) * N + (ev < N ? ev : 0);
+              const int off = ev < N ? A.s_off[sidx] : 0;
+              int len = ev < N ? A.s_len[sidx] : 0;
+              if (off + len > Tm) len = Tm - off;
+              const real cap = ev < N ? A.s_cap[sidx] : 0.0;
+              real lmin_l = M::big, lmax_l = -M::big;
+#pragma unroll
+              for (int c = 0; c < CT; ++c) {
+                const int tp = 16 * c + t;
+                const bool inw = tp >= off && tp < off + len;
+                cov[c] = cov[c] || inw;
+                lmin_l = inw ? fmin(lmin_l, vv[c]) : lmin_l;
+                lmax_l = inw ? fmax(lmax_l, vv[c]) : lmax_l;
+              }
+              real lam3[3];
+              lam3[0] = row_min<real>(lmin_l);
+              lam3[1] = row_max<real>(lmax_l);
+              lam3[2] = 0;
+              real best = M::big;
+#pragma unroll
+              for (int j = 0; j < 3; ++j) {
+                real l_ = lam3[j];
+                if (!eq) l_ = fmax(l_, 0.0);
+                real ph = 0;
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                  const int tp = 16 * c + t;
+                  if (tp >= off && tp < off + len) {
+                    const real dv = vv[c] - l_;
+                    ph += ubv[c] * fmax(dv, 0.0) + lbv[c] * fmin(dv, 0.0);
+                  }
+                }
+                ph = row_sum<real>(ph) + l_ * cap;
+                best = fmin(best, ph);
+              }
+              if (len > 0 && t == 0) ssum += best;   // one lane per session
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+              if (!cov[c] && 16 * c + t < Tm && ev < N) ssum += lbv[c] * vv[c];
+          }
+          const real tot = wave_sum<real>(ssum);
+          real bd[1] = {badv};
+          stream_block_max<1, NWV>(bd, SC, lane, wave);
+          if (lane == 0) RED[wave] = tot;   // the rounds' slab is free between iterations
+          __syncthreads();
+          real stot = 0;
+          for (int wv = 0; wv < kStreamWaves; ++wv) stot += RED[wv];
+          __syncthreads();
+          if (bd[0] == 0.0 && stot < -vtol) { status = 3; done = true; }
+        }
+      }
+      if (!done) {   // snapshot for the next certificate test (single precision: acn_qp_tiled.hpp)
+#pragma unroll 1
+        for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
+          RELANE();
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int i = (tl * 4 + r) * 64 + lane; Y2P[i] = (float)Y2[i]; }
+        }
+#pragma unroll 1
+        for (int e = wave; e < NE; e += kStreamWaves) {
+          RELANE();
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const size_t i = fidx(e, c, r); Y1P[i] = (float)Y1s[i]; }
+        }
+        have_prev = true;
+      }
       const real score = fmax(pri / fmax(eps_p, 1e-300), dua / fmax(eps_d, 1e-300));
       if (score < kStallGain * best_score) { best_score = score; best_it = it; }
       const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel, A.inacc_floor);
       const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= kStallNear * best_score;   // acn_qp_tiled.hpp
-      if (pri <= eps_p && dua <= eps_d) { status = 1; done = true; }
-      else if (it >= max_iter_p || stalled) {
+      if (done) {
+      } else if (it >= max_iter_p || stalled) {
         done = true;
         if (inacc) status = 5;
       } else if (adapt_p > 0 && it % adapt_p == 0) {
@@ -623,6 +1090,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
           rho = fmin(fmax(rho * ratio, 1e-6), 1e6);
           __syncthreads();     // every wave's stores of this pass are visible before the state is re-read
           rebuild_p();         // r0 depends on rho: P with the new penalty
+          if (aa_m > 0) {      // the fixed-point map changed: restart the ring from the current (z, y)
+            reset_u();
+            aa_cnt = 0; aa_head = 0; aa_valid = 0; aa_have_prev = false; aa_was = false;
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < AMX * AMX + AMX; k += 64) AaH[k] = 0;
+          }
         }
       }
     }

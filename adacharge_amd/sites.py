@@ -226,6 +226,12 @@ def wide128() -> InfrastructureInfo:
     return balanced_three_phase(128, pods=6, load_fraction=0.4, name="WD")
 
 
+def wide192() -> InfrastructureInfo:
+    """Synthetic 192-EVSE three-phase site (large-site kernel at horizon 48; the widest shape the IPM oracle certifies
+    in about a minute: tests/golden/wide.npz::wide192_t48_soc)."""
+    return balanced_three_phase(192, pods=8, load_fraction=0.35, name="W2")
+
+
 def snapshot_batch(
     infra: InfrastructureInfo,
     horizon: int,

@@ -247,8 +247,8 @@ int64_t acnqp_launch_count(acnqp_handle* h);
 /* Anderson columns the kernels will actually use for problems of this shape
  * (t_max periods, k_sessions slots) at the given precision when `requested`
  * columns are asked for: a function of the shape only, never of the batch
- * size (the long-horizon and general-shape kernels keep their ring in global
- * memory: 5; the large-site kernel runs plain ADMM: 0).  No reference equivalent:
+ * size (the long-horizon, large-site and general-shape kernels keep their
+ * ring in global memory: 5).  No reference equivalent:
  * test/bench plumbing so that a CPU restatement can run the same algorithm.  */
 int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, int32_t precision,
                             int32_t requested);

@@ -428,8 +428,10 @@ def test_wide_site_stream_kernel():
         assert (ref["status"] == 1).all() and (plain.status == 1).all()
         assert np.abs(ref["x"] - plain.x).max() <= 1e-5
         m_eff = h.accel_columns(batch.Tm, batch.K, default_options())
-        assert m_eff == 0                                           # large-site kernel: plain ADMM
-        assert np.array_equal(res.x, plain.x) and np.array_equal(res.iters, plain.iters)
+        assert m_eff == 5                                           # large-site kernel: ring in its workspace (round 3)
+        acc = admm_port.solve_batch(batch, threads=8, accel_mem=m_eff)
+        assert np.abs(acc["x"] - res.x).max() <= RATE_TOL           # accelerated: same optimum as the accelerated twin
+        assert res.iters.sum() < plain.iters.sum()                  # ... in fewer iterations than the plain iteration
         assert np.abs(ref["iters"] - plain.iters).max() <= 20       # same algorithm, different summation order
         h.close()
 
@@ -1090,3 +1092,98 @@ def test_config4_as_a_sharded_job_two_ranks_times_two_sites():
     for rank, x, st in got:
         assert x.shape == want.shape and (st == 1).all()
         assert np.array_equal(x, want)
+
+
+# ---- large-site kernel (N > 64, horizon <= 48): Anderson acceleration, certificate, demand-charge row (round 3) ------
+def _synth512_congested(n_base=2, scenarios=2):
+    """The bench's configs[4] leg at test size: 512 EVSE x 48, load flattening of an external profile with the sessions'
+    energy delivered (equalities), site rows binding (bench.other_workloads)."""
+    from adacharge_amd import load_flattening
+    from adacharge_amd.acn import Interface
+    from adacharge_amd.builder import ProblemBatch, scenario_batch
+
+    infra = sites.synth512()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    T = 48
+    ext = 150.0 + 100.0 * np.cos(np.arange(T) / T * 2 * np.pi)
+    obj = [ObjectiveComponent(load_flattening, 1.0, {"external_signal": ext})]
+    rng = np.random.default_rng(5)
+    snaps = [sites.random_sessions_general(infra, T, rng, False, False, demand_scale=0.12) for _ in range(n_base)]
+    base = build_batch(snaps, infra, iface, obj, "SOC", True)
+    batch = ProblemBatch.concatenate([scenario_batch(base, rng.lognormal(0.0, 0.05, size=scenarios), problem=p) for p in range(n_base)])
+    return infra, batch
+
+
+def test_config5_congested_anderson_cuts_iterations_as_the_twin_predicts():
+    """512 x 48 with binding site rows at DEFAULT tolerances: the accelerated large-site kernel reaches the optimum the C
+    twin reaches, in about the iterations the accelerated twin needs -- and in well under the plain iteration's."""
+    from oracle import admm_port
+
+    infra, batch = _synth512_congested()
+    assert batch.N == 512 and batch.Tm == 48 and batch.site.has_flat and batch.site.Mg > 32
+    h = SiteHandle(batch.site, 0)
+    assert h.accel_columns(batch.Tm, batch.K, default_options()) == 5
+    res = h.solve(batch, default_options())
+    plain = h.solve(batch, default_options(accel_mem=0))
+    assert (res.status == 1).all() and (plain.status == 1).all()
+    ref = admm_port.solve_batch(batch, threads=4, accel_mem=5)
+    refp = admm_port.solve_batch(batch, threads=4, accel_mem=0)
+    assert (ref["status"] == 1).all() and (refp["status"] == 1).all()
+    assert np.abs(refp["iters"] - plain.iters).max() <= 40            # plain: the twin's iteration
+    assert np.abs(refp["x"] - plain.x).max() <= 1e-5
+    assert np.abs(ref["x"] - res.x).max() <= RATE_TOL
+    assert res.iters.sum() <= 0.7 * plain.iters.sum()
+    assert res.iters.sum() <= 1.35 * ref["iters"].sum()
+    ph, cm = np.deg2rad(infra.phases), infra.constraint_matrix
+    mag = np.hypot(np.einsum("mn,bnt->bmt", cm * np.cos(ph), res.x), np.einsum("mn,bnt->bmt", cm * np.sin(ph), res.x))
+    assert (mag <= infra.constraint_limits[None, :, None] + 1e-3).all() and (mag / infra.constraint_limits[None, :, None]).max() > 0.95
+    h.close()
+
+
+def test_large_site_kernel_certifies_infeasibility():
+    """An infeasible 512-EVSE problem (energy equalities the feeders cannot carry) ends PRIMAL_INFEASIBLE in well under
+    5,000 iterations instead of burning max_iter, next to feasible problems in the same batch that are untouched."""
+    from adacharge_amd import load_flattening
+    from adacharge_amd.acn import Interface
+
+    infra = sites.synth512()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    T = 48
+    obj = [ObjectiveComponent(load_flattening, 1.0, {"external_signal": np.full(T, 100.0)})]
+    rng = np.random.default_rng(9)
+    ok_sl = sites.random_sessions_general(infra, T, rng, False, False, demand_scale=0.10)
+    bad_sl = sites.random_sessions_general(infra, T, rng, False, False, demand_scale=0.55)   # twice what the site carries
+    batch = build_batch([ok_sl, bad_sl, ok_sl], infra, iface, obj, "SOC", True)
+    h = SiteHandle(batch.site, 0)
+    res = h.solve(batch, default_options())
+    assert res.status.tolist() == [1, 3, 1], (res.status, res.iters)
+    assert res.iters[1] < 5000
+    alone = h.solve(batch.subset(slice(0, 1)), default_options())
+    assert np.array_equal(alone.x[0], res.x[0]) and np.array_equal(res.x[0], res.x[2])
+    h.close()
+
+
+def test_large_site_kernel_demand_charge_matches_c_twin():
+    """The demand-charge row on a wide site (128 EVSE x 40): served by the large-site kernel since round 3 (it fell to the
+    general-shape kernel before); against the C twin, and the billed peak."""
+    from adacharge_amd import demand_charge, total_energy
+    from adacharge_amd.acn import Interface
+    from oracle import admm_port
+
+    infra = sites.wide128()
+    iface = Interface({"infrastructure_info": infra, "period": 5, "demand_charge": 15.0, "prev_peak": 80.0})
+    obj = [ObjectiveComponent(total_energy, 20.0), ObjectiveComponent(demand_charge), ObjectiveComponent(equal_share, 1e-3)]
+    snaps = sites.snapshot_batch(infra, 40, 4, seed=47, min_sessions=60, demand_range=(5.0, 30.0))
+    batch = build_batch(snaps, infra, iface, obj, "SOC")
+    assert batch.site.has_max and batch.N == 128
+    h = SiteHandle(batch.site, 0)
+    res = h.solve(batch, default_options())
+    ref = admm_port.solve_batch(batch, threads=4, accel_mem=h.accel_columns(batch.Tm, batch.K, default_options()))
+    assert (res.status == 1).all() and (ref["status"] == 1).all()
+    assert np.abs(res.x - ref["x"]).max() <= RATE_TOL
+    v = infra.voltages / 1e3
+    assert np.abs(np.einsum("n,bnt->bt", v, res.x).max(axis=1) - np.einsum("n,bnt->bt", v, ref["x"]).max(axis=1)).max() <= 1e-4
+    plain = h.solve(batch, default_options(accel_mem=0))
+    refp = admm_port.solve_batch(batch, threads=4, accel_mem=0)
+    assert (plain.status == 1).all() and np.abs(plain.x - refp["x"]).max() <= 1e-5
+    h.close()

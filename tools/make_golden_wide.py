@@ -39,19 +39,30 @@ CASES = [
     # a day-shaped offline instance (adacharge.py:234-276; t_int.py:350-403 solves one with energy equalities):
     # 288 periods, 150 sessions, up to 6 consecutive sessions per EVSE -- sites.offline_day
     ("offline_day",  "caltech54", 288, "SOC",   True,  "day", False, "none",   1e-3, 218),
+    # round 3: a wide site at horizon 48 (large-site kernel with Anderson acceleration), congested (demand_scale 0.6
+    # against limits at 35 % of the full load), minimum rates on 30 % of the sessions: 9,216 variables, ~1 min of IPM
+    ("wide192_t48_soc", "wide192", 48, "SOC",   False, False, True,  "none",   1e-3, 2192),
 ]
 
 
 def main():
-    store = {"names": np.array([c[0] for c in CASES])}
+    only = sys.argv[1:]   # `python tools/make_golden_wide.py name ...`: (re)generate these cases, keep the others
+    store = {}
+    if only and os.path.exists(OUT):
+        store = dict(np.load(OUT, allow_pickle=False))
+    store["names"] = np.array([c[0] for c in CASES])
     for name, site_name, T, ct, eq, two, mins, peak_kind, es, seed in CASES:
+        if only and name not in only:
+            assert f"{name}_rates" in store, f"{name} is not in {OUT}: regenerate everything"
+            continue
         infra = getattr(sites, site_name)()
         iface = Interface({"infrastructure_info": infra, "period": 5})
         rng = np.random.default_rng(seed)
         if two == "day":
             sl = sites.offline_day(infra, rng, horizon=T)
         else:
-            sl = sites.random_sessions_general(infra, T, rng, two, mins, demand_scale=0.5 if eq else 1.5)
+            sl = sites.random_sessions_general(infra, T, rng, two, mins,
+                                               demand_scale=0.6 if site_name == "wide192" else (0.5 if eq else 1.5))
         Tb = max(s.arrival_offset + s.remaining_time for s in sl)
         full = 32.0 * len(sl)
         peak = None
