@@ -1152,7 +1152,14 @@ def test_large_site_kernel_certifies_infeasibility():
     obj = [ObjectiveComponent(load_flattening, 1.0, {"external_signal": np.full(T, 100.0)})]
     rng = np.random.default_rng(9)
     ok_sl = sites.random_sessions_general(infra, T, rng, False, False, demand_scale=0.10)
-    bad_sl = sites.random_sessions_general(infra, T, rng, False, False, demand_scale=0.55)   # twice what the site carries
+    # infeasible: every EVSE of the first pod must receive 60 % of what it can draw over the whole horizon, three times
+    # what the pod's feeder (limit at 1/3 of its full load) carries; every session fits its own window
+    from adacharge_amd.acn import SessionInfo
+    k = 208 * 5 / 60 / 1e3
+    pod = set(np.flatnonzero(infra.constraint_matrix[0]).tolist())
+    bad_sl = [s for s in ok_sl if infra.station_ids.index(s.station_id) not in pod]
+    bad_sl += [SessionInfo(infra.station_ids[i], f"pod{i}", 0.6 * 32 * T * k, 0.0, 0, T, current_time=0,
+                           min_rates=np.zeros(T), max_rates=np.full(T, 32.0)) for i in sorted(pod)]
     batch = build_batch([ok_sl, bad_sl, ok_sl], infra, iface, obj, "SOC", True)
     h = SiteHandle(batch.site, 0)
     res = h.solve(batch, default_options())
