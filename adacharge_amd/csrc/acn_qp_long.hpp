@@ -94,9 +94,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   real* HH = EH + MT * CTL * 256;                 // h^ (start: Ghat z1)
 
   // passes: pass 0 as the options state it, then cold fixed-penalty retries of a stalled problem (retry_wanted,
-  // acn_qp_tiled.hpp).  The WHOLE body is the pass, with the thread / block ids opaque and the argument block read
-  // through a per-pass opaque pointer to the kernarg segment: nothing of a pass is invariant across passes, so no
-  // pass-invariant address, predicate or argument is kept alive across the solver loop.
+  // acn_qp_tiled.hpp).  The WHOLE body is the pass, with the argument block read through a per-pass opaque pointer to
+  // the kernarg segment: no argument is kept alive across the solver loop for the next pass's sake.
   int it_total = 0, best_status = 0;
   for (int pass = 0;; ++pass) {
   typedef const __attribute__((address_space(4))) StreamArgs* KernargP;
@@ -105,10 +104,11 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   const auto& SA = *SAp;
   (void)SA_kernarg;
   const auto& A = SA.t;
-  int b_ = blockIdx.x, tid = threadIdx.x;
-  asm volatile("" : "+v"(b_));
-  asm volatile("" : "+v"(tid));
-  const int b = __builtin_amdgcn_readfirstlane(b_);
+  // (the thread / block ids are NOT made opaque here, unlike in the other kernels: with them opaque this kernel's
+  //  workspace placement of r0 / zh returned run-to-run different iterates on the GPU -- tools/gpu_determinism.py,
+  //  DESIGN.md section 3.3 -- while this form is bit-stable and equals the LDS placement; the argument pointer alone
+  //  already keeps the arguments out of the solver loop's registers)
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
   const int adapt_p = pass == 0 ? A.adapt_every : 0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

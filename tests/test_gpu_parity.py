@@ -805,12 +805,12 @@ def test_long_horizon_kernel_many_sessions_per_evse_and_warm_start():
     h.close()
 
 
-def test_long_horizon_kernel_same_answer_with_arrays_in_lds_or_workspace(tmp_path):
+def test_long_horizon_kernel_same_bits_with_arrays_in_lds_or_workspace(tmp_path):
     """Where the r0 / zh array (and x, up to 96 periods) lives -- LDS or the workspace -- is a placement, not an
-    algorithm: a child process with ACNQP_NO_RZL=1 (read once per process) must return the same statuses and the same
-    optimum.  (Round 2 asserted the same BITS; the two placements are two template instantiations, and which a * b + c
-    the compiler contracts into an fma is its choice per instantiation -- forcing -ffp-contract=on to pin that down
-    changed trajectories everywhere, so the claim is the optimum, not the rounding.)"""
+    algorithm: a child process with ACNQP_NO_RZL=1 (read once per process) must return the same iterations and the
+    same bits.  (Round 3 found this test red for a reason worth keeping it for: with the block id routed through
+    v_readfirstlane the workspace placement returned run-to-run DIFFERENT iterates -- tools/gpu_determinism.py,
+    DESIGN.md section 3.3 -- and only this comparison showed it.)"""
     import subprocess
     import sys
 
@@ -838,8 +838,8 @@ def test_long_horizon_kernel_same_answer_with_arrays_in_lds_or_workspace(tmp_pat
     a, b = np.load(files["lds"]), np.load(files["ws"])
     for T in (96, 144):
         assert np.array_equal(a[f"st{T}"], b[f"st{T}"]) and (a[f"st{T}"] == 1).all()
-        assert np.abs(a[f"x{T}"] - b[f"x{T}"]).max() <= RATE_TOL   # LP-like problems: the split is pinned by the Tikhonov floor only
-        assert np.abs(a[f"it{T}"] - b[f"it{T}"]).max() <= 0.5 * a[f"it{T}"].max()
+        assert np.array_equal(a[f"it{T}"], b[f"it{T}"])
+        assert np.array_equal(a[f"x{T}"], b[f"x{T}"])
 
 
 @pytest.mark.parametrize("ct", ["LINEAR", "SOC"])
@@ -1194,3 +1194,26 @@ def test_large_site_kernel_demand_charge_matches_c_twin():
     refp = admm_port.solve_batch(batch, threads=4, accel_mem=0)
     assert (plain.status == 1).all() and np.abs(plain.x - refp["x"]).max() <= 1e-5
     h.close()
+
+
+def test_every_kernel_family_is_run_to_run_deterministic():
+    """The same batch solved twice returns the same bits on every route (register-resident, LDS-resident long horizon,
+    long horizon, large site, general shape): a workgroup's result may not depend on timing."""
+    from adacharge_amd.acn import Interface
+
+    qc12 = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
+    qc3 = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    for name, infra, T, B, obj, kw in [
+        ("tiled", sites.caltech54(), 12, 512, qc12, {}),
+        ("long-lds", sites.jpl52(), 24, 128, qc3, {}),
+        ("long-96", sites.caltech54(), 96, 16, qc12, dict(demand_range=(5.0, 60.0))),
+        ("long-288", sites.caltech54(), 288, 8, qc12, dict(demand_range=(5.0, 60.0))),
+        ("stream", sites.wide128(), 12, 64, qc3, dict(min_sessions=40)),
+        ("general", sites.caltech54(), 320, 4, qc12, dict(demand_range=(5.0, 60.0))),
+    ]:
+        iface = Interface({"infrastructure_info": infra, "period": 5})
+        batch = build_batch(sites.snapshot_batch(infra, T, B, seed=900 + T, **kw), infra, iface, obj, "SOC")
+        h = SiteHandle(batch.site, 0)
+        a, b = h.solve(batch, default_options()), h.solve(batch, default_options())
+        h.close()
+        assert np.array_equal(a.x, b.x) and np.array_equal(a.iters, b.iters), name
