@@ -811,6 +811,22 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     if (A.pbuf_single) __syncthreads();   // the start used the one slab the first iteration writes next
   }
 
+#ifndef ACNQP_FRAG_RESIDENT
+#define ACNQP_FRAG_RESIDENT 0
+#endif
+  // A-operand fragments kept in registers across the loop (MT == 1 only): level 1 = the two post-barrier products
+  // (x~ = r0 + Ghat' e^, G x~ = Q h^), whose just-in-time loads sit on the iteration's critical path; level 2 = all four
+  constexpr int kFragRes = MT == 1 ? ACNQP_FRAG_RESIDENT : 0;
+  real fXr[4], fQr[4], fPr[4], fQtr[4];
+  if constexpr (kFragRes >= 1) {
+    const real* FG0r = static_cast<const real*>(A.fragG) + (size_t)__builtin_amdgcn_readfirstlane(wave) * MT * 2 * 4 * 64;
+    const real* FQ0r = static_cast<const real*>(A.fragQ);
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      fXr[s_] = FG0r[(1 * 4 + s_) * 64 + lane]; fQr[s_] = FQ0r[(1 * 4 + s_) * 64 + lane];
+      if constexpr (kFragRes >= 2) { fPr[s_] = FG0r[(0 * 4 + s_) * 64 + lane]; fQtr[s_] = FQ0r[(0 * 4 + s_) * 64 + lane]; }
+    }
+  }
   while (!done) {
     ++it;
     real* Pw = Pbuf + (size_t)(A.pbuf_single ? 0 : (it & 1)) * NW * MT * CT * 256;
@@ -841,7 +857,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
       for (int m = 0; m < MT; ++m) {
         vec4 acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = M::mma(FG[((m * 2 + 0) * 4 + s) * 64 + lane], r0[c][s], acc);
+        for (int s = 0; s < 4; ++s) acc = M::mma(kFragRes >= 2 ? fPr[s] : FG[((m * 2 + 0) * 4 + s) * 64 + lane], r0[c][s], acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Pw[(((wave * MT + m) * CT + c) * 4 + r) * 64 + lane] = acc[r];
       }
@@ -851,7 +867,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = M::mma(FQ[(((mo * MT + mi) * 2 + 0) * 4 + s) * 64 + lane], rho * z2[mi][c][s] - y2[mi][c][s], acc);
+          for (int s = 0; s < 4; ++s) acc = M::mma(kFragRes >= 2 ? fQtr[s] : FQ[(((mo * MT + mi) * 2 + 0) * 4 + s) * 64 + lane], rho * z2[mi][c][s] - y2[mi][c][s], acc);
         wh[mo][c] = acc;
       }
     }
@@ -887,7 +903,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = M::mma(FG[((m * 2 + 1) * 4 + s) * 64 + lane], eh[m][c][s], acc);
+        for (int s = 0; s < 4; ++s) acc = M::mma(kFragRes >= 1 ? fXr[s] : FG[((m * 2 + 1) * 4 + s) * 64 + lane], eh[m][c][s], acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const real xn = acc[r] * inv_a;
@@ -905,7 +921,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) zt = M::mma(FQ[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane], hh[mi][c][s], zt);
+          for (int s = 0; s < 4; ++s) zt = M::mma(kFragRes >= 1 ? fQr[s] : FQ[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane], hh[mi][c][s], zt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           gx[mo][c][r] = alpha * zt[r] + ((real)1 - alpha) * gx[mo][c][r];
