@@ -140,17 +140,24 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   real* Y2 = Z2 + MT * CT * 256;
   real* GX = Y2 + MT * CT * 256;
   const long long MS = (long long)MT * CT * 256, DU = NT + MS;
-  float* Y1P = reinterpret_cast<float*>(GX + MS);      // duals at the previous residual check (certificate), floats
-  float* Y2P = Y1P + NT;
   const int aa_m = min(A.accel_mem, kStreamAccelMax);
-  // Anderson state (acn_qp_tiled.hpp): u = (zh of every EVSE tile, zhr of every site tile), index uo = tile index, the
-  // site part after the NT tile entries
-  real* ZHs = GX + MS + (DU + 1) / 2;                   // the event's pre-projection points: [NT] then [MS]
-  real* UP = ZHs + DU;                                  // u after the previous event
-  real* FP = UP + DU;                                   // f = g - u at the previous event
-  real* GP = FP + DU;                                   // g at the previous event
-  float* HF = reinterpret_cast<float*>(GP + DU);        // dF ring [aa_m][DU]
-  float* HG = HF + (size_t)aa_m * DU;                   // dG ring
+  // The certificate's snapshot and the Anderson state live behind GX; their pointers are formed where they are used
+  // (residual check, event, restart) from an opaque copy of the workspace base, so that none of them is a live
+  // register pair across the solver loop:
+  //   Y1P [NT] Y2P [MS] floats: duals at the previous residual check (certificate)
+  //   ZHs [NT + MS]: the event's pre-projection points; UP, FP, GP [NT + MS] each: u, f, g at the previous event
+  //   HF, HG [aa_m][NT + MS] floats: the dF / dG rings.  Index uo = tile index, the site part after the NT tile entries.
+  const long long off_snap = 6 * NT + (long long)K * NP + 3 * MS, off_aa = off_snap + (DU + 1) / 2;
+#define ACNQP_STREAM_AA_PTRS()                                                                       \
+  unsigned aoff_ = 0;                                                                                \
+  asm volatile("" : "+s"(aoff_));                                                                    \
+  real* ZHs = W0 + off_aa + aoff_;                                                                   \
+  real* UP = ZHs + DU;                                                                               \
+  real* FP = UP + DU;                                                                                \
+  real* GP = FP + DU;                                                                                \
+  float* HF = reinterpret_cast<float*>(GP + DU);                                                     \
+  float* HG = HF + (size_t)aa_m * DU;                                                                \
+  (void)ZHs; (void)UP; (void)FP; (void)GP; (void)HF; (void)HG
   const real* FG = static_cast<const real*>(A.fragG);
   const real* FQ = static_cast<const real*>(A.fragQ);
   const real* Gm = static_cast<const real*>(A.G);
@@ -464,6 +471,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   // u of the Anderson map from the current (z, y): after the start and after every rho change
   auto reset_u = [&]() __attribute__((always_inline)) {
     if (aa_m <= 0) return;
+    ACNQP_STREAM_AA_PTRS();
     const real ir = 1.0 / rho;
 #pragma unroll 1
     for (int e = wave; e < NE; e += kStreamWaves) {
@@ -710,6 +718,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
         zhr[r] = alpha * zt[r] + (1.0 - alpha) * Z2[i] + Y2[i] * inv_rho;
       }
       if (ev_it) {
+        ACNQP_STREAM_AA_PTRS();
 #pragma unroll
         for (int r = 0; r < 4; ++r) ZHs[NT + ((mo * CT + c) * 4 + r) * 64 + lane] = zhr[r];
       } else {
@@ -739,6 +748,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       // ================= Anderson event (type II; acn_qp_tiled.hpp / oracle/admm_port.c) ============================
       // u = (zh, zhr) is the state of the fixed-point map.  Pass A: every tile's zh -> ZHs, the new column pair
       // (dF, dG) -> ring slot, the dot products dF_new . dF_j, dF_new . f, f . f.
+      ACNQP_STREAM_AA_PTRS();
       const bool col = aa_have_prev;
       const int slot = aa_head;
       real d[AMX + 2];
@@ -918,6 +928,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       }
     }
     if (check) {
+      unsigned soff_ = 0;
+      asm volatile("" : "+s"(soff_));
+      float* Y1P = reinterpret_cast<float*>(W0 + off_snap + soff_);
+      float* Y2P = Y1P + NT;
       real v[5] = {fmax(v0, sv0), v1, fmax(v2, sv2), v4, v5};
       stream_block_max<5, NWV>(v, SC, lane, wave);
       pri = v[0]; dua = v[1];
@@ -1150,4 +1164,5 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
 }
 
 #undef RELANE
+#undef ACNQP_STREAM_AA_PTRS
 }  // namespace acnqp

@@ -1,5 +1,5 @@
 // MFMA-tiled batched MPC QP solver for gfx950: one workgroup per problem, one wavefront per
-// 16-EVSE tile, every cross-EVSE product as a chain of v_mfma_f64_16x16x4_f64 / _f32_16x16x4_f32.
+// 16-EVSE tile, every cross-EVSE product as a chain of v_mfma_f64_16x16x4_f64.
 //
 // Device algorithm (restated on the CPU in oracle/admm_ref.py and oracle/admm_port.c):
 //   x~   = (a I + rho G'G)^-1 (sigma x - q + rho z1 - y1 + G'(rho z2 - y2))   per period
@@ -100,13 +100,6 @@ template <> struct Mfma<double> {
   __device__ static inline vec4 mma(double a, double b, vec4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
   static constexpr double proj_tol = 1e-13;
   static constexpr double big = 1e300;
-};
-template <> struct Mfma<float> {
-  typedef float vec4 __attribute__((ext_vector_type(4)));
-  __host__ __device__ static constexpr int rowof(int g, int r) { return 4 * g + r; }
-  __device__ static inline vec4 mma(float a, float b, vec4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-  static constexpr float proj_tol = 2e-6f;
-  static constexpr float big = 1e30f;
 };
 
 // ---- cross-lane helpers (DPP: plain VALU moves, no LDS crossbar) -------------------------------

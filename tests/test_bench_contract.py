@@ -1,5 +1,5 @@
 """The JSON line bench.py prints is a contract with the driver: check the committed record of the last GPU run
-(profiles/r02_bench.json, written by `python bench.py` on an MI355X) and the bookkeeping helpers, on the CPU."""
+(profiles/r03_bench.json, written by `python bench.py` on an MI355X) and the bookkeeping helpers, on the CPU."""
 import json
 import os
 
@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -36,8 +36,27 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d["ms_per_step"] * d["steps"] >= 500.0          # the timed region is long enough for the driver's clock
     assert "H2D" in cfg["workload"] and "D2H" in cfg["workload"]   # the metric SURVEY.md section 8d defines
     assert d["solver"]["solved"] == d["solver"]["problems"]
-    # roofline of the dominant kernel: algorithmic bytes of one launch / its HIP-event duration
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_avg_ms"] * 1e-3) / 1e9) <= 1e-9 * r["achieved"]
+    # roofline of the dominant kernel: ALGORITHMIC flops (sparse count of SURVEY 8d) x iterations run / the duration of
+    # ONE non-overlapped launch over the step's problems; the HBM view beside it
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    its = r["iterations_mean"] * r["problems_per_launch"]
+    assert abs(r["achieved"] - its * r["flops_per_iteration_sparse"] / (r["launch_ms"] * 1e-3) / 1e12) <= 1e-9 * r["achieved"]
+    assert r["flops_per_iteration_sparse"] < r["flops_per_iteration_dense"] and r["frac"] < r["frac_dense_count"]
+    assert abs(r["launch_ms"] - d["kernel_only"]["launch_ms"]) < 1e-12
+    h = r["hbm"]
+    assert abs(h["achieved_GBs"] - h["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) <= 1e-9 * h["achieved_GBs"]
+    assert r["traffic"] is None or r["traffic"] > h["algorithmic_bytes_per_launch"]
+    # the other BASELINE.json configurations are in the driver's line
+    legs = d["other_configs"]
+    for name in ("cfg2_caltech54_T24_b4096", "cfg2_jpl52_T24_b4096", "cfg3_site3_T12_b1024", "cfg4_synth512_T48_b2048", "stress_caltech54_T144_b256"):
+        leg = legs[name]
+        for k in ("kernel_ms", "iters_mean", "iters_max", "solved", "algorithmic_bytes_per_launch", "hbm_frac", "fp64_frac"):
+            assert k in leg, (name, k)
+        assert leg["solved"] == leg["batch"] and leg["failed"] == 0, name
+    assert legs["cfg4_synth512_T48_b2048"]["iters_mean"] >= 100      # instances that need more than one residual check
+    assert legs["cfg4_synth512_T48_b2048"]["anderson_columns"] == 5
+    sb = d["strict_batch256"]
+    assert sb["batch"] == 256 and sb["qps"] > 0 and sb["ms_per_call_median"] > sb["kernel_ms_median"]
 
 
 def test_bench_gpus_flag_needs_matching_world_size(monkeypatch):
@@ -59,4 +78,14 @@ def test_algorithmic_bytes_and_flops_bookkeeping():
     assert per_qp == 8 * 4 * 54 * 12 + 16 * 1 * 54 + 13 + 32 == 21645
     assert total == 256 * per_qp + site_bytes == 5557184
     assert bench.flops_per_iteration(54, 12, site) == 69024
+    # SURVEY 8d's sparse count on the headline workload: 4 nnz(A) + 12 (n + m) + 4 Mg^2 T ~ 51 k per iteration
+    from adacharge_amd import ObjectiveComponent, equal_share, quick_charge
+    from adacharge_amd.acn import Interface
+    from adacharge_amd.builder import build_batch
+
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    b = build_batch(sites.snapshot_batch(infra, 12, 64, seed=20240), infra, iface,
+                    [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)], "SOC")
+    assert 49e3 < bench.flops_per_iteration_sparse(b) < 53e3
+    assert 55e3 < bench.streamed_bytes_per_iteration(b) < 60e3
     assert np.isclose(bench.HBM_PEAK_GBS, 8000.0)
