@@ -137,6 +137,15 @@ template <typename T> __device__ inline T row_max(T v) {
   return v;
 }
 
+// A block-uniform double moved to the scalar unit (two v_readfirstlane): it then occupies a scalar register pair instead of
+// two vector registers per lane for as long as it lives (the kernels' penalty, its reciprocals, norms, scores ...).
+__device__ inline double uniform_scalar(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ inline float uniform_scalar(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, v))); }
+
 // 1 / sqrt(x): hardware estimate + two Newton steps (full precision for f64, cheaper than sqrt + div)
 __device__ inline double rsqrt_nr(double x) {
   double y = __builtin_amdgcn_rsq(x);
@@ -441,11 +450,11 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     }
   }
 
-  const real pd_user = (real)A.pdiag[b];
+  const real pd_user = uniform_scalar((real)A.pdiag[b]);
   // prox rows live in equilibrated units z' = s z:  1/2 lf z^2 = 1/2 (lf / s^2) z'^2,  dc max(z) = (dc / s) max(z')
-  const real lfb = A.lf ? (real)(A.lf[b] / (A.flat_scale * A.flat_scale)) : (real)0;
-  const real dcb = A.dc ? (real)(A.dc[b] / A.max_scale) : (real)0;
-  const real dfl = A.dfloor ? (real)(A.dfloor[b] * A.max_scale) : (real)0;
+  const real lfb = uniform_scalar(A.lf ? (real)(A.lf[b] / (A.flat_scale * A.flat_scale)) : (real)0);
+  const real dcb = uniform_scalar(A.dc ? (real)(A.dc[b] / A.max_scale) : (real)0);
+  const real dfl = uniform_scalar(A.dfloor ? (real)(A.dfloor[b] * A.max_scale) : (real)0);
   real tau_max = 0;   // warm start of the demand-charge level
   const real sigma = (real)A.sigma, alpha = (real)A.alpha;
   real rho = (real)A.rho0;
@@ -472,9 +481,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     }
     block_max<real, 4>(f, Red, lane, wave, NW);
     plain_windows = KS == 1 && f[3] == (real)0;
-    qnorm = f[1];
+    qnorm = uniform_scalar(f[1]);
     // scale-free Tikhonov floor reg_rel * |q|_inf / (max(ub) * T_b), LP-like problems only (effective_pdiag)
-    pd = effective_pdiag<real>(pd_user, (real)A.reg_rel, qnorm, f[2], A.horizon[b], lfb > (real)0 || dcb > (real)0);
+    pd = uniform_scalar(effective_pdiag<real>(pd_user, (real)A.reg_rel, qnorm, f[2], A.horizon[b], lfb > (real)0 || dcb > (real)0));
     if (f[0] > 0) {   // a session cannot meet its energy row inside its own bounds
 #pragma unroll
       for (int c = 0; c < CT; ++c)
@@ -506,7 +515,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
       for (int r = 0; r < 4; ++r) { z2[m][c][r] = 0; y2[m][c][r] = 0; gx[m][c][r] = 0; }
 
-  real a = sigma + pd + rho, inv_a = (real)1 / a, inv_rho = (real)1 / rho;
+  rho = uniform_scalar(rho);
+  real a = sigma + pd + rho, inv_a = uniform_scalar((real)1 / a), inv_rho = uniform_scalar((real)1 / rho);
   __syncthreads();
   for (int j = tid; j < 16 * MT; j += NW * 64) RowDj[j] = rho / (a + rho * RowLam[j]);
   __syncthreads();
@@ -530,15 +540,20 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 
   // ---- Anderson acceleration state (block-uniform scalars; vectors in C layout) ----------------------
   constexpr int AMX = AM > 0 ? AM : 1;
-  real up1[CT][4], fp1[CT][4], gp1[CT][4];             // u, f, g at the previous event (tile part)
-  real up2[MT][CT][4], fp2[MT][CT][4], gp2[MT][CT][4]; // ... site-row part (replicated like z2)
+  // u and f at the previous event, and the correction c applied then, kept as the float it was applied as (the
+  // general-shape kernel's and the C twin's form): g of the previous event is u + c exactly -- half the registers of a
+  // stored g.  Tile part, then the site-row part (replicated like z2).
+  real up1[CT][4], fp1[CT][4];
+  float cp1[CT][4];
+  real up2[MT][CT][4], fp2[MT][CT][4];
+  float cp2[MT][CT][4];
 #pragma unroll
   for (int c = 0; c < CT; ++c)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      up1[c][r] = 0; fp1[c][r] = 0; gp1[c][r] = 0;
+      up1[c][r] = 0; fp1[c][r] = 0; cp1[c][r] = 0.f;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) { up2[m][c][r] = 0; fp2[m][c][r] = 0; gp2[m][c][r] = 0; }
+      for (int m = 0; m < MT; ++m) { up2[m][c][r] = 0; fp2[m][c][r] = 0; cp2[m][c][r] = 0.f; }
     }
   int aa_cnt = 0, aa_head = 0, aa_cool = 0, aa_pen = 1;
   unsigned aa_valid = 0;
@@ -763,6 +778,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         x[c][r] = z1[c][r];
         y1[c][r] = -(qv[c][r] + pd * z1[c][r] + gty[r]);
         up1[c][r] = z1[c][r] + y1[c][r] * inv_rho;
+        cp1[c][r] = 0.f;
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -963,7 +979,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               hf[c * 4 + r] = cq1[c][r];
-              hg[c * 4 + r] = (float)(zh[c][r] - gp1[c][r]);
+              hg[c * 4 + r] = (float)(zh[c][r] - (up1[c][r] + (real)cp1[c][r]));
             }
           if (wave == 0) {
             float* hf2 = HistF2 + ((size_t)slot * 64 + lane) * (MT * CT * 4);
@@ -975,7 +991,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   hf2[(m * CT + c) * 4 + r] = cq2[m][c][r];
-                  hg2[(m * CT + c) * 4 + r] = (float)(zhr[m][c][r] - gp2[m][c][r]);
+                  hg2[(m * CT + c) * 4 + r] = (float)(zhr[m][c][r] - (up2[m][c][r] + (real)cp2[m][c][r]));
                 }
           }
         }
@@ -1013,9 +1029,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         for (int c = 0; c < CT; ++c)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            fp1[c][r] = f1[c][r]; gp1[c][r] = zh[c][r];
+            fp1[c][r] = f1[c][r];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) { fp2[m][c][r] = f2[m][c][r]; gp2[m][c][r] = zhr[m][c][r]; }
+            for (int m = 0; m < MT; ++m) fp2[m][c][r] = f2[m][c][r];
           }
         // block-wide sums: wave reductions (independent chains), one LDS slot per wave, the event's barrier
 #pragma unroll
@@ -1061,7 +1077,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        aa_have_prev = true; fn_prev = fn; aa_was = false;
+        aa_have_prev = true; fn_prev = uniform_scalar(fn); aa_was = false;
         // no extrapolation while the map drifts (|dF_new| <= kAaDrift |f|): the differences are rounding noise
         real dself = 0;   // |dF_new|^2 (d[slot] without a runtime register index)
 #pragma unroll
@@ -1091,6 +1107,15 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
           for (int j = 0; j < AMX; ++j) gam[j] = __shfl(ae, 8 * j + AMX);
           STAMP(11);   // event: LDL' solve
+          real cor1[CT][4], cor2[MT][CT][4];
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              cor1[c][r] = 0;
+#pragma unroll
+              for (int m = 0; m < MT; ++m) cor2[m][c][r] = 0;
+            }
 #pragma unroll
           for (int j = 0; j < AMX; ++j) {
             const int jj = j < aa_m ? j : aa_m - 1;
@@ -1100,12 +1125,30 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
             for (int c = 0; c < CT; ++c)
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                zh[c][r] -= gam[j] * (real)hg[c * 4 + r];
+                cor1[c][r] += gam[j] * (real)hg[c * 4 + r];
 #pragma unroll
-                for (int m = 0; m < MT; ++m) zhr[m][c][r] -= gam[j] * (real)hg2[(m * CT + c) * 4 + r];
+                for (int m = 0; m < MT; ++m) cor2[m][c][r] += gam[j] * (real)hg2[(m * CT + c) * 4 + r];
               }
           }
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              cp1[c][r] = (float)cor1[c][r];            // kept as float; u = g - c with exactly that c
+              zh[c][r] -= (real)cp1[c][r];
+#pragma unroll
+              for (int m = 0; m < MT; ++m) { cp2[m][c][r] = (float)cor2[m][c][r]; zhr[m][c][r] -= (real)cp2[m][c][r]; }
+            }
           aa_was = true;
+        } else {
+#pragma unroll
+          for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              cp1[c][r] = 0.f;
+#pragma unroll
+              for (int m = 0; m < MT; ++m) cp2[m][c][r] = 0.f;
+            }
         }
 #pragma unroll
         for (int c = 0; c < CT; ++c)
@@ -1245,8 +1288,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           }
       }
       block_max<real, 6>(v, Red, lane, wave, NW);
-      pri = v[0];
-      dua = v[1];
+      pri = uniform_scalar(v[0]);
+      dua = uniform_scalar(v[1]);
       const real npri = v[2];
       const real ndua = fmax(fmax(v[4], v[5]), qnorm);
       const real eps_p = (real)A.eps_abs + (real)A.eps_rel * npri;
@@ -1388,7 +1431,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         have_prev = true;
       }
       const real score = fmax(pri / fmax(eps_p, (real)1e-300), dua / fmax(eps_d, (real)1e-300));
-      if (score < (real)kStallGain * best_score) { best_score = score; best_it = it; }
+      if (score < (real)kStallGain * best_score) { best_score = uniform_scalar(score); best_it = it; }
       const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel, A.inacc_floor);
       const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= (real)kStallNear * best_score;
       if (done) {
@@ -1403,10 +1446,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         const real tol_eff = (real)A.adapt_tol * ((real)1 + (real)n_adapt * (real)(1.0 / kAdaptWiden));
         if (ratio > tol_eff || ratio < (real)1 / tol_eff) {
           ++n_adapt;
-          rho = fmin(fmax(rho * ratio, (real)1e-6), (real)1e6);
+          rho = uniform_scalar(fmin(fmax(rho * ratio, (real)1e-6), (real)1e6));
           a = sigma + pd + rho;
-          inv_a = (real)1 / a;
-          inv_rho = (real)1 / rho;
+          inv_a = uniform_scalar((real)1 / a);
+          inv_rho = uniform_scalar((real)1 / rho);
           for (int j = tid; j < 16 * MT; j += NW * 64) RowDj[j] = rho / (a + rho * RowLam[j]);
           __syncthreads();   // block-uniform branch: every wave sees the new D before the next iteration
           if constexpr (AM > 0) {
@@ -1420,8 +1463,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   up1[c][r] = z1[c][r] + y1[c][r] / rho;
+                  cp1[c][r] = 0.f;
 #pragma unroll
-                  for (int m = 0; m < MT; ++m) up2[m][c][r] = z2[m][c][r] + y2[m][c][r] / rho;
+                  for (int m = 0; m < MT; ++m) { up2[m][c][r] = z2[m][c][r] + y2[m][c][r] / rho; cp2[m][c][r] = 0.f; }
                 }
             }
           }
