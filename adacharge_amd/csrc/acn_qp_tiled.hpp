@@ -144,6 +144,15 @@ __device__ inline double uniform_scalar(double v) {
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+// A double constant materialised in a scalar register pair where it is used (two s_mov_b32), opaque to the optimiser:
+// without this the compiler hoists every such constant of the kernel (1e300, 1.2, 0.9, 1e-300, 1e-6 ...) into a vector
+// register pair at the top and keeps -- or spills -- it across the solver loop.
+__device__ inline double scalar_const(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ inline float uniform_scalar(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, v))); }
 
 // 1 / sqrt(x): hardware estimate + two Newton steps (full precision for f64, cheaper than sqrt + div)
@@ -184,14 +193,21 @@ __device__ inline double rcp_small(float nf) {
 // LDS carve-up in units of `real`; shared by host (size) and device (offsets)
 constexpr int kXS = 18;   // row stride (reals) of the per-wave 16 x 16 transpose scratch: 16-B aligned quads
 struct TiledLds {
-  int pbuf, xpose, red, rowc, aared, aah, hist, total;   // offsets in reals; hist..total hold floats
+  int pbuf, xpose, red, rowc, aared, aah, hist, snap, total;   // offsets in reals; hist..total hold floats
   int hist1, hist2;                                // floats per history column: tile part, site-row part
+  int pstride;                                     // reals between the partial-tile regions of two waves in a slab
   __host__ __device__ TiledLds(int NW, int MT, int CT, int NP, int K, int AM, int accel_mem, int real_bytes, int pbuf_single = 0) {
     int o = 0;
-    pbuf = o;  o += (pbuf_single ? 1 : 2) * NW * MT * CT * 4 * 64;   // partial tiles (double-buffered unless pbuf_single)
-    xpose = o; o += NW * CT * 16 * kXS;          // C layout <-> session layout, private to each wave
+    // Partial tiles: two slabs (one with pbuf_single), each NW per-wave regions.  With two slabs the wave's transpose
+    // scratch (C layout <-> session layout, CT * 16 * kXS reals) ALIASES the wave's own region of the slab that is idle
+    // in the current iteration -- everybody finished reading it before this iteration's barrier, and its next writer is
+    // this very wave at the top of the next iteration -- so a region is as long as the longer of the two.
+    const int ptile = MT * CT * 4 * 64, xp = CT * 16 * kXS;
+    pstride = pbuf_single ? ptile : (ptile > xp ? ptile : xp);
+    pbuf = o;  o += (pbuf_single ? 1 : 2) * NW * pstride;
+    xpose = o; o += pbuf_single ? NW * xp : 0;   // a separate scratch only when there is no idle slab
     red = o;   o += 16 * kNumRed + 8;
-    rowc = o;  o += 3 * 16 * MT;                 // per site row: eigenvalue, limit, rho / (a + rho lam)
+    rowc = o;  o += 3 * 16 * MT + 8 * MT;        // per site row: eigenvalue, limit, rho / (a + rho lam); then the row types (ints)
     aared = o; o += accel_mem > 0 ? NW * (AM + 2) : 0;          // per-wave partial dot products
     aah = o;   o += accel_mem > 0 ? NW * (AM * AM + AM) : 0;    // per-wave copy of the Gram matrix and rhs
     o = (o + 1) & ~1;
@@ -200,6 +216,9 @@ struct TiledLds {
     hist2 = 64 * MT * CT * 4;
     const int hfloats = 2 * accel_mem * (hist1 + hist2);        // dF ring then dG ring
     o += (hfloats * 4 + real_bytes - 1) / real_bytes;
+    o = (o + 1) & ~1;
+    snap = o;                                                   // duals at the previous residual check (certificate),
+    o += ((hist1 + hist2) * 4 + real_bytes - 1) / real_bytes;   // floats: [tid][CT*4], then ONE copy of the site part [lane][MT*CT*4]
     total = (o + 1) & ~1;
   }
   // bytes of LDS one Anderson column costs, and everything else (to size accel_mem on the host)
@@ -317,6 +336,7 @@ __device__ inline void block_max(real (&v)[NV], real* Red, int lane, int wave, i
 template <typename real, int NW, int CT, int MT, int KS, int OCC, int AM>
 __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArgs A_kernarg) {
   using M = Mfma<real>;
+#define BIGC ((real)scalar_const((double)M::big))
   using vec4 = typename M::vec4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   real* sm = reinterpret_cast<real*>(smem_raw);
@@ -347,7 +367,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   const int aa_m = AM > 0 ? min(A.accel_mem, AM) : 0;
   const TiledLds L(NW, MT, CT, NP, A.K, AM, aa_m, (int)sizeof(real), A.pbuf_single);
   real* Pbuf = sm + L.pbuf;
-  real* Xw = sm + L.xpose + (size_t)wave * CT * 16 * kXS;   // this wave's transpose scratch
+  const int PS = L.pstride;                                 // reals between two waves' regions of a slab
+  // this wave's transpose scratch: its region of the idle slab (re-pointed at the top of every iteration; the start
+  // stores its partial tiles in slab 0, so slab 1 is the idle one there), or a scratch of its own with one slab
+  real* Xw = A.pbuf_single ? sm + L.xpose + (size_t)wave * CT * 16 * kXS : Pbuf + (size_t)NW * PS + (size_t)wave * PS;
+  float* Y1P = reinterpret_cast<float*>(sm + L.snap) + (size_t)tid * (CT * 4);                 // certificate snapshot, own slot
+  float* Y2P = reinterpret_cast<float*>(sm + L.snap) + (size_t)L.hist1 + (size_t)lane * (MT * CT * 4);   // site part: ONE copy, written by wave 0
   real* Red = sm + L.red;
   const real* Gm = static_cast<const real*>(A.G);
   const real* Gh = static_cast<const real*>(A.Ghat);
@@ -367,25 +392,34 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   real* RowLam = sm + L.rowc;
   real* RowLim = RowLam + 16 * MT;
   real* RowDj = RowLim + 16 * MT;
-  int rtype[MT][4];
-#pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rtype[m][r] = A.rowtype[16 * m + M::rowof(g, r)];
-  for (int j = tid; j < 16 * MT; j += NW * 64) { RowLam[j] = Lm[j]; RowLim[j] = RL[j]; }
+  // row types: an LDS table in the lanes' own order -- entry (m, g, r) = type of row 16 m + rowof(g, r), the four of a
+  // lane adjacent (one 16-byte read where they are needed) -- instead of four registers per row tile across the loop
+  int* RowTy = reinterpret_cast<int*>(RowDj + 16 * MT);
+  for (int j = tid; j < 16 * MT; j += NW * 64) {
+    RowLam[j] = Lm[j]; RowLim[j] = RL[j];
+    const int m_ = j >> 4, g_ = (j >> 2) & 3, r_ = j & 3;
+    RowTy[j] = A.rowtype[16 * m_ + M::rowof(g_, r_)];
+  }
+  auto row_types = [&](int m, int (&ty)[4]) __attribute__((always_inline)) {
+    const int4 v = *reinterpret_cast<const int4*>(RowTy + (m * 4 + g) * 4);
+    ty[0] = v.x; ty[1] = v.y; ty[2] = v.z; ty[3] = v.w;
+  };
 
   // ---- problem data -> registers (C layout) --------------------------------------------
   real x[CT][4], z1[CT][4], y1[CT][4], qv[CT][4], lbv[CT][4], ubv[CT][4];
-  real pk[CT];
+  // the peak limit of the lane's period (scaled like its row), fetched where a peak row is projected
+  auto peak_at = [&](int c) __attribute__((always_inline)) -> real {
+    const int tt = 16 * c + t;
+    double pv = 1e300;
+    if (A.peak && tt < Tm) pv = A.peak[(size_t)b * Tm + tt];
+    return pv < (double)BIGC ? (real)(pv * A.peak_scale) : BIGC;
+  };
   bool evact[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) evact[r] = 16 * wave + M::rowof(g, r) < N;
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
     const int tt = 16 * c + t;
-    double pv = 1e300;
-    if (A.peak && tt < Tm) pv = A.peak[(size_t)b * Tm + tt];
-    pk[c] = pv < (double)M::big ? (real)(pv * A.peak_scale) : M::big;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int ev = 16 * wave + M::rowof(g, r);
@@ -496,7 +530,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         for (int k = tid; k < A.Mg * Tm; k += NW * 64) A.y_out[(size_t)b * A.Mg * Tm + k] = 0;
       if (tid == 0) {
         A.status[b] = 4; A.iters[b] = 0;
-        A.pri[b] = (double)M::big; A.dua[b] = (double)M::big; A.obj[b] = 0;
+        A.pri[b] = (double)BIGC; A.dua[b] = (double)BIGC; A.obj[b] = 0;
       }
       return;
     }
@@ -522,20 +556,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   __syncthreads();
 
   int status = 2, it = 0, n_adapt = 0, best_it = 0;
-  real best_score = M::big;
-  real pri = M::big, dua = M::big;
+  real best_score = BIGC;
+  real pri = BIGC, dua = BIGC;
   bool done = false, have_prev = false;
   // duals at the previous residual check (infeasibility certificate), kept in single precision: the certificate asks
   // whether v = y - y_prev is a ray (large, A'v ~ 0, negative support); 2^-24 |y| of rounding cannot fake one
-  float y1p[CT][4], y2p[MT][CT][4];
-#pragma unroll
-  for (int c = 0; c < CT; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      y1p[c][r] = 0.f;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) y2p[m][c][r] = 0.f;
-    }
+  // (in LDS since round 3: Y1P / Y2P; it is read once per residual check and was what the allocator spilled first)
   const real ptol_scale = M::proj_tol;
 
   // ---- Anderson acceleration state (block-uniform scalars; vectors in C layout) ----------------------
@@ -543,10 +569,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   // u and f at the previous event, and the correction c applied then, kept as the float it was applied as (the
   // general-shape kernel's and the C twin's form): g of the previous event is u + c exactly -- half the registers of a
   // stored g.  Tile part, then the site-row part (replicated like z2).
-  real up1[CT][4], fp1[CT][4];
-  float cp1[CT][4];
-  real up2[MT][CT][4], fp2[MT][CT][4];
-  float cp2[MT][CT][4];
+  // f of the previous event only ever enters the difference dF = f - f_prev, itself stored as a float: f_prev is kept
+  // as a float too (|dF| >= 1e-3 |f| whenever the column is used -- kAaDrift -- so this costs <= 6e-5 of a column).
+  real up1[CT][4];
+  float fp1[CT][4], cp1[CT][4];
+  real up2[MT][CT][4];
+  float fp2[MT][CT][4], cp2[MT][CT][4];
 #pragma unroll
   for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -613,8 +641,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           bool need = smode[k] == 0;
 #endif
           real m = mu[k];
-          real lo = eq ? -M::big : (real)-1;   // inequality: m >= 0, so (-1, .) brackets m = 0
-          real hi = M::big;
+          real lo = eq ? -BIGC : (real)-1;   // inequality: m >= 0, so (-1, .) brackets m = 0
+          real hi = BIGC;
           int guard = 0;
           auto newton_pass = [&]() {
             ++guard;
@@ -653,9 +681,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
             lo = (need && d > 0) ? m : lo;
             hi = (need && !(d > 0)) ? m : hi;
             // flat piece with an open bracket (rare): fetch the true bracket ends so the fallback bisects
-            const bool open = need && nf <= 0.f && !(lo > -M::big && hi < M::big);
+            const bool open = need && nf <= 0.f && !(lo > -BIGC && hi < BIGC);
             if (__any(open)) {   // the bracket ends are only ever needed here
-              real lo_l = M::big, hi_l = -M::big;
+              real lo_l = BIGC, hi_l = -BIGC;
 #pragma unroll
               for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -668,7 +696,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
               lo = open ? fmax(lo, lo0) : lo;
               hi = open ? fmin(hi, hi0) : hi;
             }
-            const bool bracketed = lo > -M::big && hi < M::big;
+            const bool bracketed = lo > -BIGC && hi < BIGC;
             const real mid = (real)0.5 * (lo + hi);
             bool newton = nf > 0.f;
             real cand = newton ? m + d * (real)rcp_small(nf) : (bracketed ? mid : fmin(fmax(m + d, lo), hi));
@@ -742,7 +770,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        zs[c][r] = -(real)kStartGain * qv[c][r];
+        zs[c][r] = -(real)scalar_const(kStartGain) * qv[c][r];
         if (warm) {
           const int tt = 16 * c + t, ev = 16 * wave + M::rowof(g, r);
           const bool ok = ev < N && tt < Tm;
@@ -786,7 +814,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = M::mma(FG0[((m * 2 + 0) * 4 + s) * 64 + lane], z1[c][s], acc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Pbuf[(((wave * MT + m) * CT + c) * 4 + r) * 64 + lane] = acc[r];
+        for (int r = 0; r < 4; ++r) Pbuf[(size_t)wave * PS + ((m * CT + c) * 4 + r) * 64 + lane] = acc[r];
       }
     }
     __syncthreads();
@@ -799,7 +827,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         for (int r = 0; r < 4; ++r) {
           real g0 = 0;
 #pragma unroll
-          for (int wv = 0; wv < NW; ++wv) g0 += Pbuf[(((wv * MT + m) * CT + c) * 4 + r) * 64 + lane];
+          for (int wv = 0; wv < NW; ++wv) g0 += Pbuf[(size_t)wv * PS + ((m * CT + c) * 4 + r) * 64 + lane];
           g0v[m][r] = g0;
         }
 #pragma unroll
@@ -838,15 +866,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   }
   while (!done) {
     ++it;
-    real* Pw = Pbuf + (size_t)(A.pbuf_single ? 0 : (it & 1)) * NW * MT * CT * 256;
+    real* Pw = Pbuf + (size_t)(A.pbuf_single ? 0 : (it & 1)) * NW * PS;
+    if (!A.pbuf_single) Xw = Pbuf + (size_t)((it + 1) & 1) * NW * PS + (size_t)wave * PS;   // the idle slab's own region
     // Per-lane constants every predicate of the loop body derives from (row types, session windows, modes) are made
     // opaque once per iteration: the compiler then evaluates `rtype == kRowBox`, `(swm >> k) & 1` ... where they are
     // used (one v_cmp each) instead of hoisting dozens of loop-invariant lane masks into SGPR pairs, which it can
     // only keep by spilling them to VGPR lanes (100-450 SGPR spills per instantiation before this).
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(rtype[m][r]));
 #pragma unroll
     for (int k = 0; k < KS; ++k) { asm volatile("" : "+v"(swm[k])); asm volatile("" : "+v"(smode[k])); }
     // an offset the compiler cannot see through keeps the fragment loads inside the loop (the base pointers stay
@@ -868,7 +893,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = M::mma(kFragRes >= 2 ? fPr[s] : FG[((m * 2 + 0) * 4 + s) * 64 + lane], r0[c][s], acc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Pw[(((wave * MT + m) * CT + c) * 4 + r) * 64 + lane] = acc[r];
+        for (int r = 0; r < 4; ++r) Pw[(size_t)wave * PS + ((m * CT + c) * 4 + r) * 64 + lane] = acc[r];
       }
 #pragma unroll
       for (int mo = 0; mo < MT; ++mo) {
@@ -894,7 +919,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         for (int r = 0; r < 4; ++r) {
           real g0 = 0;
 #pragma unroll
-          for (int wv = 0; wv < NW; ++wv) g0 += Pw[(((wv * MT + m) * CT + c) * 4 + r) * 64 + lane];
+          for (int wv = 0; wv < NW; ++wv) g0 += Pw[(size_t)wv * PS + ((m * CT + c) * 4 + r) * 64 + lane];
           const real w_ = wh[m][c][r];
           const real lam_ = RowLam[16 * m + M::rowof(g, r)];
           const real e_ = w_ - RowDj[16 * m + M::rowof(g, r)] * (g0 + lam_ * w_);
@@ -961,12 +986,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
             for (int r = 0; r < 4; ++r) {
               f1[c][r] = zh[c][r] - up1[c][r];
               fa += f1[c][r] * f1[c][r];
-              cq1[c][r] = (float)(f1[c][r] - fp1[c][r]);
+              cq1[c][r] = (float)(f1[c][r] - (real)fp1[c][r]);
 #pragma unroll
               for (int m = 0; m < MT; ++m) {
                 f2[m][c][r] = zhr[m][c][r] - up2[m][c][r];
                 fb += f2[m][c][r] * f2[m][c][r];
-                cq2[m][c][r] = (float)(f2[m][c][r] - fp2[m][c][r]);
+                cq2[m][c][r] = (float)(f2[m][c][r] - (real)fp2[m][c][r]);
               }
             }
           d[AMX + 1] = fa + w0 * fb;
@@ -1029,9 +1054,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         for (int c = 0; c < CT; ++c)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            fp1[c][r] = f1[c][r];
+            fp1[c][r] = (float)f1[c][r];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) fp2[m][c][r] = f2[m][c][r];
+            for (int m = 0; m < MT; ++m) fp2[m][c][r] = (float)f2[m][c][r];
           }
         // block-wide sums: wave reductions (independent chains), one LDS slot per wave, the event's barrier
 #pragma unroll
@@ -1051,7 +1076,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         STAMP(10);   // event: column, dot products, block reduction
         const real fn = sqrt(d[AMX + 1]);
         bool keep = col;
-        if (aa_was && fn > (real)kAaSafe * fn_prev) {
+        if (aa_was && fn > (real)scalar_const(kAaSafe) * fn_prev) {
           // the accelerated step made the residual worse: clear the ring, back off exponentially
           aa_cnt = 0; aa_head = 0; aa_valid = 0; keep = false;
           __builtin_amdgcn_wave_barrier();
@@ -1082,7 +1107,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         real dself = 0;   // |dF_new|^2 (d[slot] without a runtime register index)
 #pragma unroll
         for (int j = 0; j < AMX; ++j) dself = j == slot ? d[j] : dself;
-        if (aa_cnt > 0 && aa_cool == 0 && !check && dself > (real)(kAaDrift * kAaDrift) * d[AMX + 1]) {
+        if (aa_cnt > 0 && aa_cool == 0 && !check && dself > (real)scalar_const(kAaDrift * kAaDrift) * d[AMX + 1]) {
           // gamma = (H + eta I)^-1 b: Gauss-Jordan on the augmented AM x (AM + 1) system spread over the
           // wave, lane 8 i + j holding entry (i, j) (H is a regularised Gram matrix: no pivoting); a few
           // registers per lane instead of the whole matrix in every lane.
@@ -1091,7 +1116,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           real tr = 0;
 #pragma unroll
           for (int i = 0; i < AMX; ++i) tr += AaH[i * AMX + i];          // dead slots hold zeros
-          const real eta = (real)kAaReg * tr + (real)(sizeof(real) == 8 ? 1e-300 : 1e-37);
+          const real eta = (real)scalar_const(kAaReg) * tr + (real)scalar_const(1e-300);
           real ae = 0;
           if (gi < AMX && gj <= AMX) ae = gj < AMX ? AaH[gi * AMX + gj] : AaH[AMX * AMX + gi];
           if (gi < AMX && gi == gj) ae = ((aa_valid >> gi) & 1u) ? ae + eta : (real)1;
@@ -1167,10 +1192,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     for (int c = 0; c < CT; ++c) {
 #pragma unroll
       for (int mo = 0; mo < MT; ++mo) {
+        int rty[4];
+        row_types(mo, rty);
+        const real pkc = A.peak ? peak_at(c) : BIGC;   // block-uniform branch: only sites with a peak row load it
         real scl[2] = {(real)1, (real)1};   // radial clip factor of the register pairs (0,1), (2,3)
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          if (rtype[mo][2 * pr] == kRowSocRe) {
+          if (rty[2 * pr] == kRowSocRe) {
             const real re = zhr[mo][c][2 * pr], im = zhr[mo][c][2 * pr + 1], lim = RowLim[16 * mo + M::rowof(g, 2 * pr)];
             const real n2 = re * re + im * im;
             if (n2 > lim * lim) scl[pr] = lim * rsqrt_nr(n2);
@@ -1180,9 +1208,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         for (int r = 0; r < 4; ++r) {
           const real zh_ = zhr[mo][c][r];
           real zn = zh_;
-          const int ty = rtype[mo][r];
+          const int ty = rty[r];
           if (ty == kRowBox) zn = fmin(zh_, RowLim[16 * mo + M::rowof(g, r)]);
-          else if (ty == kRowPeak) zn = fmin(zh_, pk[c]);
+          else if (ty == kRowPeak) zn = fmin(zh_, pkc);
           else if (ty == kRowQuad) zn = zh_ * (rho / (rho + lfb));
           // kRowMax: zn = zh_ here; the horizon-wide prox follows the tile loop
           else if (ty == kRowSocRe || ty == kRowSocIm) zn = zh_ * scl[r >> 1];
@@ -1200,16 +1228,19 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
       for (int c = 0; c < CT; ++c) zv[c] = 0;
 #pragma unroll
-      for (int mo = 0; mo < MT; ++mo)
+      for (int mo = 0; mo < MT; ++mo) {
+        int rty[4];
+        row_types(mo, rty);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (rtype[mo][r] == kRowMax) {
+          if (rty[r] == kRowMax) {
             mine = true;
 #pragma unroll
             for (int c = 0; c < CT; ++c) zv[c] = z2[mo][c][r];   // = zh of that row (left unprojected above)
           }
+      }
       const real cw = dcb * inv_rho;
-      real vmax_l = -M::big;
+      real vmax_l = -BIGC;
 #pragma unroll
       for (int c = 0; c < CT; ++c) vmax_l = (16 * c + t < Tm) ? fmax(vmax_l, zv[c]) : vmax_l;
       const real vmax = row_max<real>(vmax_l);
@@ -1238,10 +1269,12 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
       tau_max = tau;
       const real lev = fmax(tau, dfl);
 #pragma unroll
-      for (int mo = 0; mo < MT; ++mo)
+      for (int mo = 0; mo < MT; ++mo) {
+        int rty[4];
+        row_types(mo, rty);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (rtype[mo][r] == kRowMax) {
+          if (rty[r] == kRowMax) {
 #pragma unroll
             for (int c = 0; c < CT; ++c) {
               const real zh_ = z2[mo][c][r];
@@ -1250,6 +1283,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
               z2[mo][c][r] = zn;
             }
           }
+      }
     }
     });
 #pragma unroll
@@ -1310,10 +1344,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-              gtv = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * wave + t], y2[m][c][s] - y2p[m][c][s], gtv);
+              gtv = M::mma(Gm[(size_t)(16 * m + M::rowof(g, s)) * NP + 16 * wave + t], y2[m][c][s] - (real)Y2P[(m * CT + c) * 4 + (s)], gtv);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const real v1 = y1[c][r] - y1p[c][r];
+            const real v1 = y1[c][r] - (real)Y1P[c * 4 + r];
             w6[0] = fmax(w6[0], fabs(v1));
             w6[1] = fmax(w6[1], fabs(v1 + gtv[r]));
           }
@@ -1321,41 +1355,45 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const real v2 = y2[m][c][r] - y2p[m][c][r];
+              const real v2 = y2[m][c][r] - (real)Y2P[(m * CT + c) * 4 + (r)];
               w6[0] = fmax(w6[0], fabs(v2));
             }
           }
         }
         block_max<real, 3>(w6, Red, lane, wave, NW);
         const real vn = w6[0];
-        const real vtol = (real)1e-4 * vn;
-        if (vn > (real)1e-12 * fmax((real)1, qnorm) && w6[1] <= vtol) {
+        const real vtol = (real)scalar_const(1e-4) * vn;
+        if (vn > (real)scalar_const(1e-12) * fmax((real)1, qnorm) && w6[1] <= vtol) {
           real bad = 0;
           if (wave == 0) {   // the site-row state is replicated: count it once
 #pragma unroll
             for (int c = 0; c < CT; ++c)
 #pragma unroll
-              for (int m = 0; m < MT; ++m)
+              for (int m = 0; m < MT; ++m) {
+                int rty[4];
+                row_types(m, rty);
+                const real pkc = peak_at(c);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  const real v2 = y2[m][c][r] - y2p[m][c][r];
-                  const int ty = rtype[m][r];
+                  const real v2 = y2[m][c][r] - (real)Y2P[(m * CT + c) * 4 + (r)];
+                  const int ty = rty[r];
                   if (ty == kRowBox) { ssum += RowLim[16 * m + M::rowof(g, r)] * fmax(v2, (real)0); if (v2 < -vtol) bad = 1; }
                   else if (ty == kRowPeak) {
-                    if (pk[c] < M::big) ssum += pk[c] * fmax(v2, (real)0); else if (v2 > vtol) bad = 1;
+                    if (pkc < BIGC) ssum += pkc * fmax(v2, (real)0); else if (v2 > vtol) bad = 1;
                     if (v2 < -vtol) bad = 1;
                   } else if (ty == kRowSocRe) {
-                    const real vi = y2[m][c][(r + 1) & 3] - y2p[m][c][(r + 1) & 3];
+                    const real vi = y2[m][c][(r + 1) & 3] - (real)Y2P[(m * CT + c) * 4 + ((r + 1) & 3)];
                     ssum += RowLim[16 * m + M::rowof(g, r)] * sqrt(v2 * v2 + vi * vi);
                   } else if (ty == kRowSocIm) {
                   } else if (fabs(v2) > vtol) bad = 1;   // free / quadratic rows admit no ray
                 }
+              }
           }
           // sessions: transpose v1 to session layout and bound each session's support function
 #pragma unroll
           for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Xw[(c * 16 + M::rowof(g, r)) * kXS + t] = y1[c][r] - y1p[c][r];
+            for (int r = 0; r < 4; ++r) Xw[(c * 16 + M::rowof(g, r)) * kXS + t] = y1[c][r] - (real)Y1P[c * 4 + r];
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1369,7 +1407,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           for (int k = 0; k < KS; ++k) {
             if (k == 0 || k < A.K) {
               covered |= swm[k];
-              real lmin_l = M::big, lmax_l = -M::big;
+              real lmin_l = BIGC, lmax_l = -BIGC;
 #pragma unroll
               for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -1379,7 +1417,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
               lam3[0] = quarter_min<real>(lmin_l);
               lam3[1] = quarter_max<real>(lmax_l);
               lam3[2] = 0;
-              real best = M::big;
+              real best = BIGC;
 #pragma unroll
               for (int j = 0; j < 3; ++j) {
                 real l_ = lam3[j];
@@ -1421,32 +1459,37 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) y1p[c][r] = (float)y1[c][r];
+          for (int r = 0; r < 4; ++r) Y1P[c * 4 + r] = (float)y1[c][r];
+        if (wave == 0) {   // the site-row state is replicated: one copy; every other wave's reads of the old one lie before
+                           // the barriers of this check's reductions
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+          for (int m = 0; m < MT; ++m)
 #pragma unroll
-          for (int c = 0; c < CT; ++c)
+            for (int c = 0; c < CT; ++c)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) y2p[m][c][r] = (float)y2[m][c][r];
+              for (int r = 0; r < 4; ++r) Y2P[(m * CT + c) * 4 + r] = (float)y2[m][c][r];
+        }
         have_prev = true;
       }
-      const real score = fmax(pri / fmax(eps_p, (real)1e-300), dua / fmax(eps_d, (real)1e-300));
-      if (score < (real)kStallGain * best_score) { best_score = uniform_scalar(score); best_it = it; }
+      const real tiny_ = (real)scalar_const(1e-300);
+      const real score = fmax(pri / fmax(eps_p, tiny_), dua / fmax(eps_d, tiny_));
+      if (score < (real)scalar_const(kStallGain) * best_score) { best_score = uniform_scalar(score); best_it = it; }
       const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel, A.inacc_floor);
-      const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= (real)kStallNear * best_score;
+      const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= (real)scalar_const(kStallNear) * best_score;
       if (done) {
       } else if (it >= max_iter_p || stalled) {
         done = true;
         if (inacc) status = 5;   // solved, inaccurately
       }
       else if (adapt_p > 0 && it % adapt_p == 0) {
-        const real sp = pri / fmax(npri, (real)1e-12);
-        const real sd = dua / fmax(ndua, (real)1e-12);
-        const real ratio = sqrt(sp / fmax(sd, (real)1e-30));
+        const real e12_ = (real)scalar_const(1e-12);
+        const real sp = pri / fmax(npri, e12_);
+        const real sd = dua / fmax(ndua, e12_);
+        const real ratio = sqrt(sp / fmax(sd, (real)scalar_const(1e-30)));
         const real tol_eff = (real)A.adapt_tol * ((real)1 + (real)n_adapt * (real)(1.0 / kAdaptWiden));
         if (ratio > tol_eff || ratio < (real)1 / tol_eff) {
           ++n_adapt;
-          rho = uniform_scalar(fmin(fmax(rho * ratio, (real)1e-6), (real)1e6));
+          rho = uniform_scalar(fmin(fmax(rho * ratio, (real)scalar_const(1e-6)), (real)scalar_const(1e6)));
           a = sigma + pd + rho;
           inv_a = uniform_scalar((real)1 / a);
           inv_rho = uniform_scalar((real)1 / rho);
@@ -1526,6 +1569,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #endif
   if (!retry_wanted(pass, A.retry_passes, status, it, A.stall_iters, A.adapt_every)) break;
   }   // passes
+#undef BIGC
 }
 
 }  // namespace acnqp
