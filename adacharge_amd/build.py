@@ -61,9 +61,11 @@ def up_to_date() -> bool:
     return not _stale(LIB, deps | {os.path.abspath(__file__)})
 
 
-def build_hip_library(force: bool = False, verbose: bool = True, extra_flags=(), out: str = LIB) -> str:
+def build_hip_library(force: bool = False, verbose: bool = True, extra_flags=(), out: str = LIB, check_hazards: bool = True) -> str:
     """Compile stale translation units (in parallel) and link.  ``extra_flags`` / ``out``: diagnostic builds
-    (e.g. ``-DACNQP_STAMPS``) into another file, always from scratch."""
+    (e.g. ``-DACNQP_STAMPS``) into another file, always from scratch.  ``check_hazards``: disassemble the linked
+    library and refuse it if a >64-bit buffer store is followed by a VALU write of its data registers (the gfx950
+    store-data hazard the compiler does not cover, adacharge_amd/store_hazard.py)."""
     diagnostic = bool(extra_flags) or out != LIB
     if not force and not diagnostic and up_to_date():
         return LIB
@@ -92,6 +94,21 @@ def build_hip_library(force: bool = False, verbose: bool = True, extra_flags=(),
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    if check_hazards:
+        try:
+            from . import store_hazard
+        except ImportError:   # run as a script
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            import store_hazard
+
+        stores, found = store_hazard.scan_library(out)
+        if verbose:
+            print(f"[build] store-data hazard scan: {stores} buffer stores of more than 64 bits, {len(found)} unguarded", flush=True)
+        if found:
+            os.replace(out, out + ".rejected")
+            raise RuntimeError(f"{len(found)} buffer stores of more than 64 bits are followed by a VALU write of their data "
+                               f"registers (gfx950 store-data hazard, DESIGN.md section 3.6); library kept as {out}.rejected\n"
+                               + store_hazard.describe(found))
     return out
 
 

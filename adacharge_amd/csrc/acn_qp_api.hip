@@ -586,6 +586,20 @@ static float event_pair_ms(acnqp_handle* h, long long launch) {
 
 int64_t acnqp_launch_count(acnqp_handle* h) { return h ? (int64_t)h->launches : 0; }
 
+#ifdef ACNQP_DEBUG_WS
+// diagnostic builds only (tools/gpu_long_race.py): the most recently used kernel workspace, copied to the host
+extern "C" int64_t acnqp_debug_copy_workspace(acnqp_handle* h, double* out, int64_t n_doubles) {
+  if (!h || h->work.empty()) return -1;
+  size_t best = 0;
+  for (size_t k = 1; k < h->work.size(); ++k) if (h->work[k].used > h->work[best].used) best = k;
+  (void)hipDeviceSynchronize();
+  const int64_t have = (int64_t)(h->work[best].buf.cap / sizeof(double));
+  const int64_t n = std::min(have, n_doubles);
+  if (out && n > 0 && hipMemcpy(out, h->work[best].buf.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+  return have;
+}
+#endif
+
 float acnqp_last_kernel_ms(acnqp_handle* h) {
   if (!h || h->launches == 0) return -1.0f;
   return event_pair_ms(h, h->launches - 1);

@@ -104,11 +104,16 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   const auto& SA = *SAp;
   (void)SA_kernarg;
   const auto& A = SA.t;
-  // (the thread / block ids are NOT made opaque here, unlike in the other kernels: with them opaque this kernel's
-  //  workspace placement of r0 / zh returned run-to-run different iterates on the GPU -- tools/gpu_determinism.py,
-  //  DESIGN.md section 3.3 -- while this form is bit-stable and equals the LDS placement; the argument pointer alone
-  //  already keeps the arguments out of the solver loop's registers)
-  const int b = blockIdx.x, tid = threadIdx.x;
+  // Block id through v_readfirstlane (as in the other kernels): the workspace descriptor and every uniform offset then
+  // live in scalar registers -- 26 v_readfirstlane in the 54 x 144 instantiation instead of 1,976, 78 -> 63 ms.  That
+  // form exposed a hardware hazard the compiler does not cover (see st2 below), which is why round 2 shipped without it.
+#if !defined(ACNQP_LONG_IDS_OPAQUE) || ACNQP_LONG_IDS_OPAQUE
+  int b_ = blockIdx.x; int tid = threadIdx.x;
+  asm volatile("" : "+v"(b_)); asm volatile("" : "+v"(tid));
+  const int b = __builtin_amdgcn_readfirstlane(b_);
+#else
+  const int b = blockIdx.x, tid = threadIdx.x;   // diagnostic: descriptor in vector registers (round 2's form)
+#endif
   const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
   const int adapt_p = pass == 0 ? A.adapt_every : 0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,6 +222,16 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     if constexpr (std::is_same<B, WsArr64>::value) {
       const ws_d2 d = {a, b};
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_v4u, d), wsr, (unsigned)lane * 16u, base.off + uo * 8u, 0);
+      // gfx950 store-data hazard: a buffer store of more than 64 bits per lane reads its data registers over several
+      // cycles, and a VALU write to them in the next two issue slots changes what the last lanes (12..15 of each DPP
+      // row) store.  LLVM inserts the wait states for such stores EXCEPT when soffset is a register
+      // (GCNHazardRecognizer::createsVALUHazard) -- exactly this instruction, and on MI355X the exemption does not hold:
+      // the new r0 of column tile c was stored with the value of tile c + 1 in those lanes, differently from run to run
+      // (tools/gpu_long_race.py located it).  The asm keeps the data registers live across three
+      // wait states; tools/check_store_hazard.py scans the ISA of every kernel for the pattern at build time.
+#if !defined(ACNQP_LONG_STORE_NOP) || ACNQP_LONG_STORE_NOP
+      asm volatile("s_nop 2" ::"v"(d.x), "v"(d.y));
+#endif
     } else if constexpr (std::is_same<B, WsArr32>::value) {
       const ws_f2 d = {(float)a, (float)b};
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ws_v2u, d), wsr, (unsigned)lane * 8u, base.off + uo * 4u, 0);

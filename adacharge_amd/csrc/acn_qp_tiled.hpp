@@ -854,6 +854,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   // A-operand fragments kept in registers across the loop (MT == 1 only): level 1 = the two post-barrier products
   // (x~ = r0 + Ghat' e^, G x~ = Q h^), whose just-in-time loads sit on the iteration's critical path; level 2 = all four
   constexpr int kFragRes = MT == 1 ? ACNQP_FRAG_RESIDENT : 0;
+#ifndef ACNQP_FRAG_PREFETCH
+#define ACNQP_FRAG_PREFETCH 0
+#endif
+  constexpr bool kFragPre = MT == 1 && kFragRes == 0 && ACNQP_FRAG_PREFETCH != 0;
   real fXr[4], fQr[4], fPr[4], fQtr[4];
   if constexpr (kFragRes >= 1) {
     const real* FG0r = static_cast<const real*>(A.fragG) + (size_t)__builtin_amdgcn_readfirstlane(wave) * MT * 2 * 4 * 64;
@@ -905,6 +909,16 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         wh[mo][c] = acc;
       }
     }
+    // Experiment switch (-DACNQP_FRAG_PREFETCH=1, off): the A-operand fragments of the two products AFTER the barrier
+    // requested before it.  Left to itself the compiler issues each of these eight loads right in front of its MFMA
+    // (load, s_waitcnt vmcnt(0), MFMA, eight times in a row); hoisting them costs 16 registers over the barrier and
+    // the partial-tile sum, i.e. 10 more spilled registers, and buys 1 % (36.25 -> 35.90 ms): the other wave of the SIMD
+    // already covers those waits.
+    real fXp[4], fQp[4];
+    if constexpr (kFragPre) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { fXp[s] = FG[(1 * 4 + s) * 64 + lane]; fQp[s] = FQ[(1 * 4 + s) * 64 + lane]; }
+    }
     STAMP(0);   // r0, P_w, w^ (8 MFMA)
     __syncthreads();   // the one barrier of the iteration: all partial tiles are in LDS
     STAMP(1);   // barrier
@@ -937,7 +951,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = M::mma(kFragRes >= 1 ? fXr[s] : FG[((m * 2 + 1) * 4 + s) * 64 + lane], eh[m][c][s], acc);
+        for (int s = 0; s < 4; ++s) acc = M::mma(kFragRes >= 1 ? fXr[s] : (kFragPre ? fXp[s] : FG[((m * 2 + 1) * 4 + s) * 64 + lane]), eh[m][c][s], acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const real xn = acc[r] * inv_a;
@@ -955,7 +969,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) zt = M::mma(kFragRes >= 1 ? fQr[s] : FQ[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane], hh[mi][c][s], zt);
+          for (int s = 0; s < 4; ++s) zt = M::mma(kFragRes >= 1 ? fQr[s] : (kFragPre ? fQp[s] : FQ[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane]), hh[mi][c][s], zt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           gx[mo][c][r] = alpha * zt[r] + ((real)1 - alpha) * gx[mo][c][r];
