@@ -167,12 +167,12 @@ def other_workloads():
         batch = ProblemBatch.concatenate([scenario_batch(base, rng.lognormal(0.0, 0.05, size=256), problem=p) for p in range(8)])
         return batch, default_options(), True, "configs[4] shape: synthetic 512 EVSE x 48, load_flattening + energy equalities, 8 snapshots x 256 demand scenarios, default tolerances"
 
-    def stress144():
+    def stress144(B=256):
         infra = sites.caltech54()
         iface = Interface({"infrastructure_info": infra, "period": 5})
         obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
-        batch = build_batch(sites.snapshot_batch(infra, 144, 256, seed=144, demand_range=(5.0, 60.0)), infra, iface, obj, "SOC")
-        return batch, default_options(), True, "the reference's stress shape (t_aco.py:286-466): 54 EVSE x 144 periods, batch 256"
+        batch = build_batch(sites.snapshot_batch(infra, 144, B, seed=144, demand_range=(5.0, 60.0)), infra, iface, obj, "SOC")
+        return batch, default_options(), True, f"the reference's stress shape (t_aco.py:286-466): 54 EVSE x 144 periods, batch {B}"
 
     return {
         "cfg2_caltech54_T24_b4096": lambda: cfg2("caltech54"),
@@ -181,7 +181,13 @@ def other_workloads():
         "cfg3_site0_T12_b1024": lambda: cfg3_site(0),
         "cfg4_synth512_T48_b2048": cfg4,
         "stress_caltech54_T144_b256": stress144,
+        # not part of the default run (tools/run_config.py stress144-2k): eight workgroups per CU in flight
+        "stress_caltech54_T144_b2048": lambda: stress144(2048),
     }
+
+
+# legs of `other_workloads` the default `python bench.py` run leaves out (profiling targets only)
+NOT_IN_DEFAULT_RUN = ("stress_caltech54_T144_b2048",)
 
 
 def time_device_launch(batch, opts, dev, reps=2):
@@ -213,7 +219,7 @@ def other_configs_leg(dev, only=None):
 
     out = {}
     for name, build in other_workloads().items():
-        if only and name not in only:
+        if (only and name not in only) or (not only and name in NOT_IN_DEFAULT_RUN):
             continue
         t0 = time.perf_counter()
         batch, opts, streamed, note = build()

@@ -1,6 +1,6 @@
 """One device-resident launch of a BASELINE.json configuration other than the bench's (profiling target):
 
-    python3 tools/run_config.py cfg2-caltech|cfg2-jpl|cfg3-site0|cfg3-site3|cfg5|stress144|cfg4 [scenarios] [--ranks R]
+    python3 tools/run_config.py cfg2-caltech|cfg2-jpl|cfg3-site0|cfg3-site3|cfg5|stress144|stress144-2k|cfg4 [scenarios] [--ranks R]
 
 Everything but `cfg4` is one of bench.py's `other_configs` legs (bench.other_workloads: one definition for the driver's
 JSON line and for the profiles): cfg2 = horizon 24, batch 4096; cfg3-siteK = 1024 demand scenarios of one site of
@@ -94,7 +94,7 @@ def main():
         print(json.dumps(dict(config="cfg4", scenarios_per_site=S, problems=tot_n, kernel_ms_total=tot_ms, qps=tot_n / tot_ms * 1e3, sites=rows)))
         raise SystemExit(0)
     ALIASES = {"cfg2-caltech": "cfg2_caltech54_T24_b4096", "cfg2-jpl": "cfg2_jpl52_T24_b4096", "cfg5": "cfg4_synth512_T48_b2048",
-               "stress144": "stress_caltech54_T144_b256", "cfg3-site3": "cfg3_site3_T12_b1024", "cfg3-site0": "cfg3_site0_T12_b1024"}
+               "stress144": "stress_caltech54_T144_b256", "stress144-2k": "stress_caltech54_T144_b2048", "cfg3-site3": "cfg3_site3_T12_b1024", "cfg3-site0": "cfg3_site0_T12_b1024"}
     import bench   # the workloads are bench.py's `other_configs` legs (one definition for the driver's line and the profiles)
     name = ALIASES.get(which, which)
     if name not in bench.other_workloads():
