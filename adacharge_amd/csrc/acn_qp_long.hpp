@@ -221,16 +221,17 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     typedef decltype(base) B;
     if constexpr (std::is_same<B, WsArr64>::value) {
       const ws_d2 d = {a, b};
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_v4u, d), wsr, (unsigned)lane * 16u, base.off + uo * 8u, 0);
+      const ws_v4u q4 = __builtin_bit_cast(ws_v4u, d);
+      __builtin_amdgcn_raw_buffer_store_b128(q4, wsr, (unsigned)lane * 16u, base.off + uo * 8u, 0);
       // gfx950 store-data hazard: a buffer store of more than 64 bits per lane reads its data registers over several
       // cycles, and a VALU write to them in the next two issue slots changes what the last lanes (12..15 of each DPP
       // row) store.  LLVM inserts the wait states for such stores EXCEPT when soffset is a register
       // (GCNHazardRecognizer::createsVALUHazard) -- exactly this instruction, and on MI355X the exemption does not hold:
       // the new r0 of column tile c was stored with the value of tile c + 1 in those lanes, differently from run to run
-      // (tools/gpu_long_race.py located it).  The asm keeps the data registers live across three
-      // wait states; tools/check_store_hazard.py scans the ISA of every kernel for the pattern at build time.
+      // (tools/gpu_long_race.py located it).  The asm keeps the store's own register tuple live across
+      // three wait states; tools/check_store_hazard.py scans the ISA of every kernel for the pattern at build time.
 #if !defined(ACNQP_LONG_STORE_NOP) || ACNQP_LONG_STORE_NOP
-      asm volatile("s_nop 2" ::"v"(d.x), "v"(d.y));
+      asm volatile("s_nop 2" ::"v"(q4));   // the 128-bit tuple the store reads, not the doubles it was built from
 #endif
     } else if constexpr (std::is_same<B, WsArr32>::value) {
       const ws_f2 d = {(float)a, (float)b};

@@ -39,3 +39,10 @@ hipError_t launch_stream(const StreamArgs& sa, hipStream_t st) {
 }
 
 }  // namespace acnqp
+
+#ifdef ACNQP_STAMPS
+/* diagnostic build only: the large-site kernel's per-phase cycle counters (this unit's copy of g_stamps) */
+extern "C" int acnqp_debug_read_stamps_stream(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(acnqp::g_stamps), sizeof(unsigned long long) * n);
+}
+#endif

@@ -35,6 +35,11 @@
 
 namespace acnqp {
 
+typedef unsigned ws_v2u_s __attribute__((ext_vector_type(2)));
+typedef unsigned ws_v4u_s __attribute__((ext_vector_type(4)));
+typedef double ws_d2_s __attribute__((ext_vector_type(2)));
+typedef float ws_f2_s __attribute__((ext_vector_type(2)));
+
 // Waves per workgroup is a template parameter NWV: 4 (two workgroups = two problems share a CU and fill each other's
 // memory phases: best throughput on large batches) or 8 (one workgroup per CU: a single problem finishes sooner).
 // The summation order of every reduction is the same for both, so the choice never changes a result bit.
@@ -60,13 +65,18 @@ struct StreamLds {
   int red, g0h, we, scal, total;
   __host__ __device__ StreamLds(int MT, int CT, int NWV) {
     int o = 0;
-    red = o;  o += NWV * CT * 256;            // the round's staged tiles
-    g0h = o;  o += MT * CT * 256;             // Ghat z1 (start) / h^
+    red = o;  o += 2 * NWV * CT * 256;        // the rounds' staged tiles, double-buffered (one barrier per round)
+    g0h = red + NWV * CT * 256;               // Ghat z1 (start) / h^: ALIASES the second slab (MT <= NWV) -- h^ lives from
+                                              // the eigen step to the site-row update, the slabs only inside the tile passes
     we = o;   o += MT * CT * 256;             // e^: B operand of every tile's x~ product
     scal = o; o += NWV * 8 + 8;
     total = o;
   }
 };
+
+#ifndef ACNQP_STREAM_FRONT_FENCE
+#define ACNQP_STREAM_FRONT_FENCE 0
+#endif
 
 template <int NV, int NWV>
 __device__ inline void stream_block_max(double (&v)[NV], double* S, int lane, int wave) {
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   constexpr int AMX = kStreamAccelMax;
   __shared__ real AaRedS[NWV * (AMX + 2)];               // per-wave partial dot products of an Anderson event
   __shared__ real AaHS[NWV * (AMX * AMX + AMX)];         // every wave's own copy of the Gram matrix and rhs
-  real* RED = sm + L.red;
+  real* RED0 = sm + L.red;
   real* G0H = sm + L.g0h;
   real* WE = sm + L.we;
   real* SC = sm + L.scal;
@@ -174,7 +184,59 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
     for (int j = 0; j < 16 * MT; ++j) jdc = A.rowtype[j] == kRowMax ? j : jdc;
   const bool dc_on = jdc >= 0;
 
-  auto fidx = [&](int e, int c, int r) -> size_t { return ((size_t)(e * CT + c) * 4 + r) * 64 + lane; };
+  // Layout of the six state arrays (x, z1, y1, q, lb, ub): 16 x 16 tiles in MFMA fragment order with the four
+  // accumulator registers of a lane stored as two adjacent PAIRS (the long-horizon kernel's layout) -- element
+  // (tile, r, lane) at tile * 256 + (r / 2) * 128 + lane * 2 + r % 2 -- so that one 16-byte access per lane moves two
+  // registers: half the memory instructions and 1 KB contiguous per wave access instead of 512 B.  The Anderson arrays
+  // (zh of the event, u, f, g, the float rings) use the same layout; the site-row state keeps the plain order [tile][r][lane].
+  auto fidx = [&](int e, int c, int r) -> size_t { return (size_t)(e * CT + c) * 256 + (size_t)((r >> 1) * 128 + lane * 2 + (r & 1)); };
+  // The hot passes (tile_front / tile_back, the Anderson event's passes) address the workspace through ONE buffer
+  // descriptor in scalar registers: element (array, uniform index u)[lane] = descriptor + (array offset + u) * 8 as the
+  // scalar offset + lane * 8 as the one 32-bit lane offset every access shares.  With plain pointers the compiler kept
+  // a 64-bit per-lane address for every (array, column tile) -- 24 registers in the fused pass, recomputed per tile --
+  // and spilled around them (416 bytes of scratch traffic per lane and tile against 864 useful, round 3).  The cold
+  // paths (start, restart, residual check, certificate, output) keep the pointers; both name the same memory.
+  const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(W0, 0, (int)(SA.ws_per_problem * 8), 0x00020000);
+  constexpr int kNt = 2;   // gfx940+ cache policy bit 1 = nt: what __builtin_nontemporal_load / _store emit
+  const unsigned oX = 0, oZ1 = (unsigned)NT, oY1 = 2 * (unsigned)NT, oQ = 3 * (unsigned)NT, oLB = 4 * (unsigned)NT, oUB = 5 * (unsigned)NT;
+  auto fidp = [&](int e, int c, int rp) -> unsigned { return (unsigned)((e * CT + c) * 256 + rp * 128); };   // registers 2 rp, 2 rp + 1
+  auto ld2_nt = [&](unsigned arr, unsigned u, real& a, real& b) __attribute__((always_inline)) {
+    const ws_d2_s d = __builtin_bit_cast(ws_d2_s, __builtin_amdgcn_raw_buffer_load_b128(wsr, (unsigned)lane * 16u, (arr + u) * 8u, kNt));
+    a = d.x; b = d.y;
+  };
+  auto st2_nt = [&](unsigned arr, unsigned u, real a, real b) __attribute__((always_inline)) {
+    const ws_d2_s d = {a, b};
+    const ws_v4u_s q = __builtin_bit_cast(ws_v4u_s, d);
+    __builtin_amdgcn_raw_buffer_store_b128(q, wsr, (unsigned)lane * 16u, (arr + u) * 8u, kNt);
+    // gfx950 store-data hazard (acn_qp_long.hpp st2): three wait states with the very register
+    // tuple the store reads kept live (the asm takes the 128-bit operand itself, not the doubles it was built from)
+    asm volatile("s_nop 2" ::"v"(q));
+  };
+  // the Anderson arrays (pre-projection points of the event, u, f, g: doubles; the dF / dG rings: floats) take the same
+  // pair layout over DU = NT + MS elements (EVSE tiles, then the site tiles): tile index `tix`, pair rp at tix * 256 + rp * 128
+  const unsigned oZH = (unsigned)off_aa, oUP = oZH + (unsigned)DU, oFP = oUP + (unsigned)DU, oGP = oFP + (unsigned)DU;
+  const unsigned bHF = (oGP + (unsigned)DU) * 8u, bHG = bHF + (unsigned)aa_m * (unsigned)DU * 4u;   // byte offsets
+  auto ld2 = [&](unsigned arr, unsigned u, real& a, real& b) __attribute__((always_inline)) {
+    const ws_d2_s d = __builtin_bit_cast(ws_d2_s, __builtin_amdgcn_raw_buffer_load_b128(wsr, (unsigned)lane * 16u, (arr + u) * 8u, 0));
+    a = d.x; b = d.y;
+  };
+  auto st2 = [&](unsigned arr, unsigned u, real a, real b) __attribute__((always_inline)) {
+    const ws_d2_s d = {a, b};
+    const ws_v4u_s q = __builtin_bit_cast(ws_v4u_s, d);
+    __builtin_amdgcn_raw_buffer_store_b128(q, wsr, (unsigned)lane * 16u, (arr + u) * 8u, 0);
+    asm volatile("s_nop 2" ::"v"(q));   // store-data hazard, as in st2_nt
+  };
+  auto ld2f = [&](unsigned boff, unsigned u, float& a, float& b) __attribute__((always_inline)) {
+    const ws_f2_s d = __builtin_bit_cast(ws_f2_s, __builtin_amdgcn_raw_buffer_load_b64(wsr, (unsigned)lane * 8u, boff + u * 4u, 0));
+    a = d.x; b = d.y;
+  };
+  auto st2f = [&](unsigned boff, unsigned u, float a, float b) __attribute__((always_inline)) {
+    const ws_f2_s d = {a, b};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ws_v2u_s, d), wsr, (unsigned)lane * 8u, boff + u * 4u, 0);
+  };
+  // element (tix, r)[lane] of an Anderson array through its pointer (cold paths)
+  auto apair = [&](unsigned tix, int r) -> size_t { return (size_t)tix * 256 + (size_t)((r >> 1) * 128 + lane * 2 + (r & 1)); };
+  const unsigned kSiteTix = (unsigned)(NE * CT);   // tile index of site tile 0 in the Anderson arrays (NT / 256)
 
   // ---- init: inputs -> fragment order; |q|_inf, max ub; a session whose bounds cannot meet its energy row ----------
   real qn = 0, um = 0, bad = 0;
@@ -252,18 +314,33 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   // ---- projection of ONE register row (one EVSE per 16-lane DPP row: EVSE 16 e + rowof(g, r), its periods = the 16
   // lanes times the CT column registers) onto B = box + energy rows.  Same safeguarded Newton as the general-shape
   // kernel / the C port.  One row at a time keeps only 3 * CT values live instead of 3 * 4 * CT. -----------------
+  // `first`: the row's session slot 0 (window, capacity, last multiplier) fetched by the caller -- tile_back requests
+  // the four rows' entries together with their bounds instead of one dependent L2 round trip per row
+  struct Slot0 { int off, len; real cap, mu; bool have; };
+  auto slot0_of = [&](int e, int r) __attribute__((always_inline)) -> Slot0 {
+    const int ev = 16 * e + M::rowof(g, r);
+    const size_t sidx = (size_t)b * K * N + (ev < N ? ev : 0);
+    Slot0 s0;
+    s0.off = ev < N ? A.s_off[sidx] : 0;
+    s0.len = ev < N ? A.s_len[sidx] : 0;
+    s0.cap = ev < N ? A.s_cap[sidx] : 0.0;
+    s0.mu = ev < N ? MU[ev] : 0.0;
+    s0.have = true;
+    return s0;
+  };
   auto project_row = [&](int e, int r, const real (&zh)[CT], const real (&lbv)[CT], const real (&ubv)[CT],
-                         real (&z1)[CT], bool reset_mu) __attribute__((always_inline)) {
+                         real (&z1)[CT], bool reset_mu, const Slot0 first) __attribute__((always_inline)) {
     const int ev = 16 * e + M::rowof(g, r);
 #pragma unroll
     for (int c = 0; c < CT; ++c) z1[c] = fmin(fmax(zh[c], lbv[c]), ubv[c]);
 #pragma unroll 1
     for (int k = 0; k < K; ++k) {
       const size_t sidx = ((size_t)b * K + k) * N + (ev < N ? ev : 0);
-      const int off = ev < N ? A.s_off[sidx] : 0;
-      int len = ev < N ? A.s_len[sidx] : 0;
+      const bool pre = first.have && k == 0;   // uniform
+      const int off = pre ? first.off : (ev < N ? A.s_off[sidx] : 0);
+      int len = pre ? first.len : (ev < N ? A.s_len[sidx] : 0);
       if (off + len > Tm) len = Tm - off;
-      const real cap = ev < N ? A.s_cap[sidx] : 0.0;
+      const real cap = pre ? first.cap : (ev < N ? A.s_cap[sidx] : 0.0);
       real s0 = 0, sl = 0, su = 0, lo_l = M::big, hi_l = -M::big;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
@@ -282,7 +359,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       const int mode = !act ? 4 : ((eq && cap >= su) ? 2 : (cap <= sl ? 3 : 0));   // 0 root-find, 2 at ub, 3 at lb, 4 nothing
       bool need = mode == 0;
       if (!eq && lo < 0) lo = 0;
-      const real mu0 = (reset_mu || ev >= N) ? 0.0 : MU[(size_t)k * NP + ev];
+      const real mu0 = (reset_mu || ev >= N) ? 0.0 : (pre ? first.mu : MU[(size_t)k * NP + ev]);
       real m = fmin(fmax(mu0, lo), hi);
 #pragma unroll 1
       for (int guard = 0; guard <= 100; ++guard) {
@@ -324,8 +401,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   };
   // One round of P: this wave's tile vector v (C layout = MFMA B operand; `have` = the wave has a tile this round)
   // goes into the slab; after the barrier the owner of each output tile (m, c) adds Ghat[m, e] v_e[c] for the tiles
-  // e of the round, in tile order.  Two barriers per round; RED is the slab.
+  // e of the round, in tile order.  ONE barrier per round: the slabs alternate, and the slab of round rd is written
+  // again in round rd + 2, after the barrier of round rd + 1, which an owner passes only with its reads of round rd
+  // done.  p_finish() (one more barrier) closes a pass before anything else touches the slabs (h^ aliases the second).
   auto p_round = [&](int rd, bool have, const real (&v)[4][CT]) __attribute__((always_inline)) {
+    real* RED = RED0 + (size_t)(rd & 1) * (kStreamWaves * CT * 256);
     if (have) {
 #pragma unroll
       for (int c = 0; c < CT; ++c)
@@ -351,8 +431,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
             for (int s = 0; s < 4; ++s) pown[c] = M::mma(af[w][s], RED[((w * CT + c) * 4 + s) * 64 + lane], pown[c]);
         }
     }
-    __syncthreads();
   };
+  auto p_finish = [&]() __attribute__((always_inline)) { __syncthreads(); };
   // r0 of every tile from the stored state -> P (start, and after a rho change)
   auto rebuild_p = [&]() __attribute__((always_inline)) {
     zero_pown();
@@ -373,6 +453,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       }
       p_round(rd, have, r0);
     }
+    p_finish();
   };
 
   // ---- start (see acn_qp_tiled.hpp): z1 = Proj_B(-kStartGain q), x = z1, y1 = -(q + pd z1); z2 = G z1 = Q (Ghat z1);
@@ -400,7 +481,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
             zs[c] = ok ? A.warm_x[((size_t)b * N + (ok ? ev : 0)) * Tm + (ok ? tt : 0)] : 0.0;
           }
         }
-        project_row(e, r, zs, lbv, ubv, z1[r], true);
+        project_row(e, r, zs, lbv, ubv, z1[r], true, Slot0{0, 0, 0.0, 0.0, false});
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
           const size_t i = fidx(e, c, r);
@@ -410,6 +491,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
     }
     p_round(rd, have, z1);
   }
+  p_finish();
   // Ghat z1 sits with the owners: hand it to the site-row update below through G0H
   if (wave < MT) {
 #pragma unroll
@@ -479,13 +561,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const size_t i = fidx(e, c, r); UP[i] = Z1s[i] + Y1s[i] * ir; }
+        for (int r = 0; r < 4; ++r) { const size_t i = fidx(e, c, r); UP[i] = Z1s[i] + Y1s[i] * ir; }   // same layout
     }
 #pragma unroll 1
     for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
       RELANE();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int i = (tl * 4 + r) * 64 + lane; UP[NT + i] = Z2[i] + Y2[i] * ir; }
+      for (int r = 0; r < 4; ++r) { const int i = (tl * 4 + r) * 64 + lane; UP[apair(kSiteTix + tl, r)] = Z2[i] + Y2[i] * ir; }
     }
   };
   reset_u();
@@ -598,11 +680,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       real xv[4], z1o[4], y1o[4], qv[4];
       vec4 acc;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const size_t i = fidx(e, c, r);
-        xv[r] = __builtin_nontemporal_load(&Xs[i]); z1o[r] = __builtin_nontemporal_load(&Z1s[i]); y1o[r] = __builtin_nontemporal_load(&Y1s[i]); qv[r] = __builtin_nontemporal_load(&Qs[i]);
-        acc[r] = sigma * xv[r] - qv[r] + rho * z1o[r] - y1o[r];
+      for (int rp = 0; rp < 2; ++rp) {
+        const unsigned i = fidp(e, c, rp);
+        ld2_nt(oX, i, xv[2 * rp], xv[2 * rp + 1]); ld2_nt(oZ1, i, z1o[2 * rp], z1o[2 * rp + 1]);
+        ld2_nt(oY1, i, y1o[2 * rp], y1o[2 * rp + 1]); ld2_nt(oQ, i, qv[2 * rp], qv[2 * rp + 1]);
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = sigma * xv[r] - qv[r] + rho * z1o[r] - y1o[r];
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -612,26 +696,44 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       for (int r = 0; r < 4; ++r) {
         const real xn = acc[r] * inv_a;
         zh[r][c] = alpha * xn + (1.0 - alpha) * z1o[r] + y1o[r] * inv_rho;
-        const real xnew = alpha * xn + (1.0 - alpha) * xv[r];
-        __builtin_nontemporal_store(xnew, &Xs[fidx(e, c, r)]);
-        sq[r][c] = sigma * xnew - qv[r];
+        xv[r] = alpha * xn + (1.0 - alpha) * xv[r];   // x_new
+        sq[r][c] = sigma * xv[r] - qv[r];
       }
+      st2_nt(oX, fidp(e, c, 0), xv[0], xv[1]);
+      st2_nt(oX, fidp(e, c, 1), xv[2], xv[3]);
+#if ACNQP_STREAM_FRONT_FENCE
+      __builtin_amdgcn_sched_barrier(0);   // one column tile's 16 loads in flight at a time (see the note at the top)
+#endif
     }
   };
   // back: box + energy-row projection of zh one register row at a time, z1 and y1 stored, the tile's NEW r0 left in zh
   auto tile_back = [&](int e, real (&zh)[4][CT], const real (&sq)[4][CT]) __attribute__((always_inline)) {
+    // the bounds and session slots of all four register rows are requested at once: one memory round trip per tile
+    // instead of four + four.  (Requesting them BEFORE tile_front, under its loads and MFMA chain, was measured too:
+    // 468 -> 507 ms on the configs[4] leg -- the 64 registers they pin spill the front.)
+    real lb4[4][CT], ub4[4][CT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      real lbv[CT], ubv[CT], z1[CT];
-#pragma unroll
-      for (int c = 0; c < CT; ++c) { const size_t i = fidx(e, c, r); lbv[c] = __builtin_nontemporal_load(&LBs[i]); ubv[c] = __builtin_nontemporal_load(&UBs[i]); }
-      project_row(e, r, zh[r], lbv, ubv, z1, false);
+    for (int rp = 0; rp < 2; ++rp)
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        const size_t i = fidx(e, c, r);
-        const real y1n = rho * (zh[r][c] - z1[c]);
-        __builtin_nontemporal_store(z1[c], &Z1s[i]); __builtin_nontemporal_store(y1n, &Y1s[i]);
-        zh[r][c] = sq[r][c] + rho * z1[c] - y1n;   // the new r0, in zh's registers
+        const unsigned i = fidp(e, c, rp);
+        ld2_nt(oLB, i, lb4[2 * rp][c], lb4[2 * rp + 1][c]); ld2_nt(oUB, i, ub4[2 * rp][c], ub4[2 * rp + 1][c]);
+      }
+    Slot0 s4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s4[r] = slot0_of(e, r);
+#pragma unroll
+    for (int rp = 0; rp < 2; ++rp) {   // the two rows of a register pair, then their 16-byte stores
+      real z1a[CT], z1b[CT];
+      project_row(e, 2 * rp, zh[2 * rp], lb4[2 * rp], ub4[2 * rp], z1a, false, s4[2 * rp]);
+      project_row(e, 2 * rp + 1, zh[2 * rp + 1], lb4[2 * rp + 1], ub4[2 * rp + 1], z1b, false, s4[2 * rp + 1]);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const unsigned i = fidp(e, c, rp);
+        const real ya = rho * (zh[2 * rp][c] - z1a[c]), yb = rho * (zh[2 * rp + 1][c] - z1b[c]);
+        st2_nt(oZ1, i, z1a[c], z1b[c]); st2_nt(oY1, i, ya, yb);
+        zh[2 * rp][c] = sq[2 * rp][c] + rho * z1a[c] - ya;   // the new r0, in zh's registers
+        zh[2 * rp + 1][c] = sq[2 * rp + 1][c] + rho * z1b[c] - yb;
       }
     }
   };
@@ -658,6 +760,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       }
     }
   };
+#ifdef ACNQP_STAMPS
+  unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_prev)::"memory");
+#endif
 #pragma unroll 1
   while (!done) {
     ++it;
@@ -675,27 +781,44 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
     sv0 = 0; sv2 = 0;
     // ---- eigen space, by the wave that owns each 16 x 16 site tile (its accumulator holds Ghat r0 for that tile):
     // e^ -> WE, h^ -> G0H ---------------------------------------------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < NOWN; ++k) {
-      if (wave >= MT) continue;
+    // (every operand of a product is requested before its MFMA chain starts: left alone the compiler emits load,
+    //  s_waitcnt vmcnt(0), MFMA thirty-six times in a row, each an L2 round trip under the load of the streaming waves)
+    if (wave < MT) {
       RELANE();
-      const int mo = wave, c = k;
-      vec4 wh = {0, 0, 0, 0};
+      const int mo = wave;
+      real fq[MT][4];   // Q' fragments of this row tile: the same for every column tile
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int i = ((mi * CT + c) * 4 + s) * 64 + lane;
-          wh = M::mma(FQi[(((mo * MT + mi) * 2 + 0) * 4 + s) * 64 + lane], rho * Z2[i] - Y2[i], wh);
-        }
+        for (int s = 0; s < 4; ++s) fq[mi][s] = FQi[(((mo * MT + mi) * 2 + 0) * 4 + s) * 64 + lane];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
-        const real lj = Lmi[16 * mo + M::rowof(g, r)];
-        const real g0 = pown[k][r];
-        const real e_ = wh[r] - (rho / (a + rho * lj)) * (g0 + lj * wh[r]);
-        WE[i] = e_;
-        G0H[i] = (g0 + lj * e_) * inv_a;
+      for (int k = 0; k < NOWN; ++k) {
+        const int c = k;
+        real z2v[MT][4], y2v[MT][4], ljv[4];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const int i = ((mi * CT + c) * 4 + s) * 64 + lane;
+            z2v[mi][s] = Z2[i]; y2v[mi][s] = Y2[i];
+          }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ljv[r] = Lmi[16 * mo + M::rowof(g, r)];
+        __builtin_amdgcn_sched_barrier(0);
+        vec4 wh = {0, 0, 0, 0};
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) wh = M::mma(fq[mi][s], rho * z2v[mi][s] - y2v[mi][s], wh);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
+          const real lj = ljv[r];
+          const real g0 = pown[k][r];
+          const real e_ = wh[r] - (rho / (a + rho * lj)) * (g0 + lj * wh[r]);
+          WE[i] = e_;
+          G0H[i] = (g0 + lj * e_) * inv_a;
+        }
       }
     }
     __syncthreads();
@@ -704,28 +827,41 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
     for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
       RELANE();
       const int mo = tl / CT, c = tl - mo * CT;
+      real fq[MT][4], hv[MT][4], gxo[4], z2o[4], y2o[4];
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          fq[mi][s] = FQi[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane];
+          hv[mi][s] = G0H[((mi * CT + c) * 4 + s) * 64 + lane];
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
+        gxo[r] = GX[i]; z2o[r] = Z2[i]; y2o[r] = Y2[i];
+      }
+      __builtin_amdgcn_sched_barrier(0);
       vec4 zt = {0, 0, 0, 0};
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          zt = M::mma(FQi[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane], G0H[((mi * CT + c) * 4 + s) * 64 + lane], zt);
+        for (int s = 0; s < 4; ++s) zt = M::mma(fq[mi][s], hv[mi][s], zt);
       real zhr[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = ((mo * CT + c) * 4 + r) * 64 + lane;
-        GX[i] = alpha * zt[r] + (1.0 - alpha) * GX[i];
-        zhr[r] = alpha * zt[r] + (1.0 - alpha) * Z2[i] + Y2[i] * inv_rho;
+        GX[i] = alpha * zt[r] + (1.0 - alpha) * gxo[r];
+        zhr[r] = alpha * zt[r] + (1.0 - alpha) * z2o[r] + y2o[r] * inv_rho;
       }
       if (ev_it) {
-        ACNQP_STREAM_AA_PTRS();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ZHs[NT + ((mo * CT + c) * 4 + r) * 64 + lane] = zhr[r];
+        st2(oZH, (kSiteTix + tl) * 256u, zhr[0], zhr[1]);
+        st2(oZH, (kSiteTix + tl) * 256u + 128u, zhr[2], zhr[3]);
       } else {
         site_project(mo, c, zhr, RLi, RTi);
       }
     }
     __syncthreads();
+    STAMP(0);   // eigen step + site rows + their two barriers
     v0 = 0; v1 = 0; v2 = 0; v4 = 0; v5 = 0;
     if (!ev_it) {
       if (dc_on && wave == kStreamWaves - 1) { RELANE(); dc_row(); }
@@ -739,40 +875,65 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
         real zh[4][CT], sq[4][CT];
         if (have) {
           tile_front(e, inv_a, inv_rho, zh, sq);
+          STAMP(1);   // fused pass: front (loads, MFMA, x store)
           tile_back(e, zh, sq);
+          STAMP(2);   // fused pass: back (bounds, water-filling, z1 / y1 stores)
           if (check) tile_residuals(e);
+          STAMP(3);   // residual terms (check iterations)
         }
         p_round(rd, have, zh);   // the tile's new r0 joins next iteration's P
+        STAMP(4);   // round: slab, barrier, owners' MFMA
       }
+      p_finish();
+      STAMP(5);   // closing barrier
     } else {
       // ================= Anderson event (type II; acn_qp_tiled.hpp / oracle/admm_port.c) ============================
       // u = (zh, zhr) is the state of the fixed-point map.  Pass A: every tile's zh -> ZHs, the new column pair
       // (dF, dG) -> ring slot, the dot products dF_new . dF_j, dF_new . f, f . f.
-      ACNQP_STREAM_AA_PTRS();
       const bool col = aa_have_prev;
       const int slot = aa_head;
       real d[AMX + 2];
 #pragma unroll
       for (int j = 0; j < AMX + 2; ++j) d[j] = 0;
       // the four registers of one tile column: g = gv[r], state index uo + 64 r
-      auto aa_tile = [&](const real (&gv)[4], size_t uo) __attribute__((always_inline)) {
-        real hv[AMX][4];
+      auto aa_tile = [&](const real (&gv)[4], unsigned tix) __attribute__((always_inline)) {
+        real uv[4], fpv[4], gpv[4];
+        float hv[AMX][4];
 #pragma unroll
-        for (int j = 0; j < AMX; ++j)
+        for (int rp = 0; rp < 2; ++rp) {
+          const unsigned u = tix * 256u + (unsigned)rp * 128u;
+          ld2(oUP, u, uv[2 * rp], uv[2 * rp + 1]); ld2(oFP, u, fpv[2 * rp], fpv[2 * rp + 1]); ld2(oGP, u, gpv[2 * rp], gpv[2 * rp + 1]);
+        }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hv[j][r] = (((aa_valid >> j) & 1u) && j != slot) ? (real)HF[(size_t)j * DU + uo + 64 * r] : 0.0;
+        for (int j = 0; j < AMX; ++j) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hv[j][r] = 0.f;
+          if (((aa_valid >> j) & 1u) && j != slot) {   // uniform
+            ld2f(bHF + (unsigned)j * (unsigned)DU * 4u, tix * 256u, hv[j][0], hv[j][1]);
+            ld2f(bHF + (unsigned)j * (unsigned)DU * 4u, tix * 256u + 128u, hv[j][2], hv[j][3]);
+          }
+        }
+        float cqv[4], cgv[4];
+        real fv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const size_t i = uo + 64 * r;
-          const real f = gv[r] - UP[i];
+          const real f = gv[r] - uv[r];
           d[AMX + 1] += f * f;
-          const float cq = (float)(f - FP[i]);
-          const float cg = (float)(gv[r] - GP[i]);
+          const float cq = (float)(f - fpv[r]);
+          const float cg = (float)(gv[r] - gpv[r]);
 #pragma unroll
-          for (int j = 0; j < AMX; ++j) d[j] += (real)cq * (j == slot ? (real)cq : hv[j][r]);
+          for (int j = 0; j < AMX; ++j) d[j] += (real)cq * (j == slot ? (real)cq : (real)hv[j][r]);
           d[AMX] += (real)cq * f;
-          if (col) { HF[(size_t)slot * DU + i] = cq; HG[(size_t)slot * DU + i] = cg; }
-          FP[i] = f; GP[i] = gv[r];
+          cqv[r] = cq; cgv[r] = cg; fv[r] = f;
+        }
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+          const unsigned u = tix * 256u + (unsigned)rp * 128u;
+          if (col) {
+            st2f(bHF + (unsigned)slot * (unsigned)DU * 4u, u, cqv[2 * rp], cqv[2 * rp + 1]);
+            st2f(bHG + (unsigned)slot * (unsigned)DU * 4u, u, cgv[2 * rp], cgv[2 * rp + 1]);
+          }
+          st2(oFP, u, fv[2 * rp], fv[2 * rp + 1]); st2(oGP, u, gv[2 * rp], gv[2 * rp + 1]);
         }
       };
 #pragma unroll 1
@@ -786,8 +947,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
           for (int c = 0; c < CT; ++c) {
             real gv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { gv[r] = zh[r][c]; ZHs[fidx(e, c, r)] = zh[r][c]; }
-            aa_tile(gv, fidx(e, c, 0));
+            for (int r = 0; r < 4; ++r) gv[r] = zh[r][c];
+            st2(oZH, (unsigned)(e * CT + c) * 256u, gv[0], gv[1]);
+            st2(oZH, (unsigned)(e * CT + c) * 256u + 128u, gv[2], gv[3]);
+            aa_tile(gv, (unsigned)(e * CT + c));
           }
         }
       }
@@ -795,9 +958,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       for (int tl = wave; tl < MT * CT; tl += kStreamWaves) {
         RELANE();
         real gv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) gv[r] = ZHs[NT + (tl * 4 + r) * 64 + lane];
-        aa_tile(gv, (size_t)NT + (size_t)tl * 256 + lane);
+        ld2(oZH, (kSiteTix + tl) * 256u, gv[0], gv[1]);
+        ld2(oZH, (kSiteTix + tl) * 256u + 128u, gv[2], gv[3]);
+        aa_tile(gv, kSiteTix + (unsigned)tl);
       }
 #pragma unroll
       for (int j = 0; j < AMX + 2; ++j) d[j] = wave_sum<real>(d[j]);
@@ -874,17 +1037,27 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
         aa_was = true;
       }
       // u = g - sum_j gamma_j dG_j for the four registers at uo; stored as the new u
-      auto aa_apply = [&](real (&out)[4], size_t uo) __attribute__((always_inline)) {
+      auto aa_apply = [&](real (&out)[4], unsigned tix) __attribute__((always_inline)) {
         if (ext) {
+          float hg[AMX][4];
+#pragma unroll
+          for (int j = 0; j < AMX; ++j) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hg[j][r] = 0.f;
+            if ((aa_valid >> j) & 1u) {   // uniform
+              ld2f(bHG + (unsigned)j * (unsigned)DU * 4u, tix * 256u, hg[j][0], hg[j][1]);
+              ld2f(bHG + (unsigned)j * (unsigned)DU * 4u, tix * 256u + 128u, hg[j][2], hg[j][3]);
+            }
+          }
 #pragma unroll
           for (int j = 0; j < AMX; ++j) {
             if (!((aa_valid >> j) & 1u)) continue;   // uniform
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[r] -= gam[j] * (real)HG[(size_t)j * DU + uo + 64 * r];
+            for (int r = 0; r < 4; ++r) out[r] -= gam[j] * (real)hg[j][r];
           }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) UP[uo + 64 * r] = out[r];
+        st2(oUP, tix * 256u, out[0], out[1]);
+        st2(oUP, tix * 256u + 128u, out[2], out[3]);
       };
       // ---- the site rows are projected from their (extrapolated) point ------------------------------------------
 #pragma unroll 1
@@ -892,9 +1065,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
         RELANE();
         const int mo = tl / CT, c = tl - mo * CT;
         real zhr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) zhr[r] = ZHs[NT + (tl * 4 + r) * 64 + lane];
-        aa_apply(zhr, (size_t)NT + (size_t)tl * 256 + lane);
+        ld2(oZH, (kSiteTix + tl) * 256u, zhr[0], zhr[1]);
+        ld2(oZH, (kSiteTix + tl) * 256u + 128u, zhr[2], zhr[3]);
+        aa_apply(zhr, kSiteTix + (unsigned)tl);
         site_project(mo, c, zhr, RLi, RTi);
       }
       __syncthreads();
@@ -910,15 +1083,16 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
         if (have) {
 #pragma unroll
           for (int c = 0; c < CT; ++c) {
-            real o4[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o4[r] = ZHs[fidx(e, c, r)];
-            aa_apply(o4, fidx(e, c, 0));
+            real o4[4], xq[4], qq[4];
+            const unsigned tix = (unsigned)(e * CT + c);
+            ld2(oZH, tix * 256u, o4[0], o4[1]); ld2(oZH, tix * 256u + 128u, o4[2], o4[3]);
+            ld2_nt(oX, fidp(e, c, 0), xq[0], xq[1]); ld2_nt(oX, fidp(e, c, 1), xq[2], xq[3]);   // x_new was stored by pass A
+            ld2_nt(oQ, fidp(e, c, 0), qq[0], qq[1]); ld2_nt(oQ, fidp(e, c, 1), qq[2], qq[3]);
+            aa_apply(o4, tix);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const size_t i = fidx(e, c, r);
               zh[r][c] = o4[r];
-              sq[r][c] = sigma * Xs[i] - Qs[i];   // x_new was stored by pass A
+              sq[r][c] = sigma * xq[r] - qq[r];
             }
           }
           tile_back(e, zh, sq);
@@ -926,6 +1100,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
         }
         p_round(rd, have, zh);
       }
+      p_finish();
+      STAMP(6);   // Anderson event iteration (both passes)
     }
     if (check) {
       unsigned soff_ = 0;
@@ -1062,10 +1238,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
           const real tot = wave_sum<real>(ssum);
           real bd[1] = {badv};
           stream_block_max<1, NWV>(bd, SC, lane, wave);
-          if (lane == 0) RED[wave] = tot;   // the rounds' slab is free between iterations
+          if (lane == 0) RED0[wave] = tot;   // the rounds' slab is free between iterations
           __syncthreads();
           real stot = 0;
-          for (int wv = 0; wv < kStreamWaves; ++wv) stot += RED[wv];
+          for (int wv = 0; wv < kStreamWaves; ++wv) stot += RED0[wv];
           __syncthreads();
           if (bd[0] == 0.0 && stot < -vtol) { status = 3; done = true; }
         }
@@ -1158,6 +1334,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   }
   }
   if (tid == 0) A.iters[b] = it_total;
+#ifdef ACNQP_STAMPS
+  STAMP(7);   // residual check, certificate, penalty update, output
+  if (lane == 0 && b < 1024 && wave < 16)
+    for (int k = 0; k < 12; ++k) g_stamps[(b * 16 + wave) * 12 + k] = st_acc[k];
+#endif
   if (!retry_wanted(pass, A.retry_passes, status, it, A.stall_iters, A.adapt_every)) break;
   __syncthreads();
   }   // passes
