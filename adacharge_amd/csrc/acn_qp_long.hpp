@@ -752,11 +752,15 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       auto aa_tile = [&](auto zsrc, unsigned zo, unsigned uo) __attribute__((always_inline)) {
         real gv[4], uv[4], fpv[4], gpv[4], hv[AMX][4], cqv[4], cgv[4], fv[4];
         ld4(zsrc, zo, gv); ld4(UP, uo, uv); ld4(FP, uo, fpv); ld4(GP, uo, gpv);
+        // every ring column is requested, live or not (a branch per column puts each load in a basic block of its own:
+        // five dependent memory round trips per tile instead of one); a dead column's data is replaced by zeros
+#pragma unroll
+        for (int j = 0; j < AMX; ++j) ld4(HF + (size_t)(j < aa_m ? j : aa_m - 1) * DU, uo, hv[j]);
 #pragma unroll
         for (int j = 0; j < AMX; ++j) {
+          const bool live = ((aa_valid >> j) & 1u) && j != slot;   // uniform
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hv[j][r] = 0;
-          if (((aa_valid >> j) & 1u) && j != slot) ld4(HF + (size_t)j * DU, uo, hv[j]);   // uniform
+          for (int r = 0; r < 4; ++r) hv[j][r] = live ? hv[j][r] : 0.0;
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -863,15 +867,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         ld4(zdst, zo, out);
         if (ext) {
 #pragma unroll
+          for (int j = 0; j < AMX; ++j) ld4(HG + (size_t)(j < aa_m ? j : aa_m - 1) * DU, uo, hv[j]);   // one batch, as in aa_tile
+#pragma unroll
           for (int j = 0; j < AMX; ++j) {
+            const bool live = (aa_valid >> j) & 1u;   // uniform
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hv[j][r] = 0;
-            if ((aa_valid >> j) & 1u) ld4(HG + (size_t)j * DU, uo, hv[j]);   // uniform
+            for (int r = 0; r < 4; ++r) out[r] -= gam[j] * (live ? hv[j][r] : 0.0);
           }
-#pragma unroll
-          for (int j = 0; j < AMX; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) out[r] -= gam[j] * hv[j][r];
         }
         st4(UP, uo, out);
       };

@@ -904,14 +904,19 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
           const unsigned u = tix * 256u + (unsigned)rp * 128u;
           ld2(oUP, u, uv[2 * rp], uv[2 * rp + 1]); ld2(oFP, u, fpv[2 * rp], fpv[2 * rp + 1]); ld2(oGP, u, gpv[2 * rp], gpv[2 * rp + 1]);
         }
+        // every ring column is requested, live or not (a branch per column would put each load in a basic block of its
+        // own: five dependent memory round trips per tile instead of one); a dead column's data is replaced by zeros
 #pragma unroll
         for (int j = 0; j < AMX; ++j) {
+          const unsigned jj = (unsigned)(j < aa_m ? j : aa_m - 1);
+          ld2f(bHF + jj * (unsigned)DU * 4u, tix * 256u, hv[j][0], hv[j][1]);
+          ld2f(bHF + jj * (unsigned)DU * 4u, tix * 256u + 128u, hv[j][2], hv[j][3]);
+        }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hv[j][r] = 0.f;
-          if (((aa_valid >> j) & 1u) && j != slot) {   // uniform
-            ld2f(bHF + (unsigned)j * (unsigned)DU * 4u, tix * 256u, hv[j][0], hv[j][1]);
-            ld2f(bHF + (unsigned)j * (unsigned)DU * 4u, tix * 256u + 128u, hv[j][2], hv[j][3]);
-          }
+        for (int j = 0; j < AMX; ++j) {
+          const bool live = ((aa_valid >> j) & 1u) && j != slot;   // uniform
+#pragma unroll
+          for (int r = 0; r < 4; ++r) hv[j][r] = live ? hv[j][r] : 0.f;
         }
         float cqv[4], cgv[4];
         real fv[4];
@@ -1041,19 +1046,16 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
         if (ext) {
           float hg[AMX][4];
 #pragma unroll
-          for (int j = 0; j < AMX; ++j) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hg[j][r] = 0.f;
-            if ((aa_valid >> j) & 1u) {   // uniform
-              ld2f(bHG + (unsigned)j * (unsigned)DU * 4u, tix * 256u, hg[j][0], hg[j][1]);
-              ld2f(bHG + (unsigned)j * (unsigned)DU * 4u, tix * 256u + 128u, hg[j][2], hg[j][3]);
-            }
+          for (int j = 0; j < AMX; ++j) {   // all columns in one batch (see aa_tile); dead ones are skipped below
+            const unsigned jj = (unsigned)(j < aa_m ? j : aa_m - 1);
+            ld2f(bHG + jj * (unsigned)DU * 4u, tix * 256u, hg[j][0], hg[j][1]);
+            ld2f(bHG + jj * (unsigned)DU * 4u, tix * 256u + 128u, hg[j][2], hg[j][3]);
           }
 #pragma unroll
           for (int j = 0; j < AMX; ++j) {
-            if (!((aa_valid >> j) & 1u)) continue;   // uniform
+            const bool live = (aa_valid >> j) & 1u;   // uniform
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[r] -= gam[j] * (real)hg[j][r];
+            for (int r = 0; r < 4; ++r) out[r] = live ? out[r] - gam[j] * (real)hg[j][r] : out[r];
           }
         }
         st2(oUP, tix * 256u, out[0], out[1]);
