@@ -287,8 +287,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   {
     real f[3] = {qn, um, bad};
     stream_block_max<3, NWV>(f, SC, lane, wave);
-    qnorm = f[0];
-    pd = effective_pdiag<real>(pd_user, A.reg_rel, qnorm, f[1], A.horizon[b], lfb > 0.0 || dcb > 0.0);
+    // block-uniform doubles are forced into scalar registers (uniform_scalar, acn_qp_tiled.hpp): as vector-register
+    // pairs a dozen of them were spilled around every tile of the fused pass
+    qnorm = uniform_scalar(f[0]);
+    pd = uniform_scalar(effective_pdiag<real>(pd_user, A.reg_rel, qnorm, f[1], A.horizon[b], lfb > 0.0 || dcb > 0.0));
     if (f[2] > 0) {
       for (size_t k = tid; k < (size_t)N * Tm; k += kStreamWaves * 64) A.x[(size_t)b * N * Tm + k] = 0;
       if (A.y_out)
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   if (pass > 0) {   // fixed penalty retry_rho * 4^(pass - 1)
     rho = A.retry_rho;
     for (int k = 1; k < pass; ++k) rho *= 4.0;
+    rho = uniform_scalar(rho);
   }
   // P = Ghat r0 (or Ghat z1 during the start): this wave's accumulators for the output tiles (m, c) it owns
   // wave m (< MT) owns the output tiles (m, c) of all column tiles c: a Ghat fragment is then fetched once per
@@ -698,6 +701,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
         zh[r][c] = alpha * xn + (1.0 - alpha) * z1o[r] + y1o[r] * inv_rho;
         xv[r] = alpha * xn + (1.0 - alpha) * xv[r];   // x_new
         sq[r][c] = sigma * xv[r] - qv[r];
+        asm volatile("" : "+v"(sq[r][c]));   // formed HERE: the compiler otherwise keeps x_new and q (spilled) until the new r0
       }
       st2_nt(oX, fidp(e, c, 0), xv[0], xv[1]);
       st2_nt(oX, fidp(e, c, 1), xv[2], xv[3]);
@@ -767,7 +771,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
 #pragma unroll 1
   while (!done) {
     ++it;
-    const real a = sigma + pd + rho, inv_a = 1.0 / a, inv_rho = 1.0 / rho;
+    const real a = sigma + pd + rho, inv_a = uniform_scalar(1.0 / a), inv_rho = uniform_scalar(1.0 / rho);
     const bool check = (it % A.check_every == 0) || it >= max_iter_p;
     const bool ev_it = aa_m > 0 && it % kAaPeriod == 0;   // Anderson event: the projections follow the extrapolation
     // an offset the compiler cannot see through keeps the loads of loop-invariant site data (Q fragments, row
@@ -1279,7 +1283,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
         const real tol_eff = A.adapt_tol * (1.0 + (real)n_adapt * (1.0 / kAdaptWiden));
         if (ratio > tol_eff || ratio < 1.0 / tol_eff) {
           ++n_adapt;
-          rho = fmin(fmax(rho * ratio, 1e-6), 1e6);
+          rho = uniform_scalar(fmin(fmax(rho * ratio, 1e-6), 1e6));
           __syncthreads();     // every wave's stores of this pass are visible before the state is re-read
           rebuild_p();         // r0 depends on rho: P with the new penalty
           if (aa_m > 0) {      // the fixed-point map changed: restart the ring from the current (z, y)
