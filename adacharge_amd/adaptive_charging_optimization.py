@@ -152,7 +152,8 @@ def demand_charge(rates, infrastructure, interface, baseline_peak=0, **kwargs):
 # ---------------------------------------------------------------------------
 #  The optimiser (aco.py:18-321)
 # ---------------------------------------------------------------------------
-_HANDLE_CACHE = {}
+_HANDLE_CACHE = {}          # insertion-ordered: least recently used first
+_HANDLE_CACHE_MAX = 64
 
 
 def _site_handle(infrastructure, constraint_type, with_peak, device, with_flat=False, with_max=False):
@@ -170,13 +171,13 @@ def _site_handle(infrastructure, constraint_type, with_peak, device, with_flat=F
         np.asarray(infrastructure.voltages).tobytes(),
         constraint_type, bool(with_peak), int(device), bool(with_flat), bool(with_max),
     )
-    ent = _HANDLE_CACHE.get(key)
+    ent = _HANDLE_CACHE.pop(key, None)
     if ent is None:
         site = make_site(infrastructure, constraint_type, with_peak=with_peak, with_flat=with_flat, with_max=with_max)
         ent = (site, backend.SiteHandle(site, device))
-        if len(_HANDLE_CACHE) > 64:
-            _HANDLE_CACHE.clear()
-        _HANDLE_CACHE[key] = ent
+        while len(_HANDLE_CACHE) >= _HANDLE_CACHE_MAX:   # least recently used out; a caller that still holds the pair
+            _HANDLE_CACHE.pop(next(iter(_HANDLE_CACHE)))  # keeps its handle alive (SiteHandle frees the device side in __del__)
+    _HANDLE_CACHE[key] = ent                             # (re-)inserted last = most recently used
     return ent
 
 

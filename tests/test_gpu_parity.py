@@ -129,6 +129,28 @@ def test_no_sessions_returns_zero_column():   # aco.py:310-311
     assert out.shape == (2, 1) and not out.any()
 
 
+def test_site_handle_cache_evicts_least_recently_used_and_keeps_live_handles_working():
+    """More distinct sites than the cache holds: the oldest entries leave one at a time, an
+    optimiser whose site was evicted gets a fresh upload, and a handle a caller still holds keeps solving."""
+    from adacharge_amd import adaptive_charging_optimization as aco
+
+    aco._HANDLE_CACHE.clear()
+    first = tiny_interface(limit=40)
+    opt = AdaptiveChargingOptimization(DEFAULT_OBJECTIVE, first)
+    ref = opt.solve(first.active_sessions(), first.infrastructure_info())
+    held = next(iter(aco._HANDLE_CACHE.values()))   # (site, SiteHandle) of the first site, kept alive by this reference
+    for k in range(aco._HANDLE_CACHE_MAX + 6):      # distinct limits -> distinct sites
+        iface = tiny_interface(limit=41 + k)
+        AdaptiveChargingOptimization(DEFAULT_OBJECTIVE, iface).solve(iface.active_sessions(), iface.infrastructure_info())
+        assert len(aco._HANDLE_CACHE) <= aco._HANDLE_CACHE_MAX
+    assert all(ent[1] is not held[1] for ent in aco._HANDLE_CACHE.values())   # evicted ...
+    again = opt.solve(first.active_sessions(), first.infrastructure_info())   # ... and uploaded again on demand
+    assert np.array_equal(again, ref)
+    batch = build_batch([first.active_sessions()], first.infrastructure_info(), first, DEFAULT_OBJECTIVE, "SOC")
+    res = held[1].solve(batch, default_options())   # the evicted handle itself is still alive
+    assert res.status[0] == 1 and np.array_equal(res.x[0][:, :ref.shape[1]], ref)
+
+
 def test_bad_constraint_type_raises_value_error():   # aco.py:173-178
     iface = tiny_interface()
     with pytest.raises(ValueError, match="SOC or AFFINE"):
