@@ -1003,6 +1003,36 @@ def test_certified_infeasible_problems_are_infeasible_for_highs():
     h.close()
 
 
+def test_large_site_kernel_certificates_agree_with_highs():
+    """The same cross-check on the large-site kernel (128 EVSE, horizon 30, LINEAR rows, equality energy rows: about half
+    of the random instances cannot be served): what the device certifies infeasible is infeasible for scipy-HiGHS on the
+    problem the reference states, what it solves is feasible there, and the solved schedules meet every row."""
+    from adacharge_amd.acn import Interface
+    from oracle.ipm import solve_lp_highs
+    from oracle.ref_problem import build_reference_problem
+
+    rng = np.random.default_rng(5015)
+    infra = sites.wide128()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    snaps = [_random_sessions_general(infra, 30, rng, False, min_rates=False, demand_scale=0.15) for _ in range(48)]
+    batch = build_batch(snaps, infra, iface, obj, "LINEAR", True)
+    h = SiteHandle(batch.site, 0)
+    res = h.solve(batch, default_options(max_iter=30000))
+    h.close()
+    assert np.isin(res.status, (1, 3)).all(), np.unique(res.status)
+    flagged, solved = np.flatnonzero(res.status == 3), np.flatnonzero(res.status == 1)
+    assert len(flagged) >= 3 and len(solved) >= 3, (len(flagged), len(solved))
+    for b in list(flagged[:6]) + list(solved[:4]):
+        prob = build_reference_problem(snaps[b], infra, iface, [("quick_charge", 1, {})], "LINEAR", enforce_energy_equality=True)
+        lp = solve_lp_highs(prob)
+        assert (lp.status == 2) == (res.status[b] == 3), (b, lp.status, res.status[b])
+    x = res.x[solved]
+    mag = np.einsum("mn,bnt->bmt", np.abs(infra.constraint_matrix), x)
+    assert (mag - infra.constraint_limits[None, :, None]).max() < 5e-3
+    assert (x <= batch.ub[solved] + 1e-9).all() and (x >= batch.lb[solved] - 1e-9).all()
+
+
 # ---- N > 1 with the real library: two ranks share the one GPU of the test box, gloo for the gather -----------------
 def _sharded_rank(rank, world, port, q):
     import torch.distributed as dist

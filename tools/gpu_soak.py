@@ -14,23 +14,29 @@ B0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # second argument: seed offset (other instances of the same classes)
 bad_total = 0
 # cases 8-13: the long-horizon kernel (horizons 40 ... 200, two session slots, peaks, equality rows) and its
-# LDS-resident variant (jpl52 at horizons 24 / 30)
-for case in range(14):
+# LDS-resident variant (jpl52 at horizons 24 / 30); cases 14-19: the large-site kernel (128 / 192 / 512 EVSE, horizons
+# 12 ... 48, one / two / three column tiles, two session slots, equality rows, peaks)
+WIDE = {14: ("wide128", 12), 15: ("wide128", 30), 16: ("wide192", 48), 17: ("synth512", 24), 18: ("synth512", 48), 19: ("wide192", 16)}
+for case in range(20):
     rng = np.random.default_rng(5000 + case + 100 * SEED)
     B = B0
-    T = [12, 16, 24, 30, 12, 20, 9, 32, 40, 72, 144, 200, 24, 30][case]
+    T = [12, 16, 24, 30, 12, 20, 9, 32, 40, 72, 144, 200, 24, 30, 12, 30, 48, 24, 48, 16][case]
     ct = ["SOC", "LINEAR"][case % 2]
-    eq = case in (2, 5, 9); two = case in (1, 3, 5, 7, 8, 10, 13); with_peak = case in (0, 3, 4, 7, 9, 11, 12)
+    eq = case in (2, 5, 9, 15, 18); two = case in (1, 3, 5, 7, 8, 10, 13, 16, 19); with_peak = case in (0, 3, 4, 7, 9, 11, 12, 17)
     infra = sites.caltech54() if case not in (6, 10, 12, 13) else sites.jpl52()
-    if case >= 8 and T > 32:
+    if case in WIDE:
+        infra = getattr(sites, WIDE[case][0])()
+        B = max(32, B0 // (4 if infra.num_stations <= 192 else 16))
+    if 8 <= case < 14 and T > 32:
         B = max(32, B0 // 16)
     iface = Interface({"infrastructure_info": infra, "period": 5, "prices": rng.uniform(0.05, 0.4, size=256)})
     obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 10.0 ** rng.uniform(-4, -2)),
            ObjectiveComponent(tou_energy_cost, float(rng.uniform(0, 5))), ObjectiveComponent(total_energy, float(rng.uniform(0, 2)))]
     snaps, peaks = [], []
     for _ in range(B):
-        snaps.append(_random_sessions_general(infra, T, rng, two, min_rates=not eq, demand_scale=0.5 if eq else 1.5))
-        peaks.append((float(rng.uniform(250, 600)) if rng.random() < 0.5 else rng.uniform(250, 600, size=T)) if with_peak else None)
+        snaps.append(_random_sessions_general(infra, T, rng, two, min_rates=not eq, demand_scale=(0.5 if eq else 1.5) * (0.3 if case in WIDE else 1.0)))
+        pscale = infra.num_stations / 54.0
+        peaks.append((float(rng.uniform(250, 600) * pscale) if rng.random() < 0.5 else rng.uniform(250, 600, size=T) * pscale) if with_peak else None)
     Ts = [max(s.arrival_offset + s.remaining_time for s in sl) for sl in snaps]
     peaks = [p if (p is None or np.isscalar(p)) else p[:t] for p, t in zip(peaks, Ts)]
     batch = build_batch(snaps, infra, iface, obj, ct, eq, peak_limits=peaks)
