@@ -67,9 +67,15 @@ def scan_isa(text):
     return stores, found
 
 
+class ScannerUnavailable(RuntimeError):
+    """llvm-objdump is not where the ROCm image keeps it: the scan cannot run (the build warns and goes on)."""
+
+
 def scan_library(path):
     """Disassemble every gfx950 code object bundled in the shared library at ``path``; returns (stores, hazards)."""
     objdump = os.path.join(_LLVM_BIN, "llvm-objdump")
+    if not os.path.exists(objdump):
+        raise ScannerUnavailable(f"{objdump} not found")
     stores, found = 0, []
     with tempfile.TemporaryDirectory() as tmp:
         local = os.path.join(tmp, "lib.so")

@@ -24,6 +24,10 @@ def test_scanner_finds_an_overwritten_wide_store_and_accepts_the_guarded_forms()
 
 
 def test_built_library_has_wide_stores_and_none_is_unguarded(hip_library):
-    stores, found = store_hazard.scan_library(backend.library_path())
+    try:
+        stores, found = store_hazard.scan_library(backend.library_path())
+    except store_hazard.ScannerUnavailable as e:   # no llvm-objdump in this image: nothing to check with
+        import pytest
+        pytest.skip(str(e))
     assert stores > 100, stores          # the long-horizon kernel's 16-byte accesses are there
     assert not found, store_hazard.describe(found)
