@@ -407,14 +407,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   // e of the round, in tile order.  ONE barrier per round: the slabs alternate, and the slab of round rd is written
   // again in round rd + 2, after the barrier of round rd + 1, which an owner passes only with its reads of round rd
   // done.  p_finish() (one more barrier) closes a pass before anything else touches the slabs (h^ aliases the second).
-  auto p_round = [&](int rd, bool have, const real (&v)[4][CT]) __attribute__((always_inline)) {
+  // (two halves: p_stage sits INSIDE the caller's `if (have)` next to the code that produced v -- with the slab write
+  //  behind a second `if (have)` after the join the tile vector was live across the join as phi(v, undefined), and the
+  //  allocator spilled and reloaded thirteen dead registers around every tile)
+  auto p_stage = [&](int rd, const real (&v)[4][CT]) __attribute__((always_inline)) {
     real* RED = RED0 + (size_t)(rd & 1) * (kStreamWaves * CT * 256);
-    if (have) {
 #pragma unroll
-      for (int c = 0; c < CT; ++c)
+    for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) RED[((wave * CT + c) * 4 + s) * 64 + lane] = v[s][c];
-    }
+      for (int s = 0; s < 4; ++s) RED[((wave * CT + c) * 4 + s) * 64 + lane] = v[s][c];
+  };
+  auto p_round = [&](int rd) __attribute__((always_inline)) {
+    real* RED = RED0 + (size_t)(rd & 1) * (kStreamWaves * CT * 256);
     __syncthreads();
     const int ne = min(kStreamWaves, NE - rd * kStreamWaves);
     if (wave < MT) {
@@ -444,8 +448,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       RELANE();
       const int e = rd * kStreamWaves + wave;
       const bool have = e < NE;
-      real r0[4][CT];
       if (have) {
+        real r0[4][CT];
 #pragma unroll
         for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -453,8 +457,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
             const size_t i = fidx(e, c, r);
             r0[r][c] = sigma * Xs[i] - Qs[i] + rho * Z1s[i] - Y1s[i];
           }
+        p_stage(rd, r0);
       }
-      p_round(rd, have, r0);
+      p_round(rd);
     }
     p_finish();
   };
@@ -468,8 +473,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
     RELANE();
     const int e = rd * kStreamWaves + wave;
     const bool have = e < NE;
-    real z1[4][CT];
     if (have) {
+      real z1[4][CT];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         real zs[CT], lbv[CT], ubv[CT], qv[CT];
@@ -491,8 +496,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
           Xs[i] = z1[r][c]; Z1s[i] = z1[r][c]; Y1s[i] = -(qv[c] + pd * z1[r][c]);
         }
       }
+      p_stage(rd, z1);
     }
-    p_round(rd, have, z1);
+    p_round(rd);
   }
   p_finish();
   // Ghat z1 sits with the owners: hand it to the site-row update below through G0H
@@ -876,16 +882,17 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
         RELANE();
         const int e = rd * kStreamWaves + wave;
         const bool have = e < NE;
-        real zh[4][CT], sq[4][CT];
         if (have) {
+          real zh[4][CT], sq[4][CT];
           tile_front(e, inv_a, inv_rho, zh, sq);
           STAMP(1);   // fused pass: front (loads, MFMA, x store)
           tile_back(e, zh, sq);
           STAMP(2);   // fused pass: back (bounds, water-filling, z1 / y1 stores)
           if (check) tile_residuals(e);
           STAMP(3);   // residual terms (check iterations)
+          p_stage(rd, zh);   // the tile's new r0 joins next iteration's P
         }
-        p_round(rd, have, zh);   // the tile's new r0 joins next iteration's P
+        p_round(rd);
         STAMP(4);   // round: slab, barrier, owners' MFMA
       }
       p_finish();
@@ -1085,8 +1092,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
         RELANE();
         const int e = rd * kStreamWaves + wave;
         const bool have = e < NE;
-        real zh[4][CT], sq[4][CT];
         if (have) {
+          real zh[4][CT], sq[4][CT];
 #pragma unroll
           for (int c = 0; c < CT; ++c) {
             real o4[4], xq[4], qq[4];
@@ -1103,8 +1110,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
           }
           tile_back(e, zh, sq);
           if (check) tile_residuals(e);
+          p_stage(rd, zh);
         }
-        p_round(rd, have, zh);
+        p_round(rd);
       }
       p_finish();
       STAMP(6);   // Anderson event iteration (both passes)
