@@ -65,6 +65,7 @@ struct TiledArgs {
   const void *fragG, *fragQ;                  // Ghat, Q as MFMA A-operand fragments: [NW][MT][2][4][64], [MT][MT][2][4][64]
   const void *fragG2, *fragQ2;                // the same blocks with the k-slices as two pairs per lane: [..][2][64][2] (acn_qp_long.hpp)
   const int32_t* horizon;
+  const int32_t* order;                       // [B] or null: workgroup -> problem (longest expected first, acn_qp_api.hip)
   const double *lb, *ub, *q, *pdiag;
   const int32_t *s_off, *s_len;
   const double* s_cap;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   int tid = threadIdx.x;
   asm volatile("" : "+v"(b_));
   asm volatile("" : "+v"(tid));
-  const int b = __builtin_amdgcn_readfirstlane(b_);
+  const int wg_ = __builtin_amdgcn_readfirstlane(b_);
   // ... and the argument block is read through a per-pass opaque pointer to the kernarg segment (the by-value struct
   // sits at its offset 0): scalar loads from constant memory, hoisted freely inside a pass, never across passes
   // (otherwise every argument the loads and the start use stays in a scalar register through the solver loop)
@@ -359,6 +360,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   asm volatile("" : "+s"(Ap));
   const auto& A = *Ap;
   (void)A_kernarg;
+  const int b = A.order ? A.order[wg_] : wg_;   // the problem this workgroup solves
   const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
   const int adapt_p = pass == 0 ? A.adapt_every : 0;
   const int lane = tid & 63, wave = tid >> 6;
