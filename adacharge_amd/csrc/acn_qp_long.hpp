@@ -111,7 +111,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   int b_ = blockIdx.x; int tid = threadIdx.x;
   asm volatile("" : "+v"(b_)); asm volatile("" : "+v"(tid));
   const int wg_ = __builtin_amdgcn_readfirstlane(b_);
-  const int b = A.order ? A.order[wg_] : wg_;   // the problem this workgroup solves
+  const int b = __builtin_amdgcn_readfirstlane(A.order ? A.order[wg_] : wg_);   // the problem this workgroup solves (a uniform value: the load alone would make it a vector register)
 #else
   const int b = blockIdx.x, tid = threadIdx.x;   // diagnostic: descriptor in vector registers (round 2's form)
 #endif

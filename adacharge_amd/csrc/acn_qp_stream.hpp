@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   asm volatile("" : "+v"(b_));
   asm volatile("" : "+v"(tid));
   const int wg_ = __builtin_amdgcn_readfirstlane(b_);
-  const int b = A.order ? A.order[wg_] : wg_;   // the problem this workgroup solves
+  const int b = __builtin_amdgcn_readfirstlane(A.order ? A.order[wg_] : wg_);   // the problem this workgroup solves (a uniform value: the load alone would make it a vector register)
   const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
   const int adapt_p = pass == 0 ? A.adapt_every : 0;
   // wave index as a scalar: tile bases become SGPR addresses (global_load saddr + lane offset) instead of one 64-bit

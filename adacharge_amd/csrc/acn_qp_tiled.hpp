@@ -360,7 +360,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   asm volatile("" : "+s"(Ap));
   const auto& A = *Ap;
   (void)A_kernarg;
-  const int b = A.order ? A.order[wg_] : wg_;   // the problem this workgroup solves
+  const int b = __builtin_amdgcn_readfirstlane(A.order ? A.order[wg_] : wg_);   // the problem this workgroup solves (a uniform value: the load alone would make it a vector register)
   const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
   const int adapt_p = pass == 0 ? A.adapt_every : 0;
   const int lane = tid & 63, wave = tid >> 6;
