@@ -715,8 +715,11 @@ struct ChunkLayout {
 // per_problem_bytes: inputs + results staged per problem AND the kernel's per-problem workspace (the long-horizon and
 // large-site kernels keep their iterates there: 1.6 MB per problem at 54 x 144, far more than the inputs) -- every one
 // of the kSlots pipeline slots holds a chunk of each, so a chunk is capped at 1 GiB of the sum
-long long chunk_problems(size_t per_problem_bytes) {
-  long long want = 2048;   // problems per launch: large enough that the launch tail (its slowest problems) is short
+long long chunk_problems(size_t per_problem_bytes, bool on_chip) {
+  // problems per launch: large enough that the launch tail (its slowest problems) is short.  The register-resident
+  // kernel takes 1,024 (two per workgroup slot): with the launches sorted longest-first (order_sort_kernel) and four
+  // streams in flight the shorter pipeline head and tail outweigh the per-launch tails (bench: 441 -> 455 k QP/s)
+  long long want = on_chip ? 1024 : 2048;
   if (const char* e = std::getenv("ACNQP_CHUNK")) { const long long v = std::atoll(e); if (v > 0) want = v; }
   const long long by_mem = (long long)((size_t)1024 * 1024 * 1024 / std::max<size_t>(per_problem_bytes, 1));
   long long n = std::max<long long>(1, std::min(want, by_mem));
@@ -741,11 +744,11 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
         chunks.emplace_back();
         cur_T = (int)Tm; cur_K = (int)K; cur_opt = opt; fill = 0;
         cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96 +
-                             (size_t)workspace_doubles(h, (int)Tm, (int)K, o->accel_mem) * 8);
+                             (size_t)workspace_doubles(h, (int)Tm, (int)K, o->accel_mem) * 8, tiled_shape(h, (int)Tm, (int)K));
         // ramp: the first kernel cannot start before its chunk's H2D has landed, and nothing overlaps that copy -- a
         // quarter-size first chunk (then a half-size one) shortens the exposed head of the pipeline
         static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
-        if (ramp && cap >= 2048) {
+        if (ramp && cap >= 1024) {
           if (chunks.size() == 1) cap /= 4;
           else if (chunks.size() == 2) cap /= 2;
         }
