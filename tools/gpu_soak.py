@@ -35,7 +35,7 @@ for case in range(20):
     snaps, peaks = [], []
     for _ in range(B):
         snaps.append(_random_sessions_general(infra, T, rng, two, min_rates=not eq, demand_scale=(0.5 if eq else 1.5) * (0.3 if case in WIDE else 1.0)))
-        pscale = infra.num_stations / 54.0
+        pscale = infra.num_stations / 54.0 * (3.0 if case in WIDE else 1.0)   # wide sites: sessions on most EVSEs, minimum rates
         peaks.append((float(rng.uniform(250, 600) * pscale) if rng.random() < 0.5 else rng.uniform(250, 600, size=T) * pscale) if with_peak else None)
     Ts = [max(s.arrival_offset + s.remaining_time for s in sl) for sl in snaps]
     peaks = [p if (p is None or np.isscalar(p)) else p[:t] for p, t in zip(peaks, Ts)]
@@ -51,8 +51,8 @@ for case in range(20):
         mag = np.hypot(np.einsum("mn,bnt->bmt", cm * np.cos(ph), x), np.einsum("mn,bnt->bmt", cm * np.sin(ph), x))
     else:
         mag = np.einsum("mn,bnt->bmt", np.abs(cm), x)
-    viol = float((mag - infra.constraint_limits[None, :, None]).max())
-    pk = float((x.sum(axis=1) - batch.peak[ok]).max()) if with_peak else 0.0
+    viol = float((mag - infra.constraint_limits[None, :, None]).max()) if len(x) else 0.0
+    pk = float((x.sum(axis=1) - batch.peak[ok]).max()) if with_peak and len(x) else 0.0
     counts = np.bincount(r.status, minlength=6)[1:]
     print(f"case {case} {ct} T={T} eq={eq} K={batch.K} peak={with_peak}: status counts(1..5) {counts.tolist()} finite {finite} box {box} "
           f"max row violation {viol:.2e} max peak violation {pk:.2e} iters mean {r.iters.mean():.0f} max {r.iters.max()} kernel {r.kernel_ms:.1f} ms", flush=True)
