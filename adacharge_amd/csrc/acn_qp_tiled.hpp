@@ -701,10 +701,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
             const bool bracketed = lo > -BIGC && hi < BIGC;
             const real mid = (real)0.5 * (lo + hi);
             bool newton = nf > 0.f;
-            real cand = newton ? m + d * (real)rcp_small(nf) : (bracketed ? mid : fmin(fmax(m + d, lo), hi));
-            if (!eq && cand < (real)0) { cand = 0; newton = false; }      // inequality: multiplier >= 0
+            real rc = (real)rcp_small(newton ? nf : 1.f);   // formed for every lane (a select, not a divergent region)
+            asm volatile("" : "+v"(rc));
+            real cand = newton ? m + d * rc : (bracketed ? mid : fmin(fmax(m + d, lo), hi));
+            const bool neg = !eq && cand < (real)0;                       // inequality: multiplier >= 0
+            cand = neg ? (real)0 : cand;
+            newton = newton && !neg;
             real alt = bracketed ? mid : fmin(fmax(cand, lo), hi);
-            if (!eq && alt < (real)0) alt = 0;
+            alt = (!eq && alt < (real)0) ? (real)0 : alt;
             const bool inside = cand > lo && cand < hi;
             cand = inside ? cand : alt;
             newton = newton && inside;
@@ -718,8 +722,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
               for (int tt = 0; tt < 4; ++tt) {
                 const bool inw = (swm[k] >> (4 * c + tt)) & 1u;
                 const real v0 = szh[c][tt] - m, v1 = szh[c][tt] - cand;
-                const bool ch = ((v0 < sub[c][tt]) != (v1 < sub[c][tt])) || ((v0 > slb[c][tt]) != (v1 > slb[c][tt]));
-                moved |= (inw && ch) ? 1u : 0u;
+                const bool ch = ((v0 < sub[c][tt]) != (v1 < sub[c][tt])) | ((v0 > slb[c][tt]) != (v1 > slb[c][tt]));
+                moved |= (unsigned)(inw & ch);   // (bitwise: `&&` / `||` became divergent branches)
               }
             { const Pair32 p = swap_u32<16>(moved); moved = p.a | p.b; }
             { const Pair32 q = swap_u32<32>(moved); moved = q.a | q.b; }
@@ -730,16 +734,20 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           };
           newton_pass();                       // peeled: straight-line with the site-row update above
           while (__any(need)) newton_pass();   // rare: the active set of some session changed
-          if (smode[k] == 0) mu[k] = m;
+          mu[k] = smode[k] == 0 ? m : mu[k];
 #pragma unroll
           for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
-              if ((swm[k] >> (4 * c + tt)) & 1u) {
-                if (smode[k] == 0) sz[c][tt] = fmin(fmax(szh[c][tt] - m, slb[c][tt]), sub[c][tt]);
-                else if (smode[k] == 2) sz[c][tt] = sub[c][tt];
-                else if (smode[k] == 3) sz[c][tt] = slb[c][tt];
-              }
+            {   // branch-free: a lane's window bit and mode select among the candidates (same values)
+              const bool inw = (swm[k] >> (4 * c + tt)) & 1u;
+              const real v0 = fmin(fmax(szh[c][tt] - m, slb[c][tt]), sub[c][tt]);
+              real val = sz[c][tt];
+              val = smode[k] == 3 ? slb[c][tt] : val;
+              val = smode[k] == 2 ? sub[c][tt] : val;
+              val = smode[k] == 0 ? v0 : val;
+              sz[c][tt] = inw ? val : sz[c][tt];
+            }
         }
       }
       STAMP(8);   // Newton passes
@@ -1211,25 +1219,31 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         int rty[4];
         row_types(mo, rty);
         const real pkc = A.peak ? peak_at(c) : BIGC;   // block-uniform branch: only sites with a peak row load it
-        real scl[2] = {(real)1, (real)1};   // radial clip factor of the register pairs (0,1), (2,3)
+        // Branch-free over the row types (a lane's type depends on its row, so every `if` here was a divergent region:
+        // s_and_saveexec / s_cbranch_execz / s_or exec -- 36 of them per iteration in every wave for four registers):
+        // every candidate is formed and the type selects one.  Same values as the branches gave.
+        real scl[2], lim4[4];
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          if (rty[2 * pr] == kRowSocRe) {
-            const real re = zhr[mo][c][2 * pr], im = zhr[mo][c][2 * pr + 1], lim = RowLim[16 * mo + M::rowof(g, 2 * pr)];
-            const real n2 = re * re + im * im;
-            if (n2 > lim * lim) scl[pr] = lim * rsqrt_nr(n2);
-          }
+        for (int r = 0; r < 4; ++r) { lim4[r] = RowLim[16 * mo + M::rowof(g, r)]; asm volatile("" : "+v"(lim4[r])); }   // (not sunk back into a branch)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {   // radial clip factor of the register pairs (0,1), (2,3)
+          const real re = zhr[mo][c][2 * pr], im = zhr[mo][c][2 * pr + 1], lim = lim4[2 * pr];
+          const real n2 = re * re + im * im;
+          const bool clip = rty[2 * pr] == kRowSocRe && n2 > lim * lim;
+          const real n2s = clip ? n2 : (real)1;            // rsqrt of a harmless argument where the lane does not clip
+          const real f = lim * rsqrt_nr(n2s);
+          scl[pr] = clip ? f : (real)1;
         }
+        const real quadf = rho / (rho + lfb);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const real zh_ = zhr[mo][c][r];
-          real zn = zh_;
           const int ty = rty[r];
-          if (ty == kRowBox) zn = fmin(zh_, RowLim[16 * mo + M::rowof(g, r)]);
-          else if (ty == kRowPeak) zn = fmin(zh_, pkc);
-          else if (ty == kRowQuad) zn = zh_ * (rho / (rho + lfb));
-          // kRowMax: zn = zh_ here; the horizon-wide prox follows the tile loop
-          else if (ty == kRowSocRe || ty == kRowSocIm) zn = zh_ * scl[r >> 1];
+          real zn = zh_;                                   // kRowMax / unused rows: zn = zh_ (the horizon-wide prox follows)
+          zn = (ty == kRowSocRe || ty == kRowSocIm) ? zh_ * scl[r >> 1] : zn;
+          zn = ty == kRowQuad ? zh_ * quadf : zn;
+          zn = ty == kRowPeak ? fmin(zh_, pkc) : zn;
+          zn = ty == kRowBox ? fmin(zh_, lim4[r]) : zn;
           y2[mo][c][r] = rho * (zh_ - zn);
           z2[mo][c][r] = zn;
         }
