@@ -678,14 +678,17 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
             const real gs = quarter_sum<real>(gl);
             const float nf = quarter_sum<float>(nl);
             const real d = gs - cap;
-            const bool fin = fabs(d) <= tol || (!eq && m <= (real)0 && d <= (real)0) || guard > ACNQP_GUARD_MAX;
-            need = need && !fin;
-            lo = (need && d > 0) ? m : lo;
-            hi = (need && !(d > 0)) ? m : hi;
+            // (per-lane logic with bitwise & / |: every `&&` / `||` of per-lane conditions was a divergent region of its own)
+            const real big_ = BIGC;
+            const bool fin = (fabs(d) <= tol) | (!eq & (m <= (real)0) & (d <= (real)0)) | (guard > ACNQP_GUARD_MAX);
+            need = need & !fin;
+            const bool dpos = d > 0;
+            lo = (need & dpos) ? m : lo;
+            hi = (need & !dpos) ? m : hi;
             // flat piece with an open bracket (rare): fetch the true bracket ends so the fallback bisects
-            const bool open = need && nf <= 0.f && !(lo > -BIGC && hi < BIGC);
+            const bool open = need & (nf <= 0.f) & !((lo > -big_) & (hi < big_));
             if (__any(open)) {   // the bracket ends are only ever needed here
-              real lo_l = BIGC, hi_l = -BIGC;
+              real lo_l = big_, hi_l = -big_;
 #pragma unroll
               for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -698,20 +701,24 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
               lo = open ? fmax(lo, lo0) : lo;
               hi = open ? fmin(hi, hi0) : hi;
             }
-            const bool bracketed = lo > -BIGC && hi < BIGC;
+            const bool bracketed = (lo > -big_) & (hi < big_);
             const real mid = (real)0.5 * (lo + hi);
             bool newton = nf > 0.f;
             real rc = (real)rcp_small(newton ? nf : 1.f);   // formed for every lane (a select, not a divergent region)
             asm volatile("" : "+v"(rc));
-            real cand = newton ? m + d * rc : (bracketed ? mid : fmin(fmax(m + d, lo), hi));
-            const bool neg = !eq && cand < (real)0;                       // inequality: multiplier >= 0
+            real c_newton = m + d * rc, c_clamped = fmin(fmax(m + d, lo), hi);   // both candidates, then selects
+            asm volatile("" : "+v"(c_newton), "+v"(c_clamped));
+            real cand = newton ? c_newton : (bracketed ? mid : c_clamped);
+            const bool neg = !eq & (cand < (real)0);                      // inequality: multiplier >= 0
             cand = neg ? (real)0 : cand;
-            newton = newton && !neg;
-            real alt = bracketed ? mid : fmin(fmax(cand, lo), hi);
-            alt = (!eq && alt < (real)0) ? (real)0 : alt;
-            const bool inside = cand > lo && cand < hi;
+            newton = newton & !neg;
+            real a_clamped = fmin(fmax(cand, lo), hi);
+            asm volatile("" : "+v"(a_clamped));
+            real alt = bracketed ? mid : a_clamped;
+            alt = (!eq & (alt < (real)0)) ? (real)0 : alt;
+            const bool inside = (cand > lo) & (cand < hi);
             cand = inside ? cand : alt;
-            newton = newton && inside;
+            newton = newton & inside;
             // A Newton step that keeps every period of the window on its piece of g (same side of
             // lb / ub before and after) is exact: g is linear between m and cand.  One OR-reduction
             // of a flag word over the session's four lanes replaces the verifying pass.
@@ -728,9 +735,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
             { const Pair32 p = swap_u32<16>(moved); moved = p.a | p.b; }
             { const Pair32 q = swap_u32<32>(moved); moved = q.a | q.b; }
             // no representable progress (the residual sits at rounding level, typical in fp32): stop
-            need = need && cand != m;
+            need = need & (cand != m);
             m = need ? cand : m;
-            need = need && !(newton && moved == 0u);
+            need = need & !(newton & (moved == 0u));
           };
           newton_pass();                       // peeled: straight-line with the site-row update above
           while (__any(need)) newton_pass();   // rare: the active set of some session changed
