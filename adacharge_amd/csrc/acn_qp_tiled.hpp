@@ -748,7 +748,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
             for (int tt = 0; tt < 4; ++tt)
             {   // branch-free: a lane's window bit and mode select among the candidates (same values)
               const bool inw = (swm[k] >> (4 * c + tt)) & 1u;
-              const real v0 = fmin(fmax(szh[c][tt] - m, slb[c][tt]), sub[c][tt]);
+              real v0 = fmin(fmax(szh[c][tt] - m, slb[c][tt]), sub[c][tt]);
+              asm volatile("" : "+v"(v0));   // formed for every lane: the selects below stay selects
               real val = sz[c][tt];
               val = smode[k] == 3 ? slb[c][tt] : val;
               val = smode[k] == 2 ? sub[c][tt] : val;
@@ -1246,11 +1247,14 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         for (int r = 0; r < 4; ++r) {
           const real zh_ = zhr[mo][c][r];
           const int ty = rty[r];
-          real zn = zh_;                                   // kRowMax / unused rows: zn = zh_ (the horizon-wide prox follows)
-          zn = (ty == kRowSocRe || ty == kRowSocIm) ? zh_ * scl[r >> 1] : zn;
-          zn = ty == kRowQuad ? zh_ * quadf : zn;
-          zn = ty == kRowPeak ? fmin(zh_, pkc) : zn;
-          zn = ty == kRowBox ? fmin(zh_, lim4[r]) : zn;
+          // a scale factor (SOC pair / quadratic row; 1 otherwise) and an upper limit (box / peak row; +big otherwise):
+          // zh * 1 and min(., big) leave the value untouched, so one multiply and one min serve every row type
+          // (kRowMax / unused rows: zn = zh_, the horizon-wide prox follows)
+          real fac = ((ty == kRowSocRe) | (ty == kRowSocIm)) ? scl[r >> 1] : (real)1;
+          fac = ty == kRowQuad ? quadf : fac;
+          real cap_ = ty == kRowBox ? lim4[r] : BIGC;
+          cap_ = ty == kRowPeak ? pkc : cap_;
+          const real zn = fmin(zh_ * fac, cap_);
           y2[mo][c][r] = rho * (zh_ - zn);
           z2[mo][c][r] = zn;
         }
