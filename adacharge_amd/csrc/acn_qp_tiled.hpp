@@ -363,7 +363,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   const int b = __builtin_amdgcn_readfirstlane(A.order ? A.order[wg_] : wg_);   // the problem this workgroup solves (a uniform value: the load alone would make it a vector register)
   const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
   const int adapt_p = pass == 0 ? A.adapt_every : 0;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave index as a SCALAR: `if (wave == 0)` is a scalar branch,
+                                                                                // per-wave LDS regions are scalar offsets (it was a vector value: divergent regions)
   const int g = lane >> 4, t = lane & 15;
   const int N = A.N, Tm = A.Tm, NP = A.NP, MR = A.MR;
   const int aa_m = AM > 0 ? min(A.accel_mem, AM) : 0;
