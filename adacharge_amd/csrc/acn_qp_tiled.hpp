@@ -1244,6 +1244,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           scl[pr] = clip ? f : (real)1;
         }
         const real quadf = rho / (rho + lfb);
+        const real big_s = BIGC;   // once, outside the selects (the opaque constant inside a select made each a branch)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const real zh_ = zhr[mo][c][r];
@@ -1253,7 +1254,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           // (kRowMax / unused rows: zn = zh_, the horizon-wide prox follows)
           real fac = ((ty == kRowSocRe) | (ty == kRowSocIm)) ? scl[r >> 1] : (real)1;
           fac = ty == kRowQuad ? quadf : fac;
-          real cap_ = ty == kRowBox ? lim4[r] : BIGC;
+          real cap_ = ty == kRowBox ? lim4[r] : big_s;
           cap_ = ty == kRowPeak ? pkc : cap_;
           const real zn = fmin(zh_ * fac, cap_);
           y2[mo][c][r] = rho * (zh_ - zn);
