@@ -194,7 +194,7 @@ __device__ inline double rcp_small(float nf) {
 // LDS carve-up in units of `real`; shared by host (size) and device (offsets)
 constexpr int kXS = 18;   // row stride (reals) of the per-wave 16 x 16 transpose scratch: 16-B aligned quads
 struct TiledLds {
-  int pbuf, xpose, red, rowc, aared, aah, hist, snap, total;   // offsets in reals; hist..total hold floats
+  int pbuf, xpose, red, rowc, fragq, aared, aah, hist, snap, total;   // offsets in reals; hist..total hold floats
   int hist1, hist2;                                // floats per history column: tile part, site-row part
   int pstride;                                     // reals between the partial-tile regions of two waves in a slab
   __host__ __device__ TiledLds(int NW, int MT, int CT, int NP, int K, int AM, int accel_mem, int real_bytes, int pbuf_single = 0) {
@@ -209,6 +209,7 @@ struct TiledLds {
     xpose = o; o += pbuf_single ? NW * xp : 0;   // a separate scratch only when there is no idle slab
     red = o;   o += 16 * kNumRed + 8;
     rowc = o;  o += 3 * 16 * MT + 8 * MT;        // per site row: eigenvalue, limit, rho / (a + rho lam); then the row types (ints)
+    fragq = o; o += MT == 1 ? 2 * 4 * 64 : 0;    // one row tile: the Q fragments of the two site-row products (4 KB), read by every wave
     aared = o; o += accel_mem > 0 ? NW * (AM + 2) : 0;          // per-wave partial dot products
     aah = o;   o += accel_mem > 0 ? NW * (AM * AM + AM) : 0;    // per-wave copy of the Gram matrix and rhs
     o = (o + 1) & ~1;
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   // site-row constants in C layout: row j = 16 m + rowof(g, r)
   // per-row constants (eigenvalue, limit, D = rho / (a + rho lam)) live in a small LDS table, not in 24 registers
   real* RowLam = sm + L.rowc;
+  real* FQs = sm + L.fragq;   // MT == 1: Q fragments in LDS (an LDS read instead of a global load in front of 8 of the 16 MFMA)
   real* RowLim = RowLam + 16 * MT;
   real* RowDj = RowLim + 16 * MT;
   // row types: an LDS table in the lanes' own order -- entry (m, g, r) = type of row 16 m + rowof(g, r), the four of a
@@ -402,6 +404,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     RowLam[j] = Lm[j]; RowLim[j] = RL[j];
     const int m_ = j >> 4, g_ = (j >> 2) & 3, r_ = j & 3;
     RowTy[j] = A.rowtype[16 * m_ + M::rowof(g_, r_)];
+  }
+  if constexpr (MT == 1) {   // (a barrier follows before the first use)
+    const real* FQg = static_cast<const real*>(A.fragQ);
+    for (int j = tid; j < 2 * 4 * 64; j += NW * 64) FQs[j] = FQg[j];
   }
   auto row_types = [&](int m, int (&ty)[4]) __attribute__((always_inline)) {
     const int4 v = *reinterpret_cast<const int4*>(RowTy + (m * 4 + g) * 4);
@@ -924,7 +930,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = M::mma(kFragRes >= 2 ? fQtr[s] : FQ[(((mo * MT + mi) * 2 + 0) * 4 + s) * 64 + lane], rho * z2[mi][c][s] - y2[mi][c][s], acc);
+          for (int s = 0; s < 4; ++s) acc = M::mma(kFragRes >= 2 ? fQtr[s] : (MT == 1 ? FQs[(0 * 4 + s) * 64 + lane] : FQ[(((mo * MT + mi) * 2 + 0) * 4 + s) * 64 + lane]), rho * z2[mi][c][s] - y2[mi][c][s], acc);
         wh[mo][c] = acc;
       }
     }
@@ -988,7 +994,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) zt = M::mma(kFragRes >= 1 ? fQr[s] : (kFragPre ? fQp[s] : FQ[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane]), hh[mi][c][s], zt);
+          for (int s = 0; s < 4; ++s) zt = M::mma(kFragRes >= 1 ? fQr[s] : (kFragPre ? fQp[s] : (MT == 1 ? FQs[(1 * 4 + s) * 64 + lane] : FQ[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane])), hh[mi][c][s], zt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           gx[mo][c][r] = alpha * zt[r] + ((real)1 - alpha) * gx[mo][c][r];
