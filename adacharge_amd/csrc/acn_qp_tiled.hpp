@@ -874,23 +874,25 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   }
 
 #ifndef ACNQP_FRAG_RESIDENT
-#define ACNQP_FRAG_RESIDENT 0
+#define ACNQP_FRAG_RESIDENT 2
 #endif
-  // A-operand fragments kept in registers across the loop (MT == 1 only): level 1 = the two post-barrier products
-  // (x~ = r0 + Ghat' e^, G x~ = Q h^), whose just-in-time loads sit on the iteration's critical path; level 2 = all four
+  // A-operand fragments of this wave's OWN products (P_w = Ghat_w r0: level 2; x~ = r0 + Ghat_w' e^: level 1) kept in
+  // registers across the loop (MT == 1 only: 8 / 16 registers); the Q fragments of the two site-row products, shared by
+  // all waves, sit in LDS (FQs).  With both the loop issues no global load for an MFMA operand at all: lone launch
+  // 30.1 -> 28.9 ms (level 2; level 1: 30.0), at 4 spilled registers.  (Round 3 first measured the registers-only form
+  // with every fragment resident: -3.7 % for +35 spilled registers -- the LDS copy of Q is what made it affordable.)
   constexpr int kFragRes = MT == 1 ? ACNQP_FRAG_RESIDENT : 0;
 #ifndef ACNQP_FRAG_PREFETCH
 #define ACNQP_FRAG_PREFETCH 0
 #endif
   constexpr bool kFragPre = MT == 1 && kFragRes == 0 && ACNQP_FRAG_PREFETCH != 0;
-  real fXr[4], fQr[4], fPr[4], fQtr[4];
+  real fXr[4], fPr[4];
   if constexpr (kFragRes >= 1) {
     const real* FG0r = static_cast<const real*>(A.fragG) + (size_t)__builtin_amdgcn_readfirstlane(wave) * MT * 2 * 4 * 64;
-    const real* FQ0r = static_cast<const real*>(A.fragQ);
 #pragma unroll
     for (int s_ = 0; s_ < 4; ++s_) {
-      fXr[s_] = FG0r[(1 * 4 + s_) * 64 + lane]; fQr[s_] = FQ0r[(1 * 4 + s_) * 64 + lane];
-      if constexpr (kFragRes >= 2) { fPr[s_] = FG0r[(0 * 4 + s_) * 64 + lane]; fQtr[s_] = FQ0r[(0 * 4 + s_) * 64 + lane]; }
+      fXr[s_] = FG0r[(1 * 4 + s_) * 64 + lane];
+      if constexpr (kFragRes >= 2) fPr[s_] = FG0r[(0 * 4 + s_) * 64 + lane];
     }
   }
   while (!done) {
@@ -930,7 +932,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) acc = M::mma(kFragRes >= 2 ? fQtr[s] : (MT == 1 ? FQs[(0 * 4 + s) * 64 + lane] : FQ[(((mo * MT + mi) * 2 + 0) * 4 + s) * 64 + lane]), rho * z2[mi][c][s] - y2[mi][c][s], acc);
+          for (int s = 0; s < 4; ++s) acc = M::mma(MT == 1 ? FQs[(0 * 4 + s) * 64 + lane] : FQ[(((mo * MT + mi) * 2 + 0) * 4 + s) * 64 + lane], rho * z2[mi][c][s] - y2[mi][c][s], acc);
         wh[mo][c] = acc;
       }
     }
@@ -994,7 +996,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) zt = M::mma(kFragRes >= 1 ? fQr[s] : (kFragPre ? fQp[s] : (MT == 1 ? FQs[(1 * 4 + s) * 64 + lane] : FQ[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane])), hh[mi][c][s], zt);
+          for (int s = 0; s < 4; ++s) zt = M::mma(MT == 1 ? FQs[(1 * 4 + s) * 64 + lane] : (kFragPre ? fQp[s] : FQ[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane]), hh[mi][c][s], zt);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           gx[mo][c][r] = alpha * zt[r] + ((real)1 - alpha) * gx[mo][c][r];
