@@ -1043,14 +1043,14 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
         if (gi < AMX && gi == gj) ae = ((aa_valid >> gi) & 1u) ? ae + eta : 1.0;
 #pragma unroll
         for (int k = 0; k < AMX; ++k) {
-          const real piv = __shfl(ae, 9 * k);
+          const real piv = lane_value(ae, 9 * k);
           const real rk = __shfl(ae, 8 * k + gj);
           const real ck = __shfl(ae, 8 * gi + k);
           const real rs = rk / piv;
           ae = gi == k ? rs : ae - ck * rs;
         }
 #pragma unroll
-        for (int j = 0; j < AMX; ++j) gam[j] = __shfl(ae, 8 * j + AMX);
+        for (int j = 0; j < AMX; ++j) gam[j] = lane_value(ae, 8 * j + AMX);
         aa_was = true;
       }
       // u = g - sum_j gamma_j dG_j for the four registers at uo; stored as the new u

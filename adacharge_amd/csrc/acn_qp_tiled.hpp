@@ -154,6 +154,12 @@ __device__ inline double scalar_const(double v) {
   asm volatile("" : "+s"(lo), "+s"(hi));
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+// The value lane `src` holds (src uniform), as a scalar: v_readlane instead of the LDS crossbar a __shfl goes through
+__device__ inline double lane_value(double v, int src) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)b, src), hi = __builtin_amdgcn_readlane((unsigned)(b >> 32), src);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ inline float uniform_scalar(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(unsigned, v))); }
 
 // 1 / sqrt(x): hardware estimate + two Newton steps (full precision for f64, cheaper than sqrt + div)
@@ -1163,7 +1169,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           if (gi < AMX && gi == gj) ae = ((aa_valid >> gi) & 1u) ? ae + eta : (real)1;
 #pragma unroll
           for (int k = 0; k < AMX; ++k) {
-            const real piv = __shfl(ae, 9 * k);
+            const real piv = lane_value(ae, 9 * k);
             const real rk = __shfl(ae, 8 * k + gj);
             const real ck = __shfl(ae, 8 * gi + k);
             const real rs = rk * rcp_nr(piv);
@@ -1171,7 +1177,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           }
           real gam[AMX];
 #pragma unroll
-          for (int j = 0; j < AMX; ++j) gam[j] = __shfl(ae, 8 * j + AMX);
+          for (int j = 0; j < AMX; ++j) gam[j] = lane_value(ae, 8 * j + AMX);
           STAMP(11);   // event: LDL' solve
           real cor1[CT][4], cor2[MT][CT][4];
 #pragma unroll
