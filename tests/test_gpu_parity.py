@@ -1003,6 +1003,39 @@ def test_certified_infeasible_problems_are_infeasible_for_highs():
     h.close()
 
 
+def test_launch_order_does_not_change_results(tmp_path):
+    """launches of >= 768 problems map workgroups to problems longest-expected first.  The same
+    batch solved in a child process with ACNQP_NO_ORDER=1 (workgroup b solves problem b) returns the same bits."""
+    import subprocess
+    import sys
+
+    infra, iface = H.caltech_interface()
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
+    batch = build_batch(sites.snapshot_batch(infra, 12, 1024, seed=4242), infra, iface, obj, "SOC")
+    h = SiteHandle(batch.site, 0)
+    res = h.solve(batch, default_options())
+    h.close()
+    out = tmp_path / "natural.npz"
+    script = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from tests import helpers as H\n"
+        "from adacharge_amd import ObjectiveComponent, equal_share, quick_charge, sites\n"
+        "from adacharge_amd.backend import SiteHandle, default_options\n"
+        "from adacharge_amd.builder import build_batch\n"
+        "infra, iface = H.caltech_interface()\n"
+        "obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]\n"
+        "batch = build_batch(sites.snapshot_batch(infra, 12, 1024, seed=4242), infra, iface, obj, 'SOC')\n"
+        "r = SiteHandle(batch.site, 0).solve(batch, default_options())\n"
+        "np.savez(%r, x=r.x, iters=r.iters, status=r.status)\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(out)))
+    env = dict(os.environ, ACNQP_NO_ORDER="1")
+    subprocess.run([sys.executable, "-c", script], check=True, env=env, timeout=300)
+    nat = np.load(out)
+    assert (res.status == 1).all()
+    assert np.array_equal(nat["status"], res.status) and np.array_equal(nat["iters"], res.iters)
+    assert np.array_equal(nat["x"], res.x)
+    assert len(np.unique((batch.s_len > 0).sum(axis=(1, 2)))) > 8   # the sort keys do differ: the order is not the identity
+
+
 def test_large_site_kernel_certificates_agree_with_highs():
     """The same cross-check on the large-site kernel (128 EVSE, horizon 30, LINEAR rows, equality energy rows: about half
     of the random instances cannot be served): what the device certifies infeasible is infeasible for scipy-HiGHS on the
