@@ -1177,7 +1177,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           }
           real gam[AMX];
 #pragma unroll
-          for (int j = 0; j < AMX; ++j) gam[j] = lane_value(ae, 8 * j + AMX);
+          for (int j = 0; j < AMX; ++j) gam[j] = __shfl(ae, 8 * j + AMX);
           STAMP(11);   // event: LDL' solve
           real cor1[CT][4], cor2[MT][CT][4];
 #pragma unroll
