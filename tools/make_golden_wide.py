@@ -42,6 +42,8 @@ CASES = [
     # round 3: a wide site at horizon 48 (large-site kernel with Anderson acceleration), congested (demand_scale 0.6
     # against limits at 35 % of the full load), minimum rates on 30 % of the sessions: 9,216 variables, ~1 min of IPM
     ("wide192_t48_soc", "wide192", 48, "SOC",   False, False, True,  "none",   1e-3, 2192),
+    # BASELINE.json configs[4]'s own shape: the synthetic 512-EVSE site at horizon 48 (24,576 variables), congested
+    ("synth512_t48_soc", "synth512", 48, "SOC", False, False, False, "none",   1e-3, 2512),
 ]
 
 
@@ -62,7 +64,7 @@ def main():
             sl = sites.offline_day(infra, rng, horizon=T)
         else:
             sl = sites.random_sessions_general(infra, T, rng, two, mins,
-                                               demand_scale=0.6 if site_name == "wide192" else (0.5 if eq else 1.5))
+                                               demand_scale=0.6 if site_name in ("wide192", "synth512") else (0.5 if eq else 1.5))
         Tb = max(s.arrival_offset + s.remaining_time for s in sl)
         full = 32.0 * len(sl)
         peak = None
