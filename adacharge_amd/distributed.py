@@ -91,29 +91,38 @@ def solve_sites_sharded(site_batches, solve_site: Callable = None, options=None,
     t_max = max(b.Tm for b in site_batches)
     handles = {}
 
-    def hip_site(k, sub):
+    def hip_launch(k, sub):
+        """Upload site k's problems and launch its solve on a stream of its own; returns the device batch (results valid
+        after the device has been synchronised)."""
         from .backend import DeviceBatch, SiteHandle, default_options
 
         if k not in handles:
-            handles[k] = SiteHandle(sub.site, local_device)
-        dev = DeviceBatch(sub, torch.device("cuda", local_device))
-        handles[k].solve_device(dev, options if options is not None else default_options(),
-                                stream=torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
-        return dev.x, dev.status
-
-    solve_site = solve_site or hip_site
+            handles[k] = (SiteHandle(sub.site, local_device), torch.cuda.Stream(device=local_device))
+        h, stream = handles[k]
+        dev = DeviceBatch(sub, torch.device("cuda", local_device))        # copies on the current stream
+        stream.wait_stream(torch.cuda.current_stream(local_device))
+        h.solve_device(dev, options if options is not None else default_options(), stream=stream.cuda_stream)
+        return dev
 
     def solve_local(lo, hi):
-        xs, ss = [], []
+        # A rank that owns several sites launches them ALL before it waits (one stream per site): the sites' kernels
+        # share the GPU, so the rank ends with its slowest site instead of the sum -- on the one-GPU rehearsal of
+        # configs[3] the congested site's stragglers (65 ms for 1,024 scenarios) hide the other seven sites entirely.
+        parts = []
         for k, b in enumerate(site_batches):
             a, e = max(lo, int(off[k])), min(hi, int(off[k + 1]))
             if a >= e:
                 continue
-            x, st = solve_site(k, b.subset(slice(a - int(off[k]), e - int(off[k]))))
+            sub = b.subset(slice(a - int(off[k]), e - int(off[k])))
+            parts.append((e - a, hip_launch(k, sub) if solve_site is None else solve_site(k, sub)))
+        if solve_site is None and parts:
+            torch.cuda.synchronize(local_device)
+        xs, ss = [], []
+        for n, res in parts:
+            x, st = (res.x, res.status) if solve_site is None else res
             x = x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x))
             st = st if torch.is_tensor(st) else torch.from_numpy(np.ascontiguousarray(st))
-            pad = torch.zeros((e - a, n_max, t_max), dtype=torch.float64, device=x.device)
+            pad = torch.zeros((n, n_max, t_max), dtype=torch.float64, device=x.device)
             pad[:, : x.shape[1], : x.shape[2]] = x
             xs.append(pad)
             ss.append(st.to(torch.int32))
@@ -124,5 +133,5 @@ def solve_sites_sharded(site_batches, solve_site: Callable = None, options=None,
     try:
         return solve_sharded(int(off[-1]), solve_local, group=group, device=device)
     finally:
-        for h in handles.values():
+        for h, _ in handles.values():
             h.close()
