@@ -44,6 +44,9 @@ CASES = [
     ("wide192_t48_soc", "wide192", 48, "SOC",   False, False, True,  "none",   1e-3, 2192),
     # BASELINE.json configs[4]'s own shape: the synthetic 512-EVSE site at horizon 48 (24,576 variables), congested
     ("synth512_t48_soc", "synth512", 48, "SOC", False, False, False, "none",   1e-3, 2512),
+    # the reference's stress shape (t_aco.py:286-313: 54 EVSE x 144 periods) with a strictly convex objective, so that the
+    # per-EVSE schedule is pinned (KAT-4 pins only the aggregate of the LP): long-horizon kernel, r0 / zh in LDS
+    ("stress144_soc", "caltech54", 144, "SOC", False, False, True,  "none",   1e-3, 2144),
 ]
 
 
