@@ -127,6 +127,7 @@ EXPORTED_SYMBOLS = (
     "acnqp_last_kernel_ms",
     "acnqp_accel_columns",
     "acnqp_kernel_times",
+    "acnqp_ordered_launch_count",
     "acnqp_solve_batches",
     "acnqp_host_alloc",
     "acnqp_host_free",
@@ -192,6 +193,8 @@ def load_library():
     lib.acnqp_host_free.restype = None
     lib.acnqp_launch_count.argtypes = [C.c_void_p]
     lib.acnqp_launch_count.restype = C.c_int64
+    lib.acnqp_ordered_launch_count.argtypes = [C.c_void_p]
+    lib.acnqp_ordered_launch_count.restype = C.c_int64
     _lib = lib
     return lib
 
@@ -438,6 +441,10 @@ class SiteHandle:
             return float("nan")
         self._launches_seen = before
         return float(sum(ms))
+
+    def ordered_launches(self) -> int:
+        """Launches of this handle whose queue order was sorted by session count (acnqp_ordered_launch_count)."""
+        return int(self._lib.acnqp_ordered_launch_count(self._h))
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.acnqp_last_kernel_ms(self._h))

@@ -65,7 +65,8 @@ def build_hip_library(force: bool = False, verbose: bool = True, extra_flags=(),
     """Compile stale translation units (in parallel) and link.  ``extra_flags`` / ``out``: diagnostic builds
     (e.g. ``-DACNQP_STAMPS``) into another file, always from scratch.  ``check_hazards``: disassemble the linked
     library and refuse it if a >64-bit buffer store is followed by a VALU write of its data registers (the gfx950
-    store-data hazard the compiler does not cover, adacharge_amd/store_hazard.py)."""
+    store-data hazard the compiler does not cover, adacharge_amd/store_hazard.py); a build whose scanner is missing
+    FAILS unless ACNQP_SKIP_HAZARD_SCAN=1; the outcome is written next to the library (``*.hazard_scan.json``)."""
     diagnostic = bool(extra_flags) or out != LIB
     if not force and not diagnostic and up_to_date():
         return LIB
@@ -101,11 +102,18 @@ def build_hip_library(force: bool = False, verbose: bool = True, extra_flags=(),
             sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
             import store_hazard
 
+        if os.environ.get("ACNQP_SKIP_HAZARD_SCAN") == "1":
+            print("[build] WARNING: store-data hazard scan skipped (ACNQP_SKIP_HAZARD_SCAN=1)", flush=True)
+            store_hazard.write_stamp(out, "skipped")
+            return out
         try:
             stores, found = store_hazard.scan_library(out)
         except store_hazard.ScannerUnavailable as e:
-            print(f"[build] WARNING: store-data hazard scan skipped ({e})", flush=True)
-            return out
+            os.replace(out, out + ".rejected")
+            raise RuntimeError(f"store-data hazard scan cannot run ({e}); the scan is the only protection against the gfx950 "
+                               f"buffer-store hazard of DESIGN.md section 3.6 -- set ACNQP_SKIP_HAZARD_SCAN=1 to build "
+                               f"without it; library kept as {out}.rejected") from e
+        store_hazard.write_stamp(out, "scanned", stores, len(found))
         if verbose:
             print(f"[build] store-data hazard scan: {stores} buffer stores of more than 64 bits, {len(found)} unguarded", flush=True)
         if found:

@@ -119,21 +119,34 @@ struct acnqp_handle {
   static constexpr int kEvRing = 64;               // event pairs of the most recent launches
   hipEvent_t ev_start[kEvRing] = {}, ev_stop[kEvRing] = {};
   long long launches = 0, reported = 0;           // launches recorded / already handed out by acnqp_kernel_times
+  long long ordered_launches = 0;                 // launches whose queue order was sorted by session count (acnqp_ordered_launch_count)
   // host-buffer entry points: kSlots pipeline slots, each with its own stream and device staging, so that the
   // H2D copies, the kernel and the D2H copies of successive chunks of a call overlap
   static constexpr int kSlots = 4;
   struct Slot { hipStream_t st = nullptr; DevBuf in, out; } slot[kSlots];
-  // workspaces of the general-shape kernel, one per launch stream: launches on different streams never share
-  // (or regrow) each other's state, and a stream's own launches are ordered by the stream
-  struct Work { hipStream_t st; DevBuf buf; DevBuf ord; long long used; };   // workspace; launch order (keys, then order)
+  // per launch stream: the kernel workspace (long-horizon, large-site, general-shape kernels) and the launch's small
+  // scheduling buffer (queue counter, then sort keys and queue order).  Launches on different streams never share (or
+  // regrow) each other's state, and a stream's own launches are ordered by the stream.
+  struct Work { hipStream_t st; DevBuf buf; DevBuf ord; long long used; hipEvent_t last; };
   std::vector<Work> work;
   long long work_clock = 0;
-  static constexpr size_t kMaxCallerWorkspaces = 4;   // beyond the handle's own kSlots streams
+  // streams of the CALLER (acnqp_solve_batch_device) beyond the handle's own kSlots: a caller that round-robins one
+  // handle over more streams than this pays an event wait + free / malloc per call; 0 < env
+  // ACNQP_CALLER_STREAMS <= 256 overrides
+  static size_t max_caller_workspaces() {
+    static const size_t v = [] {
+      const char* e = std::getenv("ACNQP_CALLER_STREAMS");
+      const long n = e ? std::atol(e) : 0;
+      return (size_t)(n > 0 && n <= 256 ? n : 16);
+    }();
+    return v;
+  }
   DevBuf* workspace_for(hipStream_t st) { return &work_for(st)->buf; }
   Work* work_for(hipStream_t st) {
     for (auto& w : work) if (w.st == st) { w.used = ++work_clock; return &w; }
     // a caller that keeps creating streams must not grow the handle without bound: evict the least recently used
-    // workspace of a caller stream (after the device has drained: that stream may be gone)
+    // entry of a caller stream -- after ITS last launch has finished (the event recorded behind it: that stream may be
+    // gone by now), not after the whole device has drained
     bool own = false;
     for (auto& sl : slot) own = own || sl.st == st;
     if (!own) {
@@ -145,16 +158,27 @@ struct acnqp_handle {
         ++callers;
         if (lru == work.size() || work[k].used < work[lru].used) lru = k;
       }
-      if (callers >= kMaxCallerWorkspaces) {
-        (void)hipDeviceSynchronize();
+      if (callers >= max_caller_workspaces()) {
+        if (work[lru].last) { (void)hipEventSynchronize(work[lru].last); (void)hipEventDestroy(work[lru].last); }
         work[lru].buf.release();
         work[lru].ord.release();
         work.erase(work.begin() + (long)lru);
       }
     }
-    work.push_back(Work{st, DevBuf(), DevBuf(), ++work_clock});
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    work.push_back(Work{st, DevBuf(), DevBuf(), ++work_clock, ev});
     return &work.back();
   }
+  void release_work() {
+    for (auto& w : work) {
+      if (w.last) (void)hipEventDestroy(w.last);
+      w.buf.release();
+      w.ord.release();
+    }
+    work.clear();
+  }
+  int cus = 0;   // compute units of the device (the work-queue launches size their grid from it)
 };
 
 namespace {
@@ -429,6 +453,7 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
   h->has_max = site->has_max ? 1 : 0;
   h->NW = 4;
   h->NP = N <= 64 ? 64 : 16 * ((N + 15) / 16);
+  if (hipDeviceGetAttribute(&h->cus, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || h->cus < 1) h->cus = 256;
   h->G.assign(site->G, site->G + (size_t)Mg * N);
   h->limits.assign(site->limits, site->limits + M);
   hipError_t e = hipSuccess;
@@ -462,7 +487,7 @@ void acnqp_destroy(acnqp_handle* h) {
     sl.in.release();
     sl.out.release();
   }
-  for (auto& w : h->work) w.buf.release();
+  h->release_work();
   delete h;
 }
 
@@ -529,20 +554,41 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.retry_rho = o->retry_rho; a.inacc_floor = o->inaccurate_floor;
   a.pbuf_single = 0;
   a.order = nullptr;
-  static const bool no_order = std::getenv("ACNQP_NO_ORDER") != nullptr;   // diagnostic: workgroup b solves problem b
-  // (only for separable objectives: with a load-flattening or demand-charge row the coupling, not the number of
-  //  sessions, sets the iteration count -- on the configs[4] leg the order by sessions was 10 % SLOWER than the natural one)
-  if (p->batch >= kOrderMinBatch && !no_order && !h->has_flat && !h->has_max) {
-    acnqp_handle::Work* w = h->work_for(st);
-    const size_t need = (size_t)p->batch * 2 * sizeof(int32_t);
-    if (need > w->ord.cap) HIP_TRY(hipStreamSynchronize(st));   // an earlier launch on this stream may still read the old one
-    HIP_TRY(w->ord.reserve(need));
-    int32_t* keys = static_cast<int32_t*>(w->ord.p);
-    int32_t* order = keys + p->batch;
-    hipLaunchKernelGGL(order_keys_kernel, dim3((p->batch + 3) / 4), dim3(256), 0, st, p->s_len, p->k_sessions * h->N, p->batch, keys);
-    hipLaunchKernelGGL(order_sort_kernel, dim3(1), dim3(kOrderKeys), 0, st, keys, p->batch, order);
-    a.order = order;
+  a.queue = nullptr;
+  (void)hipGetLastError();   // drop any stale error so the checks below report this launch only
+  // a problem whose workgroup never ran must not look solved (or carry the previous call's status)
+  HIP_TRY(hipMemsetAsync(r->status, 0, (size_t)p->batch * sizeof(int32_t), st));
+  // the launch's duration (acnqp_kernel_times, bench.py's roofline) covers everything the launch puts on the stream:
+  // the two order kernels below as well as the solver kernel (they used to sit in front of the start event)
+  const int evk = (int)(h->launches % acnqp_handle::kEvRing);
+  HIP_TRY(hipEventRecord(h->ev_start[evk], st));
+  static const bool no_order = std::getenv("ACNQP_NO_ORDER") != nullptr;   // diagnostic: queue position b = problem b
+  static const bool no_queue = std::getenv("ACNQP_NO_QUEUE") != nullptr;   // diagnostic: the static schedule (workgroup w = position w)
+  // (the order by sessions only for separable objectives: with a load-flattening or demand-charge row the coupling, not
+  //  the number of sessions, sets the iteration count -- on the configs[4] leg it was 10 % SLOWER than the natural one)
+  const bool want_order = p->batch >= kOrderMinBatch && !no_order && !h->has_flat && !h->has_max;
+  acnqp_handle::Work* wk = h->work_for(st);
+  if (!no_queue || want_order) {
+    // scheduling buffer of this stream: [0] the queue counter (its own 256-byte line), then keys[B], order[B]
+    const size_t need = 256 + (want_order ? (size_t)p->batch * 2 * sizeof(int32_t) : 0);
+    if (need > wk->ord.cap) HIP_TRY(hipStreamSynchronize(st));   // an earlier launch on this stream may still read the old one
+    HIP_TRY(wk->ord.reserve(need));
+    if (!no_queue) {
+      a.queue = static_cast<int32_t*>(wk->ord.p);
+      HIP_TRY(hipMemsetAsync(a.queue, 0, sizeof(int32_t), st));
+    }
+    if (want_order) {
+      int32_t* keys = static_cast<int32_t*>(wk->ord.p) + 64;
+      int32_t* order = keys + p->batch;
+      hipLaunchKernelGGL(order_keys_kernel, dim3((p->batch + 3) / 4), dim3(256), 0, st, p->s_len, p->k_sessions * h->N, p->batch, keys);
+      hipLaunchKernelGGL(order_sort_kernel, dim3(1), dim3(kOrderKeys), 0, st, keys, p->batch, order);
+      a.order = order;
+      h->ordered_launches++;
+    }
   }
+  // workgroups of a work-queue launch that get a workspace of their own (the kernels that stream their state): at most
+  // two resident workgroups per CU (no streaming kernel has more); the launchers cap their grid at it
+  a.grid_cap = a.queue ? std::min(p->batch, 2 * h->cus) : p->batch;
   const bool tiled = tiled_shape(h, p->t_max, p->k_sessions);
   const bool stream = !tiled && stream_shape(h, p->t_max);
   const bool lng = long_shape(h, p->t_max, p->k_sessions);
@@ -553,8 +599,8 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     const int CT = (p->t_max + 15) / 16;
     a.accel_mem = std::min(a.accel_mem, acnqp::kStreamAccelMax);
     sa.ws_per_problem = acnqp::stream_workspace(h->NP, CT, p->k_sessions, d->MR / 16, a.accel_mem);
-    DevBuf* wsb = h->workspace_for(st);
-    const size_t need = (size_t)sa.ws_per_problem * p->batch * sizeof(double);
+    DevBuf* wsb = &wk->buf;
+    const size_t need = (size_t)sa.ws_per_problem * a.grid_cap * sizeof(double);
     if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(wsb->reserve(need));
     sa.work = static_cast<double*>(wsb->p);
@@ -563,8 +609,8 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     // long-horizon kernel: same workspace idea, one more array (r0 / zh)
     a.accel_mem = std::min(a.accel_mem, acnqp::kLongAccelMax);
     sa.ws_per_problem = acnqp::long_workspace(h->NP, acnqp::long_tiles(p->t_max), p->k_sessions, d->MR / 16, a.accel_mem);
-    DevBuf* wsb = h->workspace_for(st);
-    const size_t need = (size_t)sa.ws_per_problem * p->batch * sizeof(double);
+    DevBuf* wsb = &wk->buf;
+    const size_t need = (size_t)sa.ws_per_problem * a.grid_cap * sizeof(double);
     if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(wsb->reserve(need));
     sa.work = static_cast<double*>(wsb->p);
@@ -573,19 +619,14 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     // general-shape fallback: state streamed through a global workspace (not graph-capturable: it may allocate)
     const size_t rsz = 8;
     ga.ws_per_problem = workspace_doubles(h, p->t_max, p->k_sessions, a.accel_mem);
-    DevBuf* wsb = h->workspace_for(st);
-    const size_t need = (size_t)ga.ws_per_problem * p->batch * rsz;
+    DevBuf* wsb = &wk->buf;
+    const size_t need = (size_t)ga.ws_per_problem * a.grid_cap * rsz;
     if (need > wsb->cap) HIP_TRY(hipStreamSynchronize(st));   // an earlier launch on this stream may still use the old buffer
     HIP_TRY(wsb->reserve(need));
     ga.work = wsb->p;
     ga.pair_stride = 4;
     ga.t = a;
   }
-  (void)hipGetLastError();   // drop any stale error so the check below reports this launch only
-  // a problem whose workgroup never ran must not look solved (or carry the previous call's status)
-  HIP_TRY(hipMemsetAsync(r->status, 0, (size_t)p->batch * sizeof(int32_t), st));
-  const int evk = (int)(h->launches % acnqp_handle::kEvRing);
-  HIP_TRY(hipEventRecord(h->ev_start[evk], st));
   hipError_t e = hipSuccess;
   if (tiled) {
     e = p->t_max <= 16 ? acnqp::launch_tiled_ct1(a, st) : acnqp::launch_tiled_ct2(a, st);
@@ -601,6 +642,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   }
   if (e != hipSuccess) return fail(ACNQP_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   HIP_TRY(hipEventRecord(h->ev_stop[evk], st));
+  if (wk->last) HIP_TRY(hipEventRecord(wk->last, st));   // what an eviction of this stream's buffers waits for
   ++h->launches;
   return ACNQP_OK;
 }
@@ -641,6 +683,7 @@ static float event_pair_ms(acnqp_handle* h, long long launch) {
 }
 
 int64_t acnqp_launch_count(acnqp_handle* h) { return h ? (int64_t)h->launches : 0; }
+int64_t acnqp_ordered_launch_count(acnqp_handle* h) { return h ? (int64_t)h->ordered_launches : 0; }
 
 #ifdef ACNQP_DEBUG_WS
 // diagnostic builds only (tools/gpu_long_race.py): the most recently used kernel workspace, copied to the host
@@ -712,9 +755,8 @@ struct ChunkLayout {
   }
 };
 
-// per_problem_bytes: inputs + results staged per problem AND the kernel's per-problem workspace (the long-horizon and
-// large-site kernels keep their iterates there: 1.6 MB per problem at 54 x 144, far more than the inputs) -- every one
-// of the kSlots pipeline slots holds a chunk of each, so a chunk is capped at 1 GiB of the sum
+// per_problem_bytes: inputs + results staged per problem -- every one of the kSlots pipeline slots holds a chunk of
+// each, so a chunk is capped at 1 GiB of the sum
 long long chunk_problems(size_t per_problem_bytes, bool on_chip) {
   // problems per launch: large enough that the launch tail (its slowest problems) is short.  The register-resident
   // kernel takes 1,024 (two per workgroup slot): with the launches sorted longest-first (order_sort_kernel) and four
@@ -743,8 +785,8 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
       if (chunks.empty() || (int)Tm != cur_T || (int)K != cur_K || opt != cur_opt || fill >= cap) {
         chunks.emplace_back();
         cur_T = (int)Tm; cur_K = (int)K; cur_opt = opt; fill = 0;
-        cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96 +
-                             (size_t)workspace_doubles(h, (int)Tm, (int)K, o->accel_mem) * 8, tiled_shape(h, (int)Tm, (int)K));
+        // (the kernels' workspaces belong to the resident workgroup slots since the work queue: no per-problem term)
+        cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K));
         // ramp: the first kernel cannot start before its chunk's H2D has landed, and nothing overlaps that copy -- a
         // quarter-size first chunk (then a half-size one) shortens the exposed head of the pipeline
         static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;

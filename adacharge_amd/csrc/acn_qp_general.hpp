@@ -55,15 +55,18 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   // acn_qp_tiled.hpp).  The WHOLE body is the pass, with the thread / block ids opaque and the argument block read
   // through a per-pass opaque pointer to the kernarg segment: nothing of a pass is invariant across passes, so no
   // pass-invariant address, predicate or argument is kept alive across the solver loop.
+  __shared__ int q_slot;
+  for (int q_round = 0;; ++q_round) {   // work queue: this workgroup's next problem (queue_next, acn_qp_tiled.hpp)
+  const int q_pos = queue_next(SA_kernarg.t.queue, SA_kernarg.t.B, q_round, &q_slot);
+  if (q_pos < 0) break;
   int it_total = 0, best_status = 0;
   for (int pass = 0;; ++pass) {
   typedef const __attribute__((address_space(4))) GeneralArgs* KernargP;
   KernargP SAp = (KernargP)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(SAp));
   const auto& GA = *SAp;
-  (void)SA_kernarg;
   const auto& A = GA.t;
-  int b_ = blockIdx.x, tid = threadIdx.x;
+  int b_ = q_pos, tid = threadIdx.x;
   asm volatile("" : "+v"(b_));
   asm volatile("" : "+v"(tid));
   const int wg_ = __builtin_amdgcn_readfirstlane(b_);
@@ -72,7 +75,8 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   const int adapt_p = pass == 0 ? A.adapt_every : 0;
   const int N = A.N, T = A.Tm, NP = A.NP, MR = A.MR, K = A.K;
   const int n = N * T, mt = MR * T;
-  real* W0 = static_cast<real*>(GA.work) + (size_t)b * GA.ws_per_problem;
+  // (the workspace belongs to the workgroup slot when the launch runs off the queue: acn_qp_stream.hpp)
+  real* W0 = static_cast<real*>(GA.work) + (size_t)(A.queue ? (int)blockIdx.x : b) * GA.ws_per_problem;
   real *x = W0, *z1 = x + n, *y1 = z1 + n, *r0 = y1 + n, *zh = r0 + n, *ub = zh + n;
   real *z2 = ub + n, *y2 = z2 + mt, *gx = y2 + mt, *w = gx + mt, *eh = w + mt, *hh = eh + mt, *zh2 = hh + mt;
   real* mu = zh2 + mt;             // [K*N]
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
     if (A.y_out)
       for (int k = tid; k < A.Mg * T; k += kGenThreads) A.y_out[(size_t)b * A.Mg * T + k] = 0;
     if (tid == 0) { A.status[b] = 4; A.iters[b] = 0; A.pri[b] = (double)M::big; A.dua[b] = (double)M::big; A.obj[b] = 0; }
-    return;
+    break;   // (block-uniform) out of the pass loop: the next problem of the queue
   }
   const real sigma = (real)A.sigma, alpha = (real)A.alpha;
   real rho = (real)A.rho0;
@@ -592,6 +596,7 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   if (!retry_wanted(pass, A.retry_passes, status, it, A.stall_iters, A.adapt_every)) break;
   __syncthreads();
   }   // passes
+  }   // work queue
 }
 
 }  // namespace acnqp

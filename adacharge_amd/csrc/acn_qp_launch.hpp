@@ -37,6 +37,18 @@ inline int accel_capacity_best(int NW, int MT, int CT, int NP, int K, int* pbuf_
   return std::max(one, two);
 }
 
+// Grid of a launch.  With the work queue (a.queue set) it is the number of workgroups the chip keeps RESIDENT for this
+// kernel -- occupancy x compute units, never more than the problems or than `a.grid_cap` -- and the workgroups fetch
+// problems until the queue is empty (queue_next, acn_qp_tiled.hpp); without it one workgroup per problem.
+template <typename Kern>
+inline int launch_grid(Kern kern, int threads, size_t lds, const TiledArgs& a) {
+  if (!a.queue) return a.B;
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  return std::max(1, std::min(std::min(a.B, a.grid_cap > 0 ? a.grid_cap : a.B), per_cu * cus));
+}
+
 // register-resident kernel (acn_qp_tiled.hpp): N <= 64, one / two column tiles; a.accel_mem = columns requested
 hipError_t launch_tiled_ct1(const TiledArgs& a, hipStream_t st);
 hipError_t launch_tiled_ct2(const TiledArgs& a, hipStream_t st);

@@ -18,7 +18,7 @@ static hipError_t launch_long_one(const StreamArgs& sa, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
+  hipLaunchKernelGGL(kern, dim3(launch_grid(kern, NWV * 64, lds, sa.t)), dim3(NWV * 64), lds, st, sa);
   return hipGetLastError();
 }
 
@@ -31,7 +31,7 @@ static hipError_t launch_long_rzl(const StreamArgs& sa, hipStream_t st) {
   auto kern = &admm_long_kernel<CTL, MT, NWV, false, true>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
+  hipLaunchKernelGGL(kern, dim3(launch_grid(kern, NWV * 64, lds, sa.t)), dim3(NWV * 64), lds, st, sa);
   return hipGetLastError();
 }
 // ... and x as well (horizons up to 96: 2 x 48 KB next to e^, h^)
@@ -43,7 +43,7 @@ static hipError_t launch_long_xsl(const StreamArgs& sa, hipStream_t st) {
   auto kern = &admm_long_kernel<CTL, MT, NWV, false, true, true>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
+  hipLaunchKernelGGL(kern, dim3(launch_grid(kern, NWV * 64, lds, sa.t)), dim3(NWV * 64), lds, st, sa);
   return hipGetLastError();
 }
 static bool xsl_fits(int CTL, int MT, int NP) {
@@ -63,7 +63,7 @@ static hipError_t launch_long_lds(const StreamArgs& sa, hipStream_t st) {
   auto kern = &admm_long_kernel<CTL, MT, NWV, true>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3(sa.t.B), dim3(NWV * 64), lds, st, sa);
+  hipLaunchKernelGGL(kern, dim3(launch_grid(kern, NWV * 64, lds, sa.t)), dim3(NWV * 64), lds, st, sa);
   return hipGetLastError();
 }
 

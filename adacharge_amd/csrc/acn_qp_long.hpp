@@ -96,24 +96,27 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   // passes: pass 0 as the options state it, then cold fixed-penalty retries of a stalled problem (retry_wanted,
   // acn_qp_tiled.hpp).  The WHOLE body is the pass, with the argument block read through a per-pass opaque pointer to
   // the kernarg segment: no argument is kept alive across the solver loop for the next pass's sake.
+  __shared__ int q_slot;
+  for (int q_round = 0;; ++q_round) {   // work queue: this workgroup's next problem (queue_next, acn_qp_tiled.hpp)
+  const int q_pos = queue_next(SA_kernarg.t.queue, SA_kernarg.t.B, q_round, &q_slot);
+  if (q_pos < 0) break;
   int it_total = 0, best_status = 0;
   for (int pass = 0;; ++pass) {
   typedef const __attribute__((address_space(4))) StreamArgs* KernargP;
   KernargP SAp = (KernargP)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(SAp));
   const auto& SA = *SAp;
-  (void)SA_kernarg;
   const auto& A = SA.t;
   // Block id through v_readfirstlane (as in the other kernels): the workspace descriptor and every uniform offset then
   // live in scalar registers -- 26 v_readfirstlane in the 54 x 144 instantiation instead of 1,976, 78 -> 63 ms.  That
   // form exposed a hardware hazard the compiler does not cover (see st2 below), which is why round 2 shipped without it.
 #if !defined(ACNQP_LONG_IDS_OPAQUE) || ACNQP_LONG_IDS_OPAQUE
-  int b_ = blockIdx.x; int tid = threadIdx.x;
+  int b_ = q_pos; int tid = threadIdx.x;
   asm volatile("" : "+v"(b_)); asm volatile("" : "+v"(tid));
   const int wg_ = __builtin_amdgcn_readfirstlane(b_);
   const int b = __builtin_amdgcn_readfirstlane(A.order ? A.order[wg_] : wg_);   // the problem this workgroup solves (a uniform value: the load alone would make it a vector register)
 #else
-  const int b = blockIdx.x, tid = threadIdx.x;   // diagnostic: descriptor in vector registers (round 2's form)
+  const int b = q_pos, tid = threadIdx.x;   // diagnostic: descriptor in vector registers (round 2's form)
 #endif
   const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
   const int adapt_p = pass == 0 ? A.adapt_every : 0;
@@ -126,7 +129,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   const int nct = (Tm + 15) >> 4;         // column tiles that hold periods (<= CTL); the rest is padding, all zero
   const int n_site = MT * nct, n_tile = n_site + NE * nct;   // tile items: site tiles first, then EVSE tiles
   const long long NT = (long long)NE * CTL * 256;
-  real* W0 = SA.work + (size_t)b * SA.ws_per_problem;
+  // (the workspace belongs to the workgroup slot when the launch runs off the queue: acn_qp_stream.hpp)
+  real* W0 = SA.work + (size_t)(A.queue ? (int)blockIdx.x : b) * SA.ws_per_problem;
   const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(W0, 0, (int)(SA.ws_per_problem * 8), 0x00020000);
   const unsigned NT8 = (unsigned)NT * 8u;
   const unsigned MS8 = (unsigned)(MT * CTL * 256) * 8u;
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       if (A.y_out)
         for (size_t k = tid; k < (size_t)A.Mg * Tm; k += NWV * 64) A.y_out[(size_t)b * A.Mg * Tm + k] = 0;
       if (tid == 0) { A.status[b] = 4; A.iters[b] = 0; A.pri[b] = M::big; A.dua[b] = M::big; A.obj[b] = 0; }
-      return;
+      break;   // (block-uniform) out of the pass loop: the next problem of the queue
     }
   }
 
@@ -1231,6 +1235,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   if (!retry_wanted(pass, A.retry_passes, status, it, A.stall_iters, A.adapt_every)) break;
   __syncthreads();
   }   // passes
+  }   // work queue
 }
 
 #undef RELANE

@@ -116,15 +116,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   // acn_qp_tiled.hpp).  The WHOLE body is the pass, with the thread / block ids opaque and the argument block read
   // through a per-pass opaque pointer to the kernarg segment: nothing of a pass is invariant across passes, so no
   // pass-invariant address, predicate or argument is kept alive across the solver loop.
+  __shared__ int q_slot;
+  for (int q_round = 0;; ++q_round) {   // work queue: this workgroup's next problem (queue_next, acn_qp_tiled.hpp)
+  const int q_pos = queue_next(SA_kernarg.t.queue, SA_kernarg.t.B, q_round, &q_slot);
+  if (q_pos < 0) break;
   int it_total = 0, best_status = 0;
   for (int pass = 0;; ++pass) {
   typedef const __attribute__((address_space(4))) StreamArgs* KernargP;
   KernargP SAp = (KernargP)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(SAp));
   const auto& SA = *SAp;
-  (void)SA_kernarg;
   const auto& A = SA.t;
-  int b_ = blockIdx.x, tid = threadIdx.x;
+  int b_ = q_pos, tid = threadIdx.x;
   asm volatile("" : "+v"(b_));
   asm volatile("" : "+v"(tid));
   const int wg_ = __builtin_amdgcn_readfirstlane(b_);
@@ -143,7 +146,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   const int N = A.N, Tm = A.Tm, NP = A.NP, K = A.K;
   const int NE = NP >> 4;                 // EVSE tiles
   const long long NT = (long long)NE * CT * 256;
-  real* W0 = SA.work + (size_t)b * SA.ws_per_problem;
+  // the workspace belongs to the workgroup SLOT, not to the problem, when the launch runs off the queue (every pass
+  // initialises what it reads): grid x ws_per_problem instead of B x ws_per_problem
+  real* W0 = SA.work + (size_t)(A.queue ? (int)blockIdx.x : b) * SA.ws_per_problem;
   real *Xs = W0, *Z1s = Xs + NT, *Y1s = Z1s + NT, *Qs = Y1s + NT, *LBs = Qs + NT, *UBs = LBs + NT;
   real* MU = UBs + NT;                    // [K][NP]
   // site-row state (z2, y2, G x) in tile-fragment order: touched by the owner waves once per iteration, L2-resident
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
       if (A.y_out)
         for (size_t k = tid; k < (size_t)A.Mg * Tm; k += kStreamWaves * 64) A.y_out[(size_t)b * A.Mg * Tm + k] = 0;
       if (tid == 0) { A.status[b] = 4; A.iters[b] = 0; A.pri[b] = M::big; A.dua[b] = M::big; A.obj[b] = 0; }
-      return;
+      break;   // (block-uniform) out of the pass loop: the next problem of the queue
     }
   }
 
@@ -1357,6 +1362,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   if (!retry_wanted(pass, A.retry_passes, status, it, A.stall_iters, A.adapt_every)) break;
   __syncthreads();
   }   // passes
+  }   // work queue
 }
 
 #undef RELANE

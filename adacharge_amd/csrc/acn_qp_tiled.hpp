@@ -65,7 +65,11 @@ struct TiledArgs {
   const void *fragG, *fragQ;                  // Ghat, Q as MFMA A-operand fragments: [NW][MT][2][4][64], [MT][MT][2][4][64]
   const void *fragG2, *fragQ2;                // the same blocks with the k-slices as two pairs per lane: [..][2][64][2] (acn_qp_long.hpp)
   const int32_t* horizon;
-  const int32_t* order;                       // [B] or null: workgroup -> problem (longest expected first, acn_qp_api.hip)
+  const int32_t* order;                       // [B] or null: queue position -> problem (longest expected first, acn_qp_api.hip)
+  int32_t* queue;                             // launch counter (zeroed on the stream before the launch): the grid is the chip's
+                                              // resident workgroup slots and every workgroup fetches its next queue position
+                                              // with one atomicAdd until the B problems are gone (null: workgroup w solves
+                                              // position w -- ACNQP_NO_QUEUE=1, the static schedule)
   const double *lb, *ub, *q, *pdiag;
   const int32_t *s_off, *s_len;
   const double* s_cap;
@@ -90,9 +94,29 @@ struct TiledArgs {
   int stall_iters, retry_passes, retry_max_iter;
   double inacc_floor, retry_rho;
   int pbuf_single; // 1: one partial-tile slab instead of two (one more barrier per iteration, LDS for one more ring column)
+  int grid_cap;    // host side only: most workgroups a launch may have (the kernels that stream their state own one
+                   // workspace per workgroup slot)
 };
 
 typedef const __attribute__((address_space(4))) TiledArgs* KernargPtr;   // the kernel's own argument block
+
+// ---- work queue (all four kernel families) ----------------------------------------------------------------------------
+// A launch of B problems on S resident workgroup slots used to be B workgroups handed out in index order: a slot's
+// share of the work was whatever its problems happened to need, and the launch ended with its slowest slot (configs[4]
+// leg, 2,048 problems on 512 slots: the last slot at ~2,200 iterations, the mean slot at 1,525).  Now the grid is the S
+// slots and a workgroup that finishes a problem takes the next queue position: one atomicAdd by thread 0, broadcast
+// through LDS.  Returns the position (block-uniform, a scalar), or -1 when the launch has no problem left for this
+// workgroup.  `round` counts this workgroup's fetches (the static fallback serves exactly one).  Both barriers are
+// needed: the first publishes the slot, the second keeps a fast wave's next fetch from overwriting it before a slow wave
+// has read it -- and orders the previous problem's last LDS reads before the next problem's first LDS writes.
+__device__ inline int queue_next(int32_t* queue, int B, int round, int* slot_lds) {
+  if (queue == nullptr) return round == 0 && (int)blockIdx.x < B ? (int)blockIdx.x : -1;
+  if (threadIdx.x == 0) *slot_lds = atomicAdd(queue, 1);
+  __syncthreads();
+  const int pos = __builtin_amdgcn_readfirstlane(*slot_lds);
+  __syncthreads();
+  return pos < B ? pos : -1;
+}
 
 template <typename real> struct Mfma;
 template <> struct Mfma<double> {
@@ -353,9 +377,13 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   // plateau is solved again from a cold start with a fixed penalty (retry_wanted, above).  The WHOLE body, loads
   // included, is the pass: with the thread and block ids opaque at the top nothing of a pass is invariant across
   // passes, so the compiler keeps no pass-invariant value (addresses, predicates) alive across the solver loop.
+  __shared__ int q_slot;
+  for (int q_round = 0;; ++q_round) {   // work queue: this workgroup's next problem (queue_next)
+  const int q_pos = queue_next(A_kernarg.queue, A_kernarg.B, q_round, &q_slot);
+  if (q_pos < 0) break;
   int it_total = 0, best_status = 0;
   for (int pass = 0;; ++pass) {
-  int b_ = blockIdx.x;
+  int b_ = q_pos;
   int tid = threadIdx.x;
   asm volatile("" : "+v"(b_));
   asm volatile("" : "+v"(tid));
@@ -547,7 +575,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         A.status[b] = 4; A.iters[b] = 0;
         A.pri[b] = (double)BIGC; A.dua[b] = (double)BIGC; A.obj[b] = 0;
       }
-      return;
+      break;   // (block-uniform) out of the pass loop: the next problem of the queue
     }
   }
 
@@ -1626,6 +1654,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
 #endif
   if (!retry_wanted(pass, A.retry_passes, status, it, A.stall_iters, A.adapt_every)) break;
   }   // passes
+  }   // work queue
 #undef BIGC
 }
 

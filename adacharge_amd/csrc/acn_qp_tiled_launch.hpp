@@ -16,7 +16,7 @@ hipError_t launch_tiled_occ(const TiledArgs& a, hipStream_t st) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(a.B), dim3(NW * 64), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(launch_grid(kern, NW * 64, lds, a)), dim3(NW * 64), lds, st, a);
   return hipGetLastError();
 }
 

@@ -29,46 +29,108 @@ def _vregs(tok):
     return {int(m.group(1))} if m else set()
 
 
+_BRANCH = re.compile(r"^s_(branch|cbranch_\w+)\s+(\S+)")
+
+
+def _parse(text):
+    """[(kind, text, address or None, branch target or None)]: kind "label" (a kernel symbol) or "ins".  Targets are
+    instruction addresses for an llvm-objdump disassembly (``<symbol+0xOFFSET>`` in the comment, resolved with the
+    symbol's own address) and ``.L`` label names for a compiler ``-S`` listing."""
+    out, sym_addr = [], {}
+    for raw in text.splitlines():
+        code, _, comment = raw.partition("//")
+        line = code.split(";")[0].strip()
+        m = re.match(r"^([0-9a-f]+) <(\S+)>:$", line)
+        if m:
+            sym_addr[m.group(2)] = int(m.group(1), 16)
+            out.append(("label", m.group(2), int(m.group(1), 16), None))
+            continue
+        m = re.match(r"^(_Z\w+):$", line)
+        if m:
+            out.append(("label", m.group(1), None, None))
+            continue
+        m = re.match(r"^(\.L\w+):$", line)
+        if m:
+            out.append(("local", m.group(1), None, None))
+            continue
+        if not line or line.startswith(".") or line.endswith(":"):
+            continue
+        addr = None
+        ma = re.match(r"\s*([0-9A-Fa-f]+):", comment)
+        if ma:
+            addr = int(ma.group(1), 16)
+        target = None
+        mb = _BRANCH.match(line)
+        if mb:
+            mt = re.search(r"<([^>+]+)(?:\+0x([0-9a-fA-F]+))?>", comment)
+            if mt and mt.group(1) in sym_addr:
+                target = sym_addr[mt.group(1)] + int(mt.group(2) or "0", 16)
+            elif mb.group(2).startswith(".L"):
+                target = mb.group(2)
+        out.append(("ins", line, addr, target))
+    return out
+
+
 def scan_isa(text):
     """(number of >64-bit buffer stores, [(kernel symbol, store, wait states, overwriting instruction)]) of a disassembly
-    or compiler ``-S`` listing."""
-    ins = []
-    for raw in text.splitlines():
-        line = raw.split("//")[0].split(";")[0].strip()
-        m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line) or re.match(r"^(_Z\w+):$", line)
-        if m:
-            ins.append(("label", m.group(1)))
-        elif line and not line.startswith(".") and not line.endswith(":"):
-            ins.append(("ins", line))
+    or compiler ``-S`` listing.  Every path of ``WAIT_STATES`` wait states behind a store is walked: the fall-through
+    one, and the target of every unconditional or conditional branch met on the way (a store that ends a basic block is
+    followed into both successors)."""
+    ins = _parse(text)
+    where = {}
+    for idx, (kind, l, addr, _) in enumerate(ins):
+        if kind == "ins" and addr is not None:
+            where[addr] = idx
+        elif kind == "local":
+            where[l] = idx
     kern, stores, found = "?", 0, []
-    for idx, (kind, l) in enumerate(ins):
+    for idx, (kind, l, _, _) in enumerate(ins):
         if kind == "label":
             kern = l
             continue
-        if not re.match(r"buffer_store_(dwordx[34]|b(96|128))\b", l):
+        if kind != "ins" or not re.match(r"buffer_store_(dwordx[34]|b(96|128))\b", l):
             continue
         stores += 1
         data = _vregs(l.split(None, 1)[1].split(",")[0].strip())
-        n, j = 0, idx + 1
-        while n < WAIT_STATES and j < len(ins):
-            kind2, t = ins[j]
-            j += 1
-            if kind2 == "label":
-                break
-            if t.startswith("s_nop"):
-                n += int(t.split()[1], 0) + 1
-                continue
-            n += 1
-            if t.startswith("v_") and not t.startswith("v_cmp") and len(t.split(None, 1)) > 1:
-                dst = t.split(None, 1)[1].split(",")[0].strip()
-                if _vregs(dst) & data:
-                    found.append((kern, l, n, t))
+        hit, todo, seen = None, [(idx + 1, 0)], set()
+        while todo and hit is None:
+            j, n = todo.pop()
+            while n < WAIT_STATES and j < len(ins):
+                if (j, n) in seen:
                     break
+                seen.add((j, n))
+                kind2, t, _, target = ins[j]
+                j += 1
+                if kind2 == "label":
+                    break
+                if kind2 == "local":
+                    continue
+                if t.startswith("s_nop"):
+                    n += int(t.split()[1], 0) + 1
+                    continue
+                n += 1
+                if t.startswith("s_endpgm"):
+                    break
+                mb = _BRANCH.match(t)
+                if mb:
+                    if target in where and n < WAIT_STATES:
+                        todo.append((where[target], n))
+                    if mb.group(1) == "branch":
+                        break          # unconditional: no fall-through
+                    continue
+                if t.startswith("v_") and not t.startswith("v_cmp") and len(t.split(None, 1)) > 1:
+                    dst = t.split(None, 1)[1].split(",")[0].strip()
+                    if _vregs(dst) & data:
+                        hit = (kern, l, n, t)
+                        break
+        if hit:
+            found.append(hit)
     return stores, found
 
 
 class ScannerUnavailable(RuntimeError):
-    """llvm-objdump is not where the ROCm image keeps it: the scan cannot run (the build warns and goes on)."""
+    """llvm-objdump is not where the ROCm image keeps it: the scan cannot run.  The build FAILS on this unless
+    ACNQP_SKIP_HAZARD_SCAN=1 is set (the scan is the only protection against the hazard)."""
 
 
 def scan_library(path):
@@ -94,6 +156,39 @@ def scan_library(path):
             stores += s
             found += f
     return stores, found
+
+
+def stamp_path(lib):
+    return lib + ".hazard_scan.json"
+
+
+def write_stamp(lib, state, stores=0, unguarded=0):
+    """Record next to the library what the build's scan saw: {"state": "scanned" | "skipped", ...}; a test asserts the
+    library it loads was scanned with no finding (tests/test_store_hazard.py)."""
+    import json
+
+    with open(stamp_path(lib), "w") as f:
+        json.dump({"state": state, "wide_stores": stores, "unguarded": unguarded, "library_sha256": file_sha256(lib)}, f)
+
+
+def file_sha256(path):
+    import hashlib
+
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def read_stamp(lib):
+    import json
+
+    try:
+        with open(stamp_path(lib)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def describe(found, limit=6):

@@ -181,13 +181,14 @@ def other_workloads():
         "cfg3_site0_T12_b1024": lambda: cfg3_site(0),
         "cfg4_synth512_T48_b2048": cfg4,
         "stress_caltech54_T144_b256": stress144,
-        # not part of the default run (tools/run_config.py stress144-2k): eight workgroups per CU in flight
+        # eight workgroups' worth of problems per CU: the long-horizon kernel's bandwidth-bound regime (in the default
+        # run since round 4, so that its HBM fraction is driver-timed)
         "stress_caltech54_T144_b2048": lambda: stress144(2048),
     }
 
 
 # legs of `other_workloads` the default `python bench.py` run leaves out (profiling targets only)
-NOT_IN_DEFAULT_RUN = ("stress_caltech54_T144_b2048",)
+NOT_IN_DEFAULT_RUN = ()
 
 
 def time_device_launch(batch, opts, dev, reps=2):
@@ -267,30 +268,43 @@ def strict_batch256_leg(handle, batch, opts, calls=40):
             "qps": batch.B / med, "kernel_ms_median": float(np.median(k))}
 
 
-def cpu_baseline_leg(batch, gpu_x, gpu_status, target_seconds, snaps, infra, iface, accel_mem=0):
+def cpu_baseline_leg(batch, gpu_x, gpu_status, target_seconds, snaps, infra, iface, accel_mem=0, first=256):
     """The ONLY place bench.py touches oracle/: the scalar C port of the device ADMM timed on the host cores over a
-    bounded sample, which also serves as the parity check of the sample."""
+    bounded sample, which also serves as the parity check of the sample.
+
+    `batch`: >= 32 problems per thread (256 problems on 128 threads were two problems per thread -- a pass
+    lasted as long as its slowest problem).  Reported: the all-core rate (`value`), the one-thread rate beside it, and
+    scipy-HiGHS's time per solve on the LINEAR statement of the same instances (the only third-party solver in the
+    image; cvxpy / ECOS are not installed)."""
     import numpy as np
 
     from oracle import admm_port
 
     cores = min(admm_port.max_threads(), os.cpu_count() or 1)
-    admm_port.solve_batch(batch, threads=cores, accel_mem=accel_mem)   # warm the thread pool / caches
     t0 = time.perf_counter()
-    out = admm_port.solve_batch(batch, threads=cores, accel_mem=accel_mem)   # one pass: the parity sample
+    out = admm_port.solve_batch(batch, threads=cores, accel_mem=accel_mem)   # one pass: warms the pool, the parity sample
     one_pass = max(time.perf_counter() - t0, 1e-4)
-    reps = int(max(1, min(200, round(target_seconds / one_pass))))
+    reps = int(max(1, min(50, round(target_seconds / one_pass))))
     t0 = time.perf_counter()
-    for _ in range(reps):   # bounded sample of the same workload: the first batch, `reps` times
+    for _ in range(reps):   # bounded sample of the same workload
         admm_port.solve_batch(batch, threads=cores, accel_mem=accel_mem)
     dt = time.perf_counter() - t0
     n = batch.B
+    # one thread: a slice of the same problems, sized to a few seconds
+    n1 = int(max(8, min(n, round(3.0 / max(one_pass * cores / n, 1e-5)))))
+    one = batch.subset(slice(0, n1))
+    t0 = time.perf_counter()
+    admm_port.solve_batch(one, threads=1, accel_mem=accel_mem)
+    dt1 = max(time.perf_counter() - t0, 1e-6)
     ok = (out["status"] == 1) & (gpu_status[:n] == 1)
     dx = float(np.abs(out["x"][ok] - gpu_x[:n][ok]).max()) if ok.any() else float("nan")
     res = {
         "value": n * reps / dt, "unit": "QP solves/s", "cores": int(cores), "kind": "port",
-        "sample": f"the first batch ({batch.B} problems) x {reps} passes = {n * reps} solves, oracle/admm_port.c (scalar C "
-                  f"port of the device ADMM, gcc -O3 -fopenmp, one problem per thread), {dt:.1f} s wall",
+        "one_thread_qps": n1 / dt1, "one_thread_ms_per_solve": 1e3 * dt1 / n1,
+        "problems_per_thread_per_pass": n / cores,
+        "sample": f"{n} problems of the timed workload (the first {n // first} batches) x {reps} passes = {n * reps} solves on "
+                  f"{cores} threads ({n / cores:.0f} problems per thread and pass, dynamic schedule), oracle/admm_port.c (scalar C "
+                  f"port of the device ADMM, gcc -O3 -fopenmp), {dt:.1f} s wall; one thread: {n1} problems in {dt1:.1f} s",
     }
     parity = {"port_sample": n, "max_abs_rate_diff_gpu_vs_port_A": dx,
               "status_mismatches_vs_port": int((out["status"] != gpu_status[:n]).sum())}
@@ -322,6 +336,17 @@ def cpu_baseline_leg(batch, gpu_x, gpu_status, target_seconds, snaps, infra, ifa
         parity["lp_rel_objective_gap_max"] = float(np.max(np.abs(gaps))) if gaps else None
         parity["lp_aggregate_gap_max_A"] = float(np.max(aggs)) if aggs else None
         res["independent_solver_ms_per_solve_1thread"] = 1e3 * float(np.median(th))
+        # scipy-HiGHS on the LINEAR statement of the same snapshots (aco.py:165-172 instead of the SOC rows): what a
+        # compiled third-party LP solver needs per solve on one thread, whatever cone the timed workload uses
+        tl = []
+        for b in range(min(16, len(snaps))):
+            prob = build_reference_problem(snaps[b], infra, iface, [("quick_charge", 1, {})], "LINEAR")
+            t0 = time.perf_counter()
+            solve_lp_highs(prob)
+            tl.append(time.perf_counter() - t0)
+        res["highs_linear_ms_per_solve_1thread"] = 1e3 * float(np.median(tl))
+        res["highs_linear_note"] = ("scipy.optimize.linprog(method='highs') on the LINEAR statement of the first "
+                                    f"{len(tl)} snapshots, median, scipy wrapper included; not the reference's cvxpy / ECOS path")
     except Exception as exc:  # the cross-check is informative, never fatal
         parity["independent_solver_error"] = repr(exc)
     return res, parity
@@ -532,7 +557,9 @@ def main():
             "roofline": {
                 # register / LDS-resident iterative solver: HBM is touched once per problem, so the roof that
                 # can bind is the fp64 arithmetic one (vector = matrix peak on MI355X); the HBM view is reported beside it
-                "bound": "mfma", "achieved": tf_sparse, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                "bound": "mfma", "binding_unit": "valu (fp64: the vector ALU and the matrix cores share the 78.6 TF peak; the kernel's "
+                                                 "instruction count, not its MFMA chains, is what binds: DESIGN.md 3.1)",
+                "achieved": tf_sparse, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tf_sparse / FP64_VALU_PEAK_TF,
                 "traffic": None if traffic is None else traffic / launch_b * per_step,
                 "kernel": "acnqp::admm_tiled_kernel<double, 4, 1, 1, 1, 2, 5>",
@@ -560,8 +587,11 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            cb, parity = cpu_baseline_leg(batch, results[0].x, results[0].status, args.cpu_seconds, snaps0, infra, iface,
-                                          accel_mem=handle.accel_columns(Tm, K, opts))
+            # a CPU sample of >= 32 problems per thread: the first 16 batches (4,096 problems) of the timed workload
+            ncb = max(1, min(G, 4096 // B))
+            cb, parity = cpu_baseline_leg(ProblemBatch.concatenate(batches[:ncb]), np.concatenate([r.x for r in results[:ncb]]),
+                                          np.concatenate([r.status for r in results[:ncb]]), args.cpu_seconds, snaps0, infra, iface,
+                                          accel_mem=handle.accel_columns(Tm, K, opts), first=B)
             out["cpu_baseline"] = cb
             out["parity"] = parity
         if world == 1 and not args.no_other_configs:

@@ -244,6 +244,13 @@ int32_t acnqp_kernel_times(acnqp_handle* h, float* out_ms, int32_t capacity);
  * durations: a caller that sums them can tell from this count whether any were dropped).                    */
 int64_t acnqp_launch_count(acnqp_handle* h);
 
+/* Of those, the launches whose QUEUE ORDER was sorted (longest expected problem first, by session count: launches of
+ * >= 768 problems on sites without a load-flattening / demand-charge row).  Test plumbing: lets a test assert that the
+ * ordered path really ran.  Every launch hands its problems to the resident workgroups through a work queue (one
+ * atomic counter per launch); ACNQP_NO_QUEUE=1 / ACNQP_NO_ORDER=1 in the environment select the static schedule / the
+ * natural order (diagnostics: results do not depend on either).                                                    */
+int64_t acnqp_ordered_launch_count(acnqp_handle* h);
+
 /* Anderson columns the kernels will actually use for problems of this shape
  * (t_max periods, k_sessions slots) at the given precision when `requested`
  * columns are asked for: a function of the shape only, never of the batch

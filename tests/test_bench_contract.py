@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 import bench
 from adacharge_amd import sites
@@ -89,3 +90,32 @@ def test_algorithmic_bytes_and_flops_bookkeeping():
     assert 49e3 < bench.flops_per_iteration_sparse(b) < 53e3
     assert 55e3 < bench.streamed_bytes_per_iteration(b) < 60e3
     assert np.isclose(bench.HBM_PEAK_GBS, 8000.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,n_gpus", [
+    (["--rehearse-collective"], 1),                                   # the nccl (= RCCL) branch with one rank
+    (["--gpus", "2", "--dist-backend", "gloo", "--one-device"], 2),   # two ranks on the one GPU, gloo carries the gather
+])
+def test_bench_multi_rank_path_runs(flags, n_gpus):
+    """the N > 1 code of bench.py (process group, x_dev, the per-step all-gather overlapped with the
+    next solve, the max-over-ranks clock, the gather assert) is run on every GPU test pass, so it cannot rot unseen
+    until an 8-GPU node appears.  bench.py is started as a CHILD process (for --gpus 2 it spawns its ranks itself,
+    before anything in it touches HIP).  No scaling number comes out of this: both ranks share one GPU."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batches", "8",
+           "--no-cpu-baseline", "--no-other-configs", *flags]
+    out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n_gpus and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["solver"]["solved"] == d["solver"]["problems"] == n_gpus * 8 * 256
+    assert "all-gather" in d["config"]["parallelism"] or n_gpus == 1
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0

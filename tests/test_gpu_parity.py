@@ -1003,37 +1003,62 @@ def test_certified_infeasible_problems_are_infeasible_for_highs():
     h.close()
 
 
-def test_launch_order_does_not_change_results(tmp_path):
-    """launches of >= 768 problems map workgroups to problems longest-expected first.  The same
-    batch solved in a child process with ACNQP_NO_ORDER=1 (workgroup b solves problem b) returns the same bits."""
+@pytest.mark.parametrize("family", ["tiled", "long-lds", "long-96", "stream", "general"])
+def test_work_queue_and_launch_order_do_not_change_results(tmp_path, family):
+    """a launch hands its problems to the resident workgroups through a work queue, in the order
+    `longest expected first` for launches of >= 768 problems.  ONE launch of >= 768 problems per kernel family
+    (acnqp_solve_batch_device: the pipelined host entry would cut it into chunks below the ordering threshold -- ADVICE
+    r3), the order asserted to have engaged, against child processes that run the NATURAL queue order (ACNQP_NO_ORDER=1)
+    and the STATIC schedule, one workgroup per problem (ACNQP_NO_QUEUE=1): same bits."""
     import subprocess
     import sys
 
+    from tests import queue_cases
+
+    res = queue_cases.solve(family)
+    assert int(res["ordered"]) == 1, "the launch order did not engage"
+    assert len(np.unique(res["keys"])) > 8            # the sort keys differ: the order is not the identity
+    assert np.isin(res["status"], (1, 5)).all() and (res["status"] == 1).mean() > 0.99
+    for var in ("ACNQP_NO_ORDER", "ACNQP_NO_QUEUE"):
+        out = tmp_path / f"{var}.npz"
+        subprocess.run([sys.executable, queue_cases.__file__, family, str(out)], check=True, env=dict(os.environ, **{var: "1"}),
+                       timeout=600)
+        other = np.load(out)
+        assert int(other["ordered"]) == (0 if var == "ACNQP_NO_ORDER" else 1)
+        assert np.array_equal(other["status"], res["status"]) and np.array_equal(other["iters"], res["iters"]), var
+        assert np.array_equal(other["x"], res["x"]), var
+
+
+def test_handles_do_not_leak_device_memory():
+    """acnqp_destroy releases every per-stream buffer (workspace AND the scheduling buffer): creating,
+    using and destroying handles in a loop leaves the free device memory where it was."""
+    import torch
+
     infra, iface = H.caltech_interface()
     obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
-    batch = build_batch(sites.snapshot_batch(infra, 12, 1024, seed=4242), infra, iface, obj, "SOC")
-    h = SiteHandle(batch.site, 0)
-    res = h.solve(batch, default_options())
-    h.close()
-    out = tmp_path / "natural.npz"
-    script = (
-        "import sys, numpy as np; sys.path.insert(0, %r)\n"
-        "from tests import helpers as H\n"
-        "from adacharge_amd import ObjectiveComponent, equal_share, quick_charge, sites\n"
-        "from adacharge_amd.backend import SiteHandle, default_options\n"
-        "from adacharge_amd.builder import build_batch\n"
-        "infra, iface = H.caltech_interface()\n"
-        "obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]\n"
-        "batch = build_batch(sites.snapshot_batch(infra, 12, 1024, seed=4242), infra, iface, obj, 'SOC')\n"
-        "r = SiteHandle(batch.site, 0).solve(batch, default_options())\n"
-        "np.savez(%r, x=r.x, iters=r.iters, status=r.status)\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(out)))
-    env = dict(os.environ, ACNQP_NO_ORDER="1")
-    subprocess.run([sys.executable, "-c", script], check=True, env=env, timeout=300)
-    nat = np.load(out)
-    assert (res.status == 1).all()
-    assert np.array_equal(nat["status"], res.status) and np.array_equal(nat["iters"], res.iters)
-    assert np.array_equal(nat["x"], res.x)
-    assert len(np.unique((batch.s_len > 0).sum(axis=(1, 2)))) > 8   # the sort keys do differ: the order is not the identity
+    batch = build_batch(sites.snapshot_batch(infra, 12, 1024, seed=77), infra, iface, obj, "SOC")
+    dev = torch.device("cuda", 0)
+    from adacharge_amd.backend import DeviceBatch
+
+    db = DeviceBatch(batch, dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(6)]
+
+    def cycle():
+        h = SiteHandle(batch.site, 0)
+        for s in streams:
+            h.solve_device(db, default_options(), stream=s.cuda_stream)
+        torch.cuda.synchronize()
+        h.solve(batch.subset(slice(0, 64)), default_options())
+        h.close()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    for _ in range(12):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free0 - free1 < 8 << 20, (free0, free1)     # 12 cycles x 6 streams: a leaked buffer per stream would show
 
 
 def test_large_site_kernel_certificates_agree_with_highs():

@@ -23,6 +23,62 @@ def test_scanner_finds_an_overwritten_wide_store_and_accepts_the_guarded_forms()
     assert store_hazard.scan_isa(late) == (1, [])
 
 
+def test_scanner_follows_branches_behind_a_store():
+    """A store that ends a basic block: the overwrite sits at the branch TARGET (conditional: both successors are
+    walked; unconditional: only the target), in objdump form (addresses) and in compiler -S form (.L labels)."""
+    objdump = """
+0000000000001000 <_ZN5acnqp1kE>:
+	buffer_store_dwordx4 v[44:47], v1, s[56:59], s77 offen     // 000000001000: E07C1000 4D0E2C01
+	s_cbranch_execz 3                                          // 000000001008: BF880003 <_ZN5acnqp1kE+0x18>
+	s_mov_b32 s0, 0                                            // 00000000100C: BE800080
+	s_mov_b32 s1, 0                                            // 000000001010: BE810080
+	s_mov_b32 s2, 0                                            // 000000001014: BE820080
+	v_add_f64 v[46:47], v[36:37], -v[68:69]                    // 000000001018: D2800000 4002892C
+	s_endpgm                                                   // 000000001020: BF810000
+"""
+    stores, found = store_hazard.scan_isa(objdump)
+    assert stores == 1 and len(found) == 1 and found[0][2] == 2, found      # branch (1) + the overwrite at the target (2)
+    # the same block with the guard in front of the branch is clean on both successors
+    assert store_hazard.scan_isa(objdump.replace("\ts_cbranch_execz", "\ts_nop 2\n\ts_cbranch_execz")) == (1, [])
+    # unconditional branch: the fall-through instruction is not a successor, the target is
+    listing = """
+_ZN5acnqp1kE:
+	buffer_store_dwordx4 v[44:47], v1, s[56:59], s77 offen
+	s_branch .LBB0_2
+	v_mov_b32 v44, 0
+.LBB0_2:
+	v_mov_b32 v99, 0
+	v_mov_b32 v45, 0
+	s_endpgm
+"""
+    stores, found = store_hazard.scan_isa(listing)
+    assert stores == 1 and len(found) == 1 and "v_mov_b32 v45" in found[0][3] and found[0][2] == 3, found
+    assert store_hazard.scan_isa(listing.replace("v_mov_b32 v45", "v_mov_b32 v55")) == (1, [])
+
+
+def test_loaded_library_was_scanned_by_the_build(hip_library):
+    """The build writes what its scan saw next to the library; a library built with the scan skipped (or by hand) does
+    not pass."""
+    lib = backend.library_path()
+    stamp = store_hazard.read_stamp(lib)
+    assert stamp is not None, "no hazard-scan stamp next to the library: build it with adacharge_amd.build"
+    assert stamp["library_sha256"] == store_hazard.file_sha256(lib), "the stamp is of another build"
+    assert stamp["state"] == "scanned" and stamp["unguarded"] == 0 and stamp["wide_stores"] > 100, stamp
+
+
+def test_missing_scanner_fails_the_build(monkeypatch, tmp_path):
+    from adacharge_amd import build
+
+    monkeypatch.setattr(store_hazard, "_LLVM_BIN", str(tmp_path))
+    monkeypatch.delenv("ACNQP_SKIP_HAZARD_SCAN", raising=False)
+    import pytest
+    with pytest.raises(store_hazard.ScannerUnavailable):
+        store_hazard.scan_library(backend.library_path())
+    # (build_hip_library turns that into a RuntimeError and moves the library aside; exercised here without relinking)
+    src = open(build.__file__).read()
+    assert "ACNQP_SKIP_HAZARD_SCAN" in src and "cannot run" in src
+
+
 def test_built_library_has_wide_stores_and_none_is_unguarded(hip_library):
     try:
         stores, found = store_hazard.scan_library(backend.library_path())
