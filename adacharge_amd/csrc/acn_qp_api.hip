@@ -563,7 +563,16 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   const int evk = (int)(h->launches % acnqp_handle::kEvRing);
   HIP_TRY(hipEventRecord(h->ev_start[evk], st));
   static const bool no_order = std::getenv("ACNQP_NO_ORDER") != nullptr;   // diagnostic: queue position b = problem b
-  static const bool no_queue = std::getenv("ACNQP_NO_QUEUE") != nullptr;   // diagnostic: the static schedule (workgroup w = position w)
+  static const bool no_queue_env = std::getenv("ACNQP_NO_QUEUE") != nullptr;   // diagnostic: the static schedule (workgroup w = position w)
+  static const bool queue_all = std::getenv("ACNQP_QUEUE_ALL") != nullptr;     // diagnostic: the queue for the streaming kernels too
+  // The work queue serves the kernels whose state is ON CHIP (register-resident, LDS-resident long-horizon): their
+  // launches end on their slowest workgroup slot, and levelling the slots is worth 7-10 % (headline lone launch 28.8 ->
+  // 26.9 ms, jpl52 x 24 x 4,096 67.2 -> 60.6 ms).  The kernels that stream their state through HBM are bandwidth-bound
+  // across the whole chip: a slot that ends early leaves its bandwidth to the others, and the static schedule measured
+  // the same or better (configs[4] leg 432 vs 434-438 ms, 54 x 144 x 2,048 237-243 vs 247-248 ms; gpurun_out/r4c):
+  // they keep one workgroup per problem.
+  const bool on_chip = tiled_shape(h, p->t_max, p->k_sessions) || (long_shape(h, p->t_max, p->k_sessions) && lds_long_shape(h, p->t_max));
+  const bool no_queue = no_queue_env || !(on_chip || queue_all);
   // (the order by sessions only for separable objectives: with a load-flattening or demand-charge row the coupling, not
   //  the number of sessions, sets the iteration count -- on the configs[4] leg it was 10 % SLOWER than the natural one)
   const bool want_order = p->batch >= kOrderMinBatch && !no_order && !h->has_flat && !h->has_max;
@@ -588,7 +597,9 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   }
   // workgroups of a work-queue launch that get a workspace of their own (the kernels that stream their state): at most
   // two resident workgroups per CU (no streaming kernel has more); the launchers cap their grid at it
-  a.grid_cap = a.queue ? std::min(p->batch, 2 * h->cus) : p->batch;
+  static const bool ws_per_problem = std::getenv("ACNQP_WS_PER_PROBLEM") != nullptr;   // diagnostic
+  a.ws_by_slot = a.queue && !ws_per_problem ? 1 : 0;
+  a.grid_cap = a.ws_by_slot ? std::min(p->batch, 2 * h->cus) : p->batch;
   const bool tiled = tiled_shape(h, p->t_max, p->k_sessions);
   const bool stream = !tiled && stream_shape(h, p->t_max);
   const bool lng = long_shape(h, p->t_max, p->k_sessions);

@@ -76,7 +76,10 @@ __global__ __launch_bounds__(kGenThreads) void admm_general_kernel(const General
   const int N = A.N, T = A.Tm, NP = A.NP, MR = A.MR, K = A.K;
   const int n = N * T, mt = MR * T;
   // (the workspace belongs to the workgroup slot when the launch runs off the queue: acn_qp_stream.hpp)
-  real* W0 = static_cast<real*>(GA.work) + (size_t)(A.queue ? (int)blockIdx.x : b) * GA.ws_per_problem;
+  int ws_slot_ = (int)blockIdx.x;   // (opaque per pass: acn_qp_stream.hpp)
+  asm volatile("" : "+v"(ws_slot_));
+  ws_slot_ = __builtin_amdgcn_readfirstlane(ws_slot_);
+  real* W0 = static_cast<real*>(GA.work) + (size_t)(A.ws_by_slot ? ws_slot_ : b) * GA.ws_per_problem;
   real *x = W0, *z1 = x + n, *y1 = z1 + n, *r0 = y1 + n, *zh = r0 + n, *ub = zh + n;
   real *z2 = ub + n, *y2 = z2 + mt, *gx = y2 + mt, *w = gx + mt, *eh = w + mt, *hh = eh + mt, *zh2 = hh + mt;
   real* mu = zh2 + mt;             // [K*N]

@@ -130,7 +130,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   const int n_site = MT * nct, n_tile = n_site + NE * nct;   // tile items: site tiles first, then EVSE tiles
   const long long NT = (long long)NE * CTL * 256;
   // (the workspace belongs to the workgroup slot when the launch runs off the queue: acn_qp_stream.hpp)
-  real* W0 = SA.work + (size_t)(A.queue ? (int)blockIdx.x : b) * SA.ws_per_problem;
+  int ws_slot_ = (int)blockIdx.x;   // (opaque per pass: acn_qp_stream.hpp)
+  asm volatile("" : "+v"(ws_slot_));
+  ws_slot_ = __builtin_amdgcn_readfirstlane(ws_slot_);
+  real* W0 = SA.work + (size_t)(A.ws_by_slot ? ws_slot_ : b) * SA.ws_per_problem;
   const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(W0, 0, (int)(SA.ws_per_problem * 8), 0x00020000);
   const unsigned NT8 = (unsigned)NT * 8u;
   const unsigned MS8 = (unsigned)(MT * CTL * 256) * 8u;

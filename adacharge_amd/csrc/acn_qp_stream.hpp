@@ -148,7 +148,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   const long long NT = (long long)NE * CT * 256;
   // the workspace belongs to the workgroup SLOT, not to the problem, when the launch runs off the queue (every pass
   // initialises what it reads): grid x ws_per_problem instead of B x ws_per_problem
-  real* W0 = SA.work + (size_t)(A.queue ? (int)blockIdx.x : b) * SA.ws_per_problem;
+  // (the slot index is made opaque per pass like the ids above: as a plain blockIdx.x every workspace address was
+  //  invariant across the passes, was hoisted out of the pass loop and lived -- spilled -- across the solver loop:
+  //  <3,3,4> 90 -> 188 spilled registers, configs[4] leg 423 -> 460 ms)
+  int ws_slot_ = (int)blockIdx.x;
+  asm volatile("" : "+v"(ws_slot_));
+  ws_slot_ = __builtin_amdgcn_readfirstlane(ws_slot_);
+  real* W0 = SA.work + (size_t)(A.ws_by_slot ? ws_slot_ : b) * SA.ws_per_problem;
   real *Xs = W0, *Z1s = Xs + NT, *Y1s = Z1s + NT, *Qs = Y1s + NT, *LBs = Qs + NT, *UBs = LBs + NT;
   real* MU = UBs + NT;                    // [K][NP]
   // site-row state (z2, y2, G x) in tile-fragment order: touched by the owner waves once per iteration, L2-resident

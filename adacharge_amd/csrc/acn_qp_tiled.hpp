@@ -94,6 +94,7 @@ struct TiledArgs {
   int stall_iters, retry_passes, retry_max_iter;
   double inacc_floor, retry_rho;
   int pbuf_single; // 1: one partial-tile slab instead of two (one more barrier per iteration, LDS for one more ring column)
+  int ws_by_slot;  // 1: a streaming kernel's workspace belongs to the workgroup slot (work-queue launches), 0: to the problem
   int grid_cap;    // host side only: most workgroups a launch may have (the kernels that stream their state own one
                    // workspace per workgroup slot)
 };

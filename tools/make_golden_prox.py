@@ -76,6 +76,12 @@ CASES = {
     "dc54_t96_soc":  ("caltech54", 96,  "SOC",    False, ("dc", 0.0),   103,  _gen_snapshot(dict(demand_range=(5.0, 90.0)))),
     "dc54_t144_lin": ("caltech54", 144, "LINEAR", False, ("dc", 0.0),   151,  _gen_snapshot(dict(demand_range=(5.0, 60.0)))),
     "lf54_t144_eq":  ("caltech54", 144, "SOC",    True,  ("lf", 1000.0), 5144, _gen_dense(0.18, 0.3)),
+    # the same three with equal_share * 1e-3 beside the flattening term: load_flattening alone is quadratic in the
+    # per-period AGGREGATE only (rank one per period), so the per-EVSE split of its optimum is not unique -- like the LP
+    # of quick_charge.  The pure cases pin objective, aggregate power and feasibility; these pin the per-EVSE rates.
+    "lf192_t48_eq_es": ("wide192",   48,  "SOC", True, ("lf", 300.0, 1e-3),  5192, _gen_general(0.3)),
+    "lf512_t48_eq_es": ("synth512",  48,  "SOC", True, ("lf", 100.0, 1e-3),  5,    _gen_bench_cfg4(5)),
+    "lf54_t144_eq_es": ("caltech54", 144, "SOC", True, ("lf", 1000.0, 1e-3), 5144, _gen_dense(0.18, 0.3)),
 }
 
 
@@ -85,8 +91,10 @@ def objective_of(kind, T):
 
     if kind[0] == "lf":
         ext = ext_profile(T, kind[1])
-        return ([("load_flattening", 1.0, {"external_signal": ext})],
-                [ObjectiveComponent(load_flattening, 1.0, {"external_signal": ext})], {})
+        es = kind[2] if len(kind) > 2 else 0.0
+        spec = [("load_flattening", 1.0, {"external_signal": ext})] + ([("equal_share", es, {})] if es else [])
+        obj = [ObjectiveComponent(load_flattening, 1.0, {"external_signal": ext})] + ([ObjectiveComponent(equal_share, es)] if es else [])
+        return spec, obj, {}
     return ([("total_energy", 20.0, {}), ("demand_charge", 1.0, {}), ("equal_share", 1e-3, {})],
             [ObjectiveComponent(total_energy, 20.0), ObjectiveComponent(demand_charge), ObjectiveComponent(equal_share, 1e-3)],
             {"demand_charge": 15.0, "prev_peak": 50.0})
@@ -135,7 +143,6 @@ def main():
     from oracle.ref_problem import build_reference_problem
 
     only = args or list(CASES)
-    store = dict(np.load(OUT, allow_pickle=False)) if os.path.exists(OUT) else {}
     for name in only:
         infra, iface, sl, spec, obj, ct, eq, kind, seed, T, site_name = case_problem(name)
         t0 = time.time()
@@ -151,7 +158,8 @@ def main():
             "demand": np.array([s.remaining_demand for s in sl]),
             "minr": np.concatenate([s.min_rates for s in sl]),
             "maxr": np.concatenate([s.max_rates for s in sl]),
-            "meta": np.array([T, 1 if ct == "SOC" else 0, 1 if eq else 0, 1 if kind[0] == "lf" else 0, seed], float),
+            "meta": np.array([T, 1 if ct == "SOC" else 0, 1 if eq else 0, 1 if kind[0] == "lf" else 0, seed,
+                              kind[2] if kind[0] == "lf" and len(kind) > 2 else (1e-3 if kind[0] == "dc" else 0.0)], float),
             "ext": ext_profile(Tb, kind[1]) if kind[0] == "lf" else np.zeros(0),
             "site": np.array(site_name),
             "rates": r,
@@ -159,6 +167,8 @@ def main():
             "cert": np.array([cert.stationarity, cert.primal, cert.dual]),
             "binding": np.array([(u > 1 - 1e-6).sum(), u.max()]),
         }
+        # (re-read the file right before it is rewritten: several generators may run side by side, one case each)
+        store = dict(np.load(OUT, allow_pickle=False)) if os.path.exists(OUT) else {}
         for k, v in st.items():
             store[f"{name}_{k}"] = v
         store["names"] = np.array(sorted({k.rsplit("_", 1)[0] for k in store if k.endswith("_rates")}))
