@@ -109,7 +109,7 @@ class Options(C.Structure):
         ("stall_iters", C.c_int32),
         ("retry_passes", C.c_int32),
         ("retry_max_iter", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("polish_iters", C.c_int32),
         ("retry_rho", C.c_double),
         ("inaccurate_floor", C.c_double),
     ]
@@ -128,6 +128,7 @@ EXPORTED_SYMBOLS = (
     "acnqp_accel_columns",
     "acnqp_kernel_times",
     "acnqp_ordered_launch_count",
+    "acnqp_polish_stats",
     "acnqp_solve_batches",
     "acnqp_host_alloc",
     "acnqp_host_free",
@@ -195,6 +196,8 @@ def load_library():
     lib.acnqp_launch_count.restype = C.c_int64
     lib.acnqp_ordered_launch_count.argtypes = [C.c_void_p]
     lib.acnqp_ordered_launch_count.restype = C.c_int64
+    lib.acnqp_polish_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]
+    lib.acnqp_polish_stats.restype = C.c_int
     _lib = lib
     return lib
 
@@ -441,6 +444,12 @@ class SiteHandle:
             return float("nan")
         self._launches_seen = before
         return float(sum(ms))
+
+    def polish_stats(self) -> dict:
+        """Counters of the device-side polish over this handle's life (acnqp_polish_stats; synchronises)."""
+        buf = (C.c_int64 * 6)()
+        _check(self._lib.acnqp_polish_stats(self._h, buf, 6), "acnqp_polish_stats")
+        return dict(zip(("attempted", "solved", "gave_up_rows", "gave_up_pivot", "gave_up_rounds", "gave_up_kkt"), [int(v) for v in buf]))
 
     def ordered_launches(self) -> int:
         """Launches of this handle whose queue order was sorted by session count (acnqp_ordered_launch_count)."""

@@ -101,7 +101,11 @@ struct SiteDev {
   int32_t* rowtype = nullptr;
   int32_t* rowabi = nullptr;     // internal row -> row of acnqp_site.G (-1: padding)
   void* rowscale = nullptr;      // equilibration factor of each internal row
+  double *Gabi = nullptr, *limabi = nullptr;   // acnqp_site.G / limits as the caller gave them (the polish kernel works in the caller's units)
   void release() {
+    if (Gabi) (void)hipFree(Gabi);
+    if (limabi) (void)hipFree(limabi);
+    Gabi = limabi = nullptr;
     for (void** p : {&G, &Ghat, &Q, &lam, &rowlim, &fragG, &fragQ, &fragG2, &fragQ2, &rowscale}) { if (*p) (void)hipFree(*p); *p = nullptr; }
     if (rowtype) (void)hipFree(rowtype);
     if (rowabi) (void)hipFree(rowabi);
@@ -127,7 +131,7 @@ struct acnqp_handle {
   // per launch stream: the kernel workspace (long-horizon, large-site, general-shape kernels) and the launch's small
   // scheduling buffer (queue counter, then sort keys and queue order).  Launches on different streams never share (or
   // regrow) each other's state, and a stream's own launches are ordered by the stream.
-  struct Work { hipStream_t st; DevBuf buf; DevBuf ord; long long used; hipEvent_t last; };
+  struct Work { hipStream_t st; DevBuf buf; DevBuf ord; DevBuf pol; long long used; hipEvent_t last; };   // pol: the polish's list and multiplier buffer
   std::vector<Work> work;
   long long work_clock = 0;
   // streams of the CALLER (acnqp_solve_batch_device) beyond the handle's own kSlots: a caller that round-robins one
@@ -162,12 +166,13 @@ struct acnqp_handle {
         if (work[lru].last) { (void)hipEventSynchronize(work[lru].last); (void)hipEventDestroy(work[lru].last); }
         work[lru].buf.release();
         work[lru].ord.release();
+        work[lru].pol.release();
         work.erase(work.begin() + (long)lru);
       }
     }
     hipEvent_t ev = nullptr;
     (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-    work.push_back(Work{st, DevBuf(), DevBuf(), ++work_clock, ev});
+    work.push_back(Work{st, DevBuf(), DevBuf(), DevBuf(), ++work_clock, ev});
     return &work.back();
   }
   void release_work() {
@@ -175,10 +180,12 @@ struct acnqp_handle {
       if (w.last) (void)hipEventDestroy(w.last);
       w.buf.release();
       w.ord.release();
+      w.pol.release();
     }
     work.clear();
   }
   int cus = 0;   // compute units of the device (the work-queue launches size their grid from it)
+  int32_t* pol_stats = nullptr;   // device counters of the polish kernel, summed over the handle's life (acnqp_polish_stats)
 };
 
 namespace {
@@ -359,6 +366,10 @@ int build_site_dev(acnqp_handle* h, SiteDev* d) {
   if (e == hipSuccess) e = hipMemcpy(d->rowtype, ty.data(), MR * sizeof(int32_t), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void**)&d->rowabi, MR * sizeof(int32_t));
   if (e == hipSuccess) e = hipMemcpy(d->rowabi, abi.data(), MR * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&d->Gabi, std::max<size_t>(h->G.size(), 1) * sizeof(double));
+  if (e == hipSuccess && !h->G.empty()) e = hipMemcpy(d->Gabi, h->G.data(), h->G.size() * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void**)&d->limabi, std::max<size_t>(h->limits.size(), 1) * sizeof(double));
+  if (e == hipSuccess && !h->limits.empty()) e = hipMemcpy(d->limabi, h->limits.data(), h->limits.size() * sizeof(double), hipMemcpyHostToDevice);
   if (e != hipSuccess) { d->release(); return fail(ACNQP_ERR_HIP, std::string("site upload: ") + hipGetErrorString(e)); }
   d->MR = MR;
   d->ready = true;
@@ -419,7 +430,7 @@ void acnqp_default_options(acnqp_options* o) {
   o->stall_iters = 3000;
   o->retry_passes = 2;
   o->retry_max_iter = 8000;
-  o->reserved_ = 0;
+  o->polish_iters = 1200;
   o->retry_rho = 0.5;
   o->inaccurate_floor = 1e-5;
 }
@@ -470,6 +481,10 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
   }
   int rc = build_site_dev(h, &h->dev64);
   if (rc != ACNQP_OK) { acnqp_destroy(h); return rc; }
+  if (hipMalloc((void**)&h->pol_stats, 8 * sizeof(int32_t)) != hipSuccess || hipMemset(h->pol_stats, 0, 8 * sizeof(int32_t)) != hipSuccess) {
+    acnqp_destroy(h);
+    return fail(ACNQP_ERR_HIP, "acnqp_create: polish counters");
+  }
   *out = h;
   return ACNQP_OK;
 }
@@ -488,6 +503,7 @@ void acnqp_destroy(acnqp_handle* h) {
     sl.out.release();
   }
   h->release_work();
+  if (h->pol_stats) (void)hipFree(h->pol_stats);
   delete h;
 }
 
@@ -514,7 +530,7 @@ static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, 
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: null result array");
   if (!(o->eps_abs >= 0) || !(o->eps_rel >= 0) || o->max_iter < 1 || o->check_every < 1 || !(o->rho > 0) ||
       !(o->sigma >= 0) || !(o->alpha > 0 && o->alpha < 2) || !(o->adapt_tol > 1) || !(o->reg_rel >= 0) ||
-      o->adapt_every < 0 || o->stall_iters < 0 || o->retry_passes < 0 || o->retry_passes > 8 || o->retry_max_iter < 1 ||
+      o->adapt_every < 0 || o->polish_iters < 0 || o->stall_iters < 0 || o->retry_passes < 0 || o->retry_passes > 8 || o->retry_max_iter < 1 ||
       !(o->retry_rho > 0) || !(o->inaccurate_floor >= 0))
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: invalid option value");
   if (o->precision != 64)
@@ -555,6 +571,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.pbuf_single = 0;
   a.order = nullptr;
   a.queue = nullptr;
+  a.polish_iters = 0; a.resume = 0; a.pol_list = nullptr; a.pol_count = nullptr; a.count_dev = nullptr;
   (void)hipGetLastError();   // drop any stale error so the checks below report this launch only
   // a problem whose workgroup never ran must not look solved (or carry the previous call's status)
   HIP_TRY(hipMemsetAsync(r->status, 0, (size_t)p->batch * sizeof(int32_t), st));
@@ -638,18 +655,64 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     ga.pair_stride = 4;
     ga.t = a;
   }
-  hipError_t e = hipSuccess;
-  if (tiled) {
-    e = p->t_max <= 16 ? acnqp::launch_tiled_ct1(a, st) : acnqp::launch_tiled_ct2(a, st);
-  } else if (stream) {
-    e = acnqp::launch_stream(sa, st);
-  } else if (lng) {
-    e = acnqp::launch_long(sa, st, lds_long_shape(h, p->t_max));
-  } else {
+  auto launch_solver = [&](const acnqp::TiledArgs& aa) -> hipError_t {
+    if (tiled) return p->t_max <= 16 ? acnqp::launch_tiled_ct1(aa, st) : acnqp::launch_tiled_ct2(aa, st);
+    if (stream) { sa.t = aa; return acnqp::launch_stream(sa, st); }
+    if (lng) { sa.t = aa; return acnqp::launch_long(sa, st, lds_long_shape(h, p->t_max)); }
     // workgroup size by problem size: the plain loops are latency-bound, more threads per problem hide more of it
     const long long nvar = (long long)h->N * p->t_max;
     const int nt = nvar <= 4096 ? 256 : (nvar <= 12288 ? 512 : 1024);
-    e = acnqp::launch_general(ga, nt, st);
+    ga.t = aa;
+    return acnqp::launch_general(ga, nt, st);
+  };
+  // ---- the polish (acn_qp_polish.hpp): small sites, separable objective, served by an on-chip kernel ------------------
+  // solver kernel (pass 0 up to polish_iters iterations; what has not converged by then is listed) -> polish kernel over
+  // the list -> solver kernel again over the list for what the polish gave up on (from scratch, with the retry passes:
+  // the answer it had before there was a polish).  Three launches on the stream, the last two nearly empty as a rule.
+  const int nrow_site = h->M + h->has_peak;
+  int pol_rows = 0;
+  static const bool no_polish = std::getenv("ACNQP_NO_POLISH") != nullptr;   // diagnostic
+  if (!no_polish && o->polish_iters > 0 && o->polish_iters < o->max_iter && on_chip && h->N <= 64 && p->t_max <= 32 &&
+      p->k_sessions <= acnqp::kMaxK && !h->has_flat && !h->has_max && !a.warm_x)
+    pol_rows = acnqp::polish_rows_that_fit(h->N, p->t_max, h->Mg, nrow_site);
+  hipError_t e = hipSuccess;
+  if (pol_rows >= 32) {
+    // [0] queue of the polish kernel, [1] queue of the resume launch, [2] list length; list[B]; multipliers [B][Mg][Tm]
+    // unless the caller wants them anyway
+    const size_t ybytes = r->y ? 0 : (size_t)p->batch * h->Mg * p->t_max * sizeof(double);
+    const size_t lbytes = ((size_t)p->batch * sizeof(int32_t) + 255) & ~(size_t)255;
+    const size_t need = 256 + lbytes + ybytes;
+    if (need > wk->pol.cap) HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(wk->pol.reserve(need));
+    int32_t* ctr = static_cast<int32_t*>(wk->pol.p);
+    int32_t* list = ctr + 64;
+    double* ybuf = r->y ? r->y : reinterpret_cast<double*>(static_cast<char*>(wk->pol.p) + 256 + lbytes);
+    HIP_TRY(hipMemsetAsync(ctr, 0, 256, st));
+    acnqp::TiledArgs a1 = a;
+    a1.polish_iters = o->polish_iters - o->polish_iters % std::max(1, o->check_every);   // the exit is taken at a residual check
+    if (a1.polish_iters < o->check_every) a1.polish_iters = o->check_every;
+    a1.pol_list = list; a1.pol_count = ctr + 2; a1.y_out = ybuf;
+    e = launch_solver(a1);
+    if (e == hipSuccess) {
+      acnqp::PolishArgs pa;
+      pa.B = p->batch; pa.N = h->N; pa.Tm = p->t_max; pa.K = p->k_sessions; pa.M = h->M; pa.Mg = h->Mg; pa.cone = h->cone;
+      pa.has_peak = h->has_peak; pa.max_rows = pol_rows;
+      pa.G = d->Gabi; pa.limits = d->limabi;
+      pa.horizon = p->horizon; pa.lb = p->lb; pa.ub = p->ub; pa.q = p->q; pa.pdiag = p->pdiag;
+      pa.s_off = p->s_off; pa.s_len = p->s_len; pa.s_cap = p->s_cap; pa.s_eq = p->s_eq; pa.peak = h->has_peak ? p->peak : nullptr;
+      pa.x = r->x; pa.y = ybuf; pa.status = r->status; pa.iters = r->iters; pa.pri = r->pri_res; pa.dua = r->dua_res; pa.obj = r->obj;
+      pa.list = list; pa.count = ctr + 2; pa.queue = ctr + 0; pa.stats = h->pol_stats; pa.reg_rel = o->reg_rel;
+      e = acnqp::launch_polish(pa, h->cus, st);
+    }
+    if (e == hipSuccess) {
+      acnqp::TiledArgs a3 = a;
+      a3.resume = 1; a3.order = list; a3.count_dev = ctr + 2; a3.queue = ctr + 1;
+      a3.ws_by_slot = 1; a3.grid_cap = std::min(p->batch, 2 * h->cus);   // (<= the grid the workspace was sized for)
+      if (!a.ws_by_slot) a3.grid_cap = std::min(a3.grid_cap, a.grid_cap);
+      e = launch_solver(a3);
+    }
+  } else {
+    e = launch_solver(a);
   }
   if (e != hipSuccess) return fail(ACNQP_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
   HIP_TRY(hipEventRecord(h->ev_stop[evk], st));
@@ -695,6 +758,16 @@ static float event_pair_ms(acnqp_handle* h, long long launch) {
 
 int64_t acnqp_launch_count(acnqp_handle* h) { return h ? (int64_t)h->launches : 0; }
 int64_t acnqp_ordered_launch_count(acnqp_handle* h) { return h ? (int64_t)h->ordered_launches : 0; }
+
+int acnqp_polish_stats(acnqp_handle* h, int64_t* out, int32_t capacity) {
+  if (!h || !out || capacity < 1) return fail(ACNQP_ERR_INVALID, "acnqp_polish_stats: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  int32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIP_TRY(hipMemcpy(v, h->pol_stats, sizeof(v), hipMemcpyDeviceToHost));
+  for (int k = 0; k < capacity && k < 6; ++k) out[k] = v[k];
+  return ACNQP_OK;
+}
 
 #ifdef ACNQP_DEBUG_WS
 // diagnostic builds only (tools/gpu_long_race.py): the most recently used kernel workspace, copied to the host

@@ -11,6 +11,7 @@
 #include "acn_qp_general.hpp"
 #include "acn_qp_stream.hpp"
 #include "acn_qp_long.hpp"
+#include "acn_qp_polish.hpp"
 
 namespace acnqp {
 
@@ -57,6 +58,10 @@ hipError_t launch_stream(const StreamArgs& sa, hipStream_t st);
 // long-horizon kernel (acn_qp_long.hpp); lds_resident: its LDS-resident variant for two column tiles x two row tiles
 int long_tiles(int t_max);
 hipError_t launch_long(const StreamArgs& sa, hipStream_t st, bool lds_resident);
+// polish kernel (acn_qp_polish.hpp): rows of the Schur system its LDS holds for a shape (0: does not fit); launch over
+// the list the solver kernel left
+int polish_rows_that_fit(int N, int Tm, int Mg, int nrow);
+hipError_t launch_polish(const PolishArgs& pa, int cus, hipStream_t st);
 // general-shape kernel (acn_qp_general.hpp), `threads` in {256, 512, 1024}
 hipError_t launch_general(const GeneralArgs& ga, int threads, hipStream_t st);
 

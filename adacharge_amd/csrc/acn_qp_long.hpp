@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   // the kernarg segment: no argument is kept alive across the solver loop for the next pass's sake.
   __shared__ int q_slot;
   for (int q_round = 0;; ++q_round) {   // work queue: this workgroup's next problem (queue_next, acn_qp_tiled.hpp)
-  const int q_pos = queue_next(SA_kernarg.t.queue, SA_kernarg.t.B, q_round, &q_slot);
+  const int q_pos = queue_next(SA_kernarg.t.queue, queue_length(SA_kernarg.t), q_round, &q_slot);
   if (q_pos < 0) break;
   int it_total = 0, best_status = 0;
   for (int pass = 0;; ++pass) {
@@ -118,6 +118,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
 #else
   const int b = q_pos, tid = threadIdx.x;   // diagnostic: descriptor in vector registers (round 2's form)
 #endif
+  if (A.resume) {   // the launch behind the polish kernel (acn_qp_tiled.hpp): what it solved is done; the rest starts over
+    if (A.status[b] != kStatusPolish && pass == 0) break;
+    if (pass == 0) it_total = A.iters[b];
+  }
   const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
   const int adapt_p = pass == 0 ? A.adapt_every : 0;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1157,6 +1161,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel, A.inacc_floor);
       const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= kStallNear * best_score;   // acn_qp_tiled.hpp
       if (done) {
+      } else if (pass == 0 && A.polish_iters > 0 && it >= A.polish_iters) {
+        status = kStatusPolish;   // not converged after polish_iters iterations: the polish kernel takes over (acn_qp_polish.hpp)
+        done = true;
       } else if (it >= max_iter_p || stalled) {
         done = true;
         if (inacc) status = 5;
@@ -1228,6 +1235,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     real o = 0;
     for (int wv = 0; wv < NWV; ++wv) o += SC[wv];
     A.status[b] = status; A.pri[b] = pri; A.dua[b] = dua; A.obj[b] = o;
+    if (status == kStatusPolish) A.pol_list[atomicAdd(A.pol_count, 1)] = b;
   }
   }
   if (tid == 0) A.iters[b] = it_total;

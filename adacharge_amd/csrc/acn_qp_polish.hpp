@@ -1,0 +1,666 @@
+// Device-side polish: the active-set Newton method that takes over from the ADMM when a problem of a small site
+// (N <= 64, horizon <= 32: the shapes of BASELINE.json configs[1]-[3]) has not converged after options.polish_iters
+// iterations.  The reference's solver is an interior-point method (ECOS through cvxpy, aco.py:318): 15-25 iterations on
+// every instance, no plateau.  A first-order method has one -- the tangentially degenerate congested instances of
+// DESIGN.md section 2 turn the ADMM sub-linear -- and until round 4 the answer was two cold 8,000-iteration restarts
+// (configs[3] site 3: a launch as long as its slowest problem, 9,800 iterations).  The ADMM iterate is good enough to
+// GUESS the optimal working set, though; from there Newton on the KKT conditions converges in a few dozen small dense
+// solves whatever the conditioning of the fixed-point map.
+//
+// Restated line by line in numpy, with the derivation, in oracle/polish_ref.py (the executable specification of this
+// kernel); results are checked against the IPM certificates of tests/golden/stalled.npz.
+//
+// One workgroup of 256 threads per problem.  Thread (i = tid / 4, h = tid % 4) owns the periods [h TQ, (h + 1) TQ) of
+// EVSE i, TQ = ceil(Tm / 4) <= 8, in registers: a session's sums are two lane exchanges inside the EVSE's quad.  The site
+// rows live in LDS: G, G x, G dx, the rows of the Schur system (normal + tangent row of every tight disc, period-major)
+// and its packed lower triangle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "acn_qp_tiled.hpp"
+
+namespace acnqp {
+
+constexpr int kPolThreads = 256;
+constexpr int kPolTQ = 8;            // periods per thread (Tm <= 32)
+constexpr int kPolMaxRounds = 96;
+constexpr double kPolTolBound = 1e-7;    // |x - bound| below which the ADMM iterate counts as "on the bound"
+constexpr double kPolTolRow = 1e-9;      // relative size of a site-row multiplier that counts as non-zero
+constexpr double kPolTolStep = 1e-9;     // convergence of a round: |dx|_inf <= tol max(1, |x|_inf)
+constexpr double kPolTolDual = 1e-9;     // a multiplier below -tol max(1, |q|_inf) leaves the working set
+constexpr double kPolTolPrimal = 1e-9;   // accepted violation of a row, relative to max(1, limit)
+constexpr double kPolRegRel = 1e-9;      // dual regularisation of the Schur system, relative to pd
+constexpr double kPolTangentMin = 1e-7;  // a disc with a multiplier below tol max(1, |q|_inf) gets no curvature row
+
+struct PolishArgs {
+  int B, N, Tm, K, M, Mg, cone, has_peak, max_rows;
+  const double *G, *limits;        // acnqp_site.G [Mg][N] and limits [M] as the caller gave them (no equilibration)
+  const int32_t* horizon;
+  const double *lb, *ub, *q, *pdiag;
+  const int32_t *s_off, *s_len;
+  const double* s_cap;
+  const uint8_t* s_eq;
+  const double* peak;
+  double *x, *y;                   // in: the ADMM iterate (schedule, site-row multipliers in the caller's units); out: the optimum
+  int32_t *status, *iters;
+  double *pri, *dua, *obj;
+  const int32_t *list, *count;     // problems left to the polish by the solver kernel
+  int32_t* queue;                  // launch counter of the work queue
+  int32_t* stats;                  // [0] attempted, [1] succeeded, [2] gave up: rows, [3] pivot, [4] rounds, [5] verification
+  double reg_rel;
+};
+
+// LDS carve-up in doubles (host: size; device: offsets)
+struct PolishLds {
+  int xs, ds, gs, u, du, nu, invn, rc0, rc1, rca, rdg, lam, S, red, ints, total;
+  __host__ __device__ PolishLds(int N, int Tm, int Mg, int nrow, int max_rows) {
+    int o = 0;
+    xs = o; o += N * Tm;
+    ds = o; o += N * Tm;
+    gs = o; o += Mg * N;
+    u = o; o += Mg * Tm;
+    du = o; o += Mg * Tm;
+    nu = o; o += nrow * Tm;
+    invn = o; o += N * 4;
+    rc0 = o; o += max_rows;
+    rc1 = o; o += max_rows;
+    rca = o; o += max_rows;
+    rdg = o; o += max_rows;
+    lam = o; o += max_rows;
+    S = o; o += max_rows * (max_rows + 1) / 2;
+    red = o; o += 16;
+    ints = o;   // ints from here: rj[max_rows], rr[max_rows], rt[max_rows], tstart[Tm + 1], ract[nrow], misc[8]; then cs[N * Tm] bytes
+    const int nint = 3 * max_rows + (Tm + 1) + nrow + 8;
+    o += (nint + 1) / 2 + (N * Tm + 7) / 8;
+    total = o;
+  }
+  // largest max_rows whose carve-up fits `bytes` of LDS
+  __host__ static int rows_that_fit(int N, int Tm, int Mg, int nrow, int bytes) {
+    int best = 0;
+    for (int m = 16; m <= 256; m += 8)
+      if ((long long)PolishLds(N, Tm, Mg, nrow, m).total * 8 <= bytes) best = m;
+    return best;
+  }
+};
+
+__device__ inline double pol_quad_sum(double v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  return v;
+}
+__device__ inline double pol_wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
+}
+// block-wide max; every thread gets it (two barriers; `red` holds one double per wave)
+__device__ inline double pol_block_max(double v, double* red) {
+  v = pol_wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+__device__ inline double pol_block_sum(double v, double* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+// block-wide minimum with a payload; ties go to the smaller code (deterministic).  code < 0: no candidate.
+__device__ inline void pol_block_argmin(double& v, int& code, double* red) {
+  for (int o = 32; o > 0; o >>= 1) {
+    const double ov = __shfl_xor(v, o);
+    const int oc = __shfl_xor(code, o);
+    const bool take = oc >= 0 && (code < 0 || ov < v || (ov == v && oc < code));
+    v = take ? ov : v;
+    code = take ? oc : code;
+  }
+  int* redi = reinterpret_cast<int*>(red + 4);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = v; redi[threadIdx.x >> 6] = code; }
+  __syncthreads();
+  v = red[0]; code = redi[0];
+  for (int w = 1; w < 4; ++w) {
+    const double ov = red[w];
+    const int oc = redi[w];
+    const bool take = oc >= 0 && (code < 0 || ov < v || (ov == v && oc < code));
+    v = take ? ov : v;
+    code = take ? oc : code;
+  }
+}
+
+// blocking-constraint / release codes: kind in the top bits
+constexpr int kPolLb = 0, kPolUb = 1, kPolSess = 2, kPolRow = 3;
+__device__ inline int pol_code(int kind, int p0, int p1) { return (kind << 24) | (p0 << 8) | p1; }
+
+template <int kVariant>   // (a template only so that the header can be included by every translation unit; instantiated in acn_qp_polish.hip)
+__global__ __launch_bounds__(kPolThreads, 1) void polish_kernel(const PolishArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pol_smem[];
+  double* sm = reinterpret_cast<double*>(pol_smem);
+  const int N = A.N, Tm = A.Tm, K = A.K, M = A.M, Mg = A.Mg;
+  const bool soc = A.cone == 1;
+  const int nrow = M + (A.has_peak ? 1 : 0);
+  const PolishLds L(N, Tm, Mg, nrow, A.max_rows);
+  double *Xs = sm + L.xs, *Ds = sm + L.ds, *Gs = sm + L.gs, *U = sm + L.u, *DU = sm + L.du, *NU = sm + L.nu, *INVN = sm + L.invn;
+  double *RC0 = sm + L.rc0, *RC1 = sm + L.rc1, *RCA = sm + L.rca, *RDG = sm + L.rdg, *LAM = sm + L.lam, *S = sm + L.S, *RED = sm + L.red;
+  int* RJ = reinterpret_cast<int*>(sm + L.ints);      // ABI row j of the Schur row
+  int* RR = RJ + A.max_rows;                           // its site row r (0 .. nrow - 1); tangent rows: -1 - r
+  int* RT = RR + A.max_rows;                           // its period
+  int* TSTART = RT + A.max_rows;                       // Schur rows of period t: [TSTART[t], TSTART[t + 1])
+  unsigned* RACT = reinterpret_cast<unsigned*>(TSTART + Tm + 1);   // per site row: bit t = tight at period t
+  int* MISC = reinterpret_cast<int*>(RACT + nrow);     // [0] m, [1] fail flag
+  signed char* CS = reinterpret_cast<signed char*>(MISC + 8);   // per (i, t): -2 not free, -1 free, k >= 0 free in tight session k
+  __shared__ int q_slot;
+
+  const int tid = threadIdx.x;
+  const int i = tid >> 2, h = tid & 3;
+  const int TQ = (Tm + 3) >> 2;
+  const bool iv = i < N;
+  auto row_j = [&](int r) { return r < M ? r : Mg - 1; };
+  auto row_is_disc = [&](int r) { return soc && r < M; };
+
+  for (int q_round = 0;; ++q_round) {
+    const int nlist = *A.count;
+    const int pos = queue_next(A.queue, nlist < A.B ? nlist : A.B, q_round, &q_slot);
+    if (pos < 0) break;
+    const int b = A.list[pos];
+    if (A.status[b] != kStatusPolish) continue;   // (block-uniform)
+    if (tid == 0) atomicAdd(A.stats + 0, 1);
+    const bool eq = A.s_eq[b] != 0;
+    const double pd_user = A.pdiag[b];
+
+    // ---- own variables ----------------------------------------------------------------------------------------
+    double xv[kPolTQ], lbv[kPolTQ], ubv[kPolTQ], qv[kPolTQ], dv[kPolTQ], gv[kPolTQ], ev[kPolTQ];
+    unsigned atlb = 0, atub = 0, fixedm = 0, validm = 0;
+    double qmax = 0, umax = 0;
+#pragma unroll
+    for (int k = 0; k < kPolTQ; ++k) {
+      const int t = h * TQ + k;
+      const bool ok = iv && k < TQ && t < Tm;
+      const size_t idx = ((size_t)b * N + (ok ? i : 0)) * Tm + (ok ? t : 0);
+      lbv[k] = ok ? A.lb[idx] : 0.0;
+      ubv[k] = ok ? fmax(A.ub[idx], lbv[k]) : 0.0;
+      qv[k] = ok ? A.q[idx] : 0.0;
+      xv[k] = ok ? fmin(fmax(A.x[idx], lbv[k]), ubv[k]) : 0.0;
+      dv[k] = 0; gv[k] = 0; ev[k] = 0;
+      validm |= ok ? 1u << k : 0u;
+      qmax = fmax(qmax, fabs(qv[k]));
+      umax = fmax(umax, ubv[k]);
+      const bool lo = xv[k] <= lbv[k] + kPolTolBound;
+      const bool hi = xv[k] >= ubv[k] - kPolTolBound && !lo;
+      atlb |= lo ? 1u << k : 0u;
+      atub |= hi ? 1u << k : 0u;
+      fixedm |= (ubv[k] - lbv[k] <= kPolTolBound) ? 1u << k : 0u;
+    }
+    const double qraw = pol_block_max(qmax, RED);
+    const double ubmax = pol_block_max(umax, RED);
+    const double qn = fmax(1.0, qraw);
+    const double pd = effective_pdiag<double>(pd_user, A.reg_rel, qraw, ubmax, A.horizon[b], false);
+    // ---- own sessions (the same on the four threads of the quad) ---------------------------------------------------
+    unsigned swm[kMaxK];      // bit k: own period k lies in the window
+    double scap[kMaxK], smu[kMaxK];
+    bool sact[kMaxK], shas[kMaxK];
+#pragma unroll
+    for (int ks = 0; ks < kMaxK; ++ks) {
+      swm[ks] = 0; scap[ks] = 0; smu[ks] = 0; sact[ks] = false; shas[ks] = false;
+      if (ks < K && iv) {
+        const size_t sidx = ((size_t)b * K + ks) * N + i;
+        const int off = A.s_off[sidx], len = A.s_len[sidx];
+        scap[ks] = A.s_cap[sidx];
+        shas[ks] = len > 0;
+#pragma unroll
+        for (int k = 0; k < kPolTQ; ++k) {
+          const int t = h * TQ + k;
+          if (k < TQ && t >= off && t < off + len && t < Tm) swm[ks] |= 1u << k;
+        }
+      }
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < kPolTQ; ++k) s += ((swm[ks] >> k) & 1u) ? xv[k] : 0.0;
+      s = pol_quad_sum(s);
+      sact[ks] = shas[ks] && (eq || s >= scap[ks] - kPolTolBound * fmax(1.0, fabs(scap[ks])));
+    }
+    // ---- site data; first guess of the tight site rows from the ADMM's multipliers ----------------------------------
+    for (int k = tid; k < Mg * N; k += kPolThreads) Gs[k] = A.G[k];
+    for (int r = tid; r < nrow; r += kPolThreads) RACT[r] = 0;
+    __syncthreads();
+    for (int k = tid; k < nrow * Tm; k += kPolThreads) {
+      const int r = k / Tm, t = k - r * Tm, j = row_j(r);
+      const double y0 = A.y[((size_t)b * Mg + j) * Tm + t];
+      const double mag = row_is_disc(r) ? hypot(y0, A.y[((size_t)b * Mg + j + M) * Tm + t]) : y0;
+      const double lim = r < M ? A.limits[r] : A.peak[(size_t)b * Tm + t];
+      const bool on = mag > kPolTolRow * qn && lim < 1e299;
+      NU[k] = on ? mag : 0.0;
+      if (on) atomicOr(&RACT[r], 1u << t);
+    }
+    __syncthreads();
+
+    int why = 4, rounds = 0;   // reason of a failure (index into stats), rounds made
+    bool success = false;
+    double stat_out = 0, prim_out = 0;
+    for (int rnd = 0; rnd < kPolMaxRounds; ++rnd) {
+      rounds = rnd + 1;
+      const unsigned freem = validm & ~(atlb | atub);
+      // ---- (1) x mirror, session projector pieces --------------------------------------------------------------------
+      double nfree[kMaxK], cE[kMaxK];
+      bool son[kMaxK];
+#pragma unroll
+      for (int ks = 0; ks < kMaxK; ++ks) {
+        double nf = 0, sx = 0;
+#pragma unroll
+        for (int k = 0; k < kPolTQ; ++k) {
+          const bool inw = (swm[ks] >> k) & 1u;
+          nf += (inw && ((freem >> k) & 1u)) ? 1.0 : 0.0;
+          sx += inw ? xv[k] : 0.0;
+        }
+        nfree[ks] = pol_quad_sum(nf);
+        cE[ks] = scap[ks] - pol_quad_sum(sx);
+        son[ks] = sact[ks] && nfree[ks] > 0;
+        if (h == 0 && iv) INVN[i * 4 + ks] = son[ks] ? 1.0 / nfree[ks] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < kPolTQ; ++k) {
+        const int t = h * TQ + k;
+        if (iv && k < TQ && t < Tm) {
+          Xs[i * Tm + t] = xv[k];
+          int c = ((freem >> k) & 1u) ? -1 : -2;
+#pragma unroll
+          for (int ks = 0; ks < kMaxK; ++ks) c = (c == -1 && son[ks] && ((swm[ks] >> k) & 1u)) ? ks : c;
+          CS[i * Tm + t] = (signed char)c;
+        }
+      }
+      __syncthreads();
+      // ---- (2) G x ------------------------------------------------------------------------------------------------------
+      for (int k = tid; k < Mg * Tm; k += kPolThreads) {
+        const int j = k / Tm, t = k - j * Tm;
+        double s = 0;
+        for (int e = 0; e < N; ++e) s += Gs[j * N + e] * Xs[e * Tm + t];
+        U[k] = s;
+      }
+      __syncthreads();
+      // ---- (3) rows of the Schur system, period-major (one thread: a few hundred checks) ------------------------------------
+      if (tid == 0) {
+        int m = 0;
+        bool over = false;
+        for (int t = 0; t < Tm; ++t) {
+          TSTART[t] = m;
+          for (int r = 0; r < nrow; ++r) {
+            if (!((RACT[r] >> t) & 1u)) continue;
+            const int j = row_j(r);
+            const double lim = r < M ? A.limits[r] : A.peak[(size_t)b * Tm + t];
+            if (m + 2 > A.max_rows) { over = true; break; }
+            if (row_is_disc(r)) {
+              const double u0 = U[j * Tm + t], u1 = U[(j + M) * Tm + t];
+              const double val = hypot(u0, u1);
+              if (!(val > 1e-12)) continue;
+              const double n0 = u0 / val, n1 = u1 / val, nu = NU[r * Tm + t];
+              RJ[m] = j; RR[m] = r; RT[m] = t; RC0[m] = n0; RC1[m] = n1; RCA[m] = lim - val; RDG[m] = 0.0; ++m;
+              if (nu > kPolTangentMin * qn) {
+                RJ[m] = j; RR[m] = -1 - r; RT[m] = t; RC0[m] = -n1; RC1[m] = n0; RCA[m] = 0.0; RDG[m] = pd * val / nu; ++m;
+              }
+            } else {
+              RJ[m] = j; RR[m] = r; RT[m] = t; RC0[m] = 1.0; RC1[m] = 0.0; RCA[m] = lim - U[j * Tm + t]; RDG[m] = 0.0; ++m;
+            }
+          }
+          if (over) break;
+        }
+        TSTART[Tm] = m;
+        MISC[0] = m;
+        MISC[1] = over ? 1 : 0;
+      }
+      // ---- (4) gradient on the free variables, v_free = -P g + pd e ---------------------------------------------------------
+      double Eg[kMaxK];
+#pragma unroll
+      for (int k = 0; k < kPolTQ; ++k) gv[k] = ((freem >> k) & 1u) ? pd * xv[k] + qv[k] : 0.0;
+#pragma unroll
+      for (int ks = 0; ks < kMaxK; ++ks) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < kPolTQ; ++k) s += (((swm[ks] & freem) >> k) & 1u) ? gv[k] : 0.0;
+        Eg[ks] = pol_quad_sum(s);
+      }
+#pragma unroll
+      for (int k = 0; k < kPolTQ; ++k) {
+        double pg = gv[k], e = 0;
+#pragma unroll
+        for (int ks = 0; ks < kMaxK; ++ks) {
+          const bool in = son[ks] && (((swm[ks] & freem) >> k) & 1u);
+          pg -= in ? Eg[ks] / nfree[ks] : 0.0;
+          e += in ? cE[ks] / nfree[ks] : 0.0;
+        }
+        ev[k] = e;
+        const int t = h * TQ + k;
+        if (iv && k < TQ && t < Tm) Ds[i * Tm + t] = -pg + pd * e;
+      }
+      __syncthreads();
+      const int m = MISC[0];
+      if (MISC[1]) { why = 2; break; }
+      // ---- (5) S = R P R' + diag, rhs = R v_free - pd c_A --------------------------------------------------------------------
+      const double reg = kPolRegRel * pd;
+      for (int a = tid; a < m; a += kPolThreads) {
+        const int ja = RJ[a], ta = RT[a];
+        const double c0 = RC0[a], c1 = RC1[a];
+        double s = 0;
+        for (int e = 0; e < N; ++e) {
+          const double ra = c0 * Gs[ja * N + e] + (c1 != 0.0 ? c1 * Gs[(ja + M) * N + e] : 0.0);
+          s += ra * Ds[e * Tm + ta];
+        }
+        LAM[a] = s - pd * RCA[a];
+      }
+      for (int p = tid; p < m * (m + 1) / 2; p += kPolThreads) {
+        int a = (int)((sqrt(8.0 * (double)p + 1.0) - 1.0) * 0.5);
+        while ((a + 1) * (a + 2) / 2 <= p) ++a;
+        while (a * (a + 1) / 2 > p) --a;
+        const int c = p - a * (a + 1) / 2;   // c <= a
+        const int ja = RJ[a], ta = RT[a], jc = RJ[c], tc = RT[c];
+        const double a0 = RC0[a], a1 = RC1[a], c0 = RC0[c], c1 = RC1[c];
+        double s = 0;
+        for (int e = 0; e < N; ++e) {
+          const int ca = CS[e * Tm + ta], cc = CS[e * Tm + tc];
+          if (ca == -2 || cc == -2) continue;
+          const double ra = a0 * Gs[ja * N + e] + (a1 != 0.0 ? a1 * Gs[(ja + M) * N + e] : 0.0);
+          const double rc = c0 * Gs[jc * N + e] + (c1 != 0.0 ? c1 * Gs[(jc + M) * N + e] : 0.0);
+          double w = ta == tc ? 1.0 : 0.0;
+          if (ca >= 0 && ca == cc) w -= INVN[e * 4 + ca];
+          s += w * ra * rc;
+        }
+        S[p] = s + (a == c ? RDG[a] + reg : 0.0);
+      }
+      __syncthreads();
+      // ---- (6) Cholesky (packed lower, right-looking, a row per thread), two triangular solves -----------------------------------
+      bool bad_pivot = false;
+      for (int k = 0; k < m; ++k) {
+        const double piv = S[k * (k + 1) / 2 + k];
+        if (!(piv > 0.0)) { bad_pivot = true; break; }   // (uniform: every thread reads the same entry)
+        const double dinv = 1.0 / sqrt(piv);
+        const int r = k + 1 + tid;
+        double l = 0;
+        if (r < m) { l = S[r * (r + 1) / 2 + k] * dinv; }
+        __syncthreads();
+        if (r < m) S[r * (r + 1) / 2 + k] = l;
+        if (tid == 0) S[k * (k + 1) / 2 + k] = piv * dinv;
+        __syncthreads();
+        if (r < m) {
+          double* row = S + r * (r + 1) / 2;
+          for (int c = k + 1; c <= r; ++c) row[c] -= l * S[c * (c + 1) / 2 + k];
+        }
+        __syncthreads();
+      }
+      if (bad_pivot) { why = 3; break; }
+      {
+        double acc = tid < m ? LAM[tid] : 0.0;   // forward: L y = rhs
+        for (int k = 0; k < m; ++k) {
+          if (tid == k) LAM[k] = acc / S[k * (k + 1) / 2 + k];
+          __syncthreads();
+          if (tid > k && tid < m) acc -= S[tid * (tid + 1) / 2 + k] * LAM[k];
+        }
+        __syncthreads();
+        acc = tid < m ? LAM[tid] : 0.0;          // backward: L' lam = y
+        for (int k = m - 1; k >= 0; --k) {
+          if (tid == k) LAM[k] = acc / S[k * (k + 1) / 2 + k];
+          __syncthreads();
+          if (tid < k) acc -= S[k * (k + 1) / 2 + tid] * LAM[k];
+        }
+        __syncthreads();
+      }
+      // ---- (7) the step ---------------------------------------------------------------------------------------------------------
+      double rl[kPolTQ];   // (R' lam)(i, t), and of the NORMAL rows alone (the multipliers' part of the gradient)
+      double rn[kPolTQ];
+#pragma unroll
+      for (int k = 0; k < kPolTQ; ++k) {
+        rl[k] = 0; rn[k] = 0;
+        const int t = h * TQ + k;
+        if (iv && k < TQ && t < Tm) {
+          for (int a = TSTART[t]; a < TSTART[t + 1]; ++a) {
+            const int ja = RJ[a];
+            const double c1 = RC1[a];
+            const double ra = RC0[a] * Gs[ja * N + i] + (c1 != 0.0 ? c1 * Gs[(ja + M) * N + i] : 0.0);
+            rl[k] += LAM[a] * ra;
+            rn[k] += RR[a] >= 0 ? LAM[a] * ra : 0.0;
+          }
+        }
+      }
+      double Ev[kMaxK];
+#pragma unroll
+      for (int ks = 0; ks < kMaxK; ++ks) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < kPolTQ; ++k) s += (((swm[ks] & freem) >> k) & 1u) ? gv[k] + rl[k] : 0.0;
+        Ev[ks] = pol_quad_sum(s);
+        smu[ks] = son[ks] ? -(pd * cE[ks] + Ev[ks]) / nfree[ks] : 0.0;
+      }
+      double stepl = 0;
+#pragma unroll
+      for (int k = 0; k < kPolTQ; ++k) {
+        double pv = gv[k] + rl[k];
+#pragma unroll
+        for (int ks = 0; ks < kMaxK; ++ks) pv -= (son[ks] && (((swm[ks] & freem) >> k) & 1u)) ? Ev[ks] / nfree[ks] : 0.0;
+        dv[k] = ((freem >> k) & 1u) ? -pv / pd + ev[k] : 0.0;
+        stepl = fmax(stepl, fabs(dv[k]));
+        const int t = h * TQ + k;
+        if (iv && k < TQ && t < Tm) Ds[i * Tm + t] = dv[k];
+      }
+      __syncthreads();
+      for (int k = tid; k < Mg * Tm; k += kPolThreads) {
+        const int j = k / Tm, t = k - j * Tm;
+        double s = 0;
+        for (int e = 0; e < N; ++e) s += Gs[j * N + e] * Ds[e * Tm + t];
+        DU[k] = s;
+      }
+      __syncthreads();
+      // ---- (8) ratio test against everything outside the working set ---------------------------------------------------------------
+      double alpha = 1.0;
+      int block = -1;
+#pragma unroll
+      for (int k = 0; k < kPolTQ; ++k) {
+        if (!((freem >> k) & 1u)) continue;
+        const int t = h * TQ + k;
+        const double d = dv[k];
+        if (d < -1e-14) {
+          const double a_ = fmax((lbv[k] - xv[k]) / d, 0.0);
+          if (a_ < alpha) { alpha = a_; block = pol_code(kPolLb, i, t); }
+        } else if (d > 1e-14) {
+          const double a_ = fmax((ubv[k] - xv[k]) / d, 0.0);
+          if (a_ < alpha) { alpha = a_; block = pol_code(kPolUb, i, t); }
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < kMaxK; ++ks) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < kPolTQ; ++k) s += ((swm[ks] >> k) & 1u) ? dv[k] : 0.0;
+        const double de = pol_quad_sum(s);
+        if (h == 0 && shas[ks] && !sact[ks] && de > 1e-14) {
+          const double a_ = fmax(cE[ks] / de, 0.0);
+          if (a_ < alpha) { alpha = a_; block = pol_code(kPolSess, i, ks); }
+        }
+      }
+      for (int k = tid; k < nrow * Tm; k += kPolThreads) {
+        const int r = k / Tm, t = k - r * Tm, j = row_j(r);
+        if ((RACT[r] >> t) & 1u) continue;
+        const double lim = r < M ? A.limits[r] : A.peak[(size_t)b * Tm + t];
+        if (!(lim < 1e299)) continue;
+        if (row_is_disc(r)) {
+          const double u0 = U[j * Tm + t], u1 = U[(j + M) * Tm + t], d0 = DU[j * Tm + t], d1 = DU[(j + M) * Tm + t];
+          const double aa = d0 * d0 + d1 * d1, bb = 2.0 * (u0 * d0 + u1 * d1), cc = u0 * u0 + u1 * u1 - lim * lim;
+          if (aa > 1e-28 && (bb > 0 || cc > 0)) {
+            const double dsc = bb * bb - 4.0 * aa * cc;
+            if (dsc >= 0) {
+              const double a_ = fmax((-bb + sqrt(dsc)) / (2.0 * aa), 0.0);
+              if (a_ < alpha) { alpha = a_; block = pol_code(kPolRow, r, t); }
+            }
+          }
+        } else {
+          const double du = DU[j * Tm + t];
+          if (du > 1e-14) {
+            const double a_ = fmax((lim - U[j * Tm + t]) / du, 0.0);
+            if (a_ < alpha) { alpha = a_; block = pol_code(kPolRow, r, t); }
+          }
+        }
+      }
+      pol_block_argmin(alpha, block, RED);
+      if (block < 0) alpha = 1.0;
+      // ---- (9) move; the new multipliers; the blocking constraint joins the working set ------------------------------------------------
+      double xm = 0;
+#pragma unroll
+      for (int k = 0; k < kPolTQ; ++k) { xv[k] += alpha * dv[k]; xm = fmax(xm, fabs(xv[k])); }
+      const double step = pol_block_max(stepl, RED);
+      const double xmax = pol_block_max(xm, RED);
+      for (int k = tid; k < nrow * Tm; k += kPolThreads) NU[k] = 0.0;
+      __syncthreads();
+      for (int a = tid; a < m; a += kPolThreads)
+        if (RR[a] >= 0) NU[RR[a] * Tm + RT[a]] = LAM[a];
+      if (block >= 0) {
+        const int kind = block >> 24, p0 = (block >> 8) & 0xffff, p1 = block & 0xff;
+        if (kind == kPolLb || kind == kPolUb) {
+          if (p0 == i && p1 >= h * TQ && p1 < h * TQ + TQ) {
+            const int k = p1 - h * TQ;
+#pragma unroll
+            for (int kk = 0; kk < kPolTQ; ++kk)
+              if (kk == k) {
+                if (kind == kPolLb) { atlb |= 1u << kk; xv[kk] = lbv[kk]; } else { atub |= 1u << kk; xv[kk] = ubv[kk]; }
+              }
+          }
+        } else if (kind == kPolSess) {
+          if (p0 == i) {
+#pragma unroll
+            for (int ks = 0; ks < kMaxK; ++ks) if (ks == p1) sact[ks] = true;
+          }
+        } else if (tid == 0) {
+          RACT[p0] |= 1u << p1;
+        }
+      }
+      __syncthreads();
+      const bool conv = block < 0 && step <= kPolTolStep * fmax(1.0, xmax);
+      if (!conv) continue;
+      // ---- (10) multipliers of the whole working set: the most negative one leaves; none: verify and finish ---------------------------------
+      double worst = -kPolTolDual * qn;
+      int who = -1;
+      double statl = 0;
+#pragma unroll
+      for (int k = 0; k < kPolTQ; ++k) {
+        double gr = pd * xv[k] + qv[k] + rn[k];
+#pragma unroll
+        for (int ks = 0; ks < kMaxK; ++ks) gr += ((swm[ks] >> k) & 1u) ? smu[ks] : 0.0;
+        gv[k] = gr;
+        const int t = h * TQ + k;
+        if (!((validm >> k) & 1u)) continue;
+        if ((freem >> k) & 1u) { statl = fmax(statl, fabs(gr)); continue; }
+        if ((fixedm >> k) & 1u) continue;
+        if (((atlb >> k) & 1u) && gr < worst) { worst = gr; who = pol_code(kPolLb, i, t); }
+        if (((atub >> k) & 1u) && -gr < worst) { worst = -gr; who = pol_code(kPolUb, i, t); }
+      }
+      if (!eq && h == 0) {
+#pragma unroll
+        for (int ks = 0; ks < kMaxK; ++ks)
+          if (sact[ks] && smu[ks] < worst) { worst = smu[ks]; who = pol_code(kPolSess, i, ks); }
+      }
+      for (int k = tid; k < nrow * Tm; k += kPolThreads) {
+        const int r = k / Tm, t = k - r * Tm;
+        if (((RACT[r] >> t) & 1u) && NU[k] < worst) { worst = NU[k]; who = pol_code(kPolRow, r, t); }
+      }
+      pol_block_argmin(worst, who, RED);
+      if (who >= 0) {
+        const int kind = who >> 24, p0 = (who >> 8) & 0xffff, p1 = who & 0xff;
+        if (kind == kPolLb || kind == kPolUb) {
+          if (p0 == i && p1 >= h * TQ && p1 < h * TQ + TQ) {
+            const int k = p1 - h * TQ;
+            if (kind == kPolLb) atlb &= ~(1u << k); else atub &= ~(1u << k);
+          }
+        } else if (kind == kPolSess) {
+          if (p0 == i) {
+#pragma unroll
+            for (int ks = 0; ks < kMaxK; ++ks) if (ks == p1) sact[ks] = false;
+          }
+        } else if (tid == 0) {
+          RACT[p0] &= ~(1u << p1);
+          NU[p0 * Tm + p1] = 0.0;
+        }
+        __syncthreads();
+        continue;
+      }
+      // ---- KKT on the full problem ------------------------------------------------------------------------------------------------------------
+      const double stat = pol_block_max(statl, RED);
+      double pvl = 0;
+#pragma unroll
+      for (int ks = 0; ks < kMaxK; ++ks) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < kPolTQ; ++k) s += ((swm[ks] >> k) & 1u) ? xv[k] : 0.0;
+        const double d = pol_quad_sum(s) - scap[ks];
+        if (shas[ks]) pvl = fmax(pvl, (eq ? fabs(d) : d) / fmax(1.0, fabs(scap[ks])));
+      }
+#pragma unroll
+      for (int k = 0; k < kPolTQ; ++k) {
+        const int t = h * TQ + k;
+        if (iv && k < TQ && t < Tm) Xs[i * Tm + t] = xv[k];
+      }
+      __syncthreads();
+      for (int k = tid; k < Mg * Tm; k += kPolThreads) {
+        const int j = k / Tm, t = k - j * Tm;
+        double s = 0;
+        for (int e = 0; e < N; ++e) s += Gs[j * N + e] * Xs[e * Tm + t];
+        U[k] = s;
+      }
+      __syncthreads();
+      for (int k = tid; k < nrow * Tm; k += kPolThreads) {
+        const int r = k / Tm, t = k - r * Tm, j = row_j(r);
+        const double lim = r < M ? A.limits[r] : A.peak[(size_t)b * Tm + t];
+        if (!(lim < 1e299)) continue;
+        const double val = row_is_disc(r) ? hypot(U[j * Tm + t], U[(j + M) * Tm + t]) : U[j * Tm + t];
+        pvl = fmax(pvl, (val - lim) / fmax(1.0, lim));
+      }
+      const double pv = pol_block_max(pvl, RED);
+      stat_out = stat; prim_out = pv;
+      success = stat <= 1e-8 * qn && pv <= 10.0 * kPolTolPrimal;
+      why = 5;
+      break;
+    }
+    // ---- results -----------------------------------------------------------------------------------------------------------------------------------
+    if (success) {
+      double ol = 0;
+#pragma unroll
+      for (int k = 0; k < kPolTQ; ++k) {
+        const int t = h * TQ + k;
+        if (iv && k < TQ && t < Tm) {
+          A.x[((size_t)b * N + i) * Tm + t] = xv[k];
+          ol += (0.5 * pd_user * xv[k] + qv[k]) * xv[k];
+        }
+      }
+      const double o = pol_block_sum(ol, RED);
+      // site-row multipliers in the caller's units (a disc's pair: nu times its outward normal, at the final x: U is current)
+      for (int k = tid; k < Mg * Tm; k += kPolThreads) A.y[(size_t)b * Mg * Tm + k] = 0.0;
+      __syncthreads();
+      for (int k = tid; k < nrow * Tm; k += kPolThreads) {
+        const int r = k / Tm, t = k - r * Tm, j = row_j(r);
+        const double nu = NU[k];
+        if (nu == 0.0) continue;
+        if (row_is_disc(r)) {
+          const double u0 = U[j * Tm + t], u1 = U[(j + M) * Tm + t], val = hypot(u0, u1);
+          if (val > 0) {
+            A.y[((size_t)b * Mg + j) * Tm + t] = nu * u0 / val;
+            A.y[((size_t)b * Mg + j + M) * Tm + t] = nu * u1 / val;
+          }
+        } else {
+          A.y[((size_t)b * Mg + j) * Tm + t] = nu;
+        }
+      }
+      if (tid == 0) {
+        A.status[b] = 1;
+        A.iters[b] += rounds;
+        A.pri[b] = fmax(prim_out, 0.0);
+        A.dua[b] = stat_out;
+        A.obj[b] = o;
+        atomicAdd(A.stats + 1, 1);
+      }
+    } else if (tid == 0) {
+      A.iters[b] += rounds;
+      atomicAdd(A.stats + why, 1);
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace acnqp

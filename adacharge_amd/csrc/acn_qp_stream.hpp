@@ -118,7 +118,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel
   // pass-invariant address, predicate or argument is kept alive across the solver loop.
   __shared__ int q_slot;
   for (int q_round = 0;; ++q_round) {   // work queue: this workgroup's next problem (queue_next, acn_qp_tiled.hpp)
-  const int q_pos = queue_next(SA_kernarg.t.queue, SA_kernarg.t.B, q_round, &q_slot);
+  const int q_pos = queue_next(SA_kernarg.t.queue, queue_length(SA_kernarg.t), q_round, &q_slot);
   if (q_pos < 0) break;
   int it_total = 0, best_status = 0;
   for (int pass = 0;; ++pass) {

@@ -47,6 +47,7 @@ __device__ unsigned long long g_stamps[1024 * 16 * 12];
 #endif
 
 constexpr int kMaxK = 4;       // session slots per EVSE
+constexpr int kStatusPolish = 6;   // internal status: "left to the polish kernel" (never returned to a caller)
 constexpr int kNumRed = 8;
 
 // row types of the (internally ordered) site rows
@@ -94,6 +95,13 @@ struct TiledArgs {
   int stall_iters, retry_passes, retry_max_iter;
   double inacc_floor, retry_rho;
   int pbuf_single; // 1: one partial-tile slab instead of two (one more barrier per iteration, LDS for one more ring column)
+  // -- the polish (acn_qp_polish.hpp): a pass-0 problem that has not converged after polish_iters iterations (0 = off) leaves
+  //    the solver kernel with the internal status kStatusPolish, its iterate in x / y_out, and its index appended to pol_list;
+  //    `resume` = 1 is the launch that follows the polish kernel: it runs over pol_list (order = pol_list, count_dev = its
+  //    length, on the device), skips what the polish solved and solves the rest from scratch as if there were no polish
+  int polish_iters, resume;
+  int32_t *pol_list, *pol_count;
+  const int32_t* count_dev;   // number of queue positions, on the device (null: B)
   int ws_by_slot;  // 1: a streaming kernel's workspace belongs to the workgroup slot (work-queue launches), 0: to the problem
   int grid_cap;    // host side only: most workgroups a launch may have (the kernels that stream their state own one
                    // workspace per workgroup slot)
@@ -110,6 +118,11 @@ typedef const __attribute__((address_space(4))) TiledArgs* KernargPtr;   // the 
 // workgroup.  `round` counts this workgroup's fetches (the static fallback serves exactly one).  Both barriers are
 // needed: the first publishes the slot, the second keeps a fast wave's next fetch from overwriting it before a slow wave
 // has read it -- and orders the previous problem's last LDS reads before the next problem's first LDS writes.
+__device__ inline int queue_length(const TiledArgs& a) {
+  if (a.count_dev == nullptr) return a.B;
+  const int n = *a.count_dev;
+  return n < a.B ? n : a.B;
+}
 __device__ inline int queue_next(int32_t* queue, int B, int round, int* slot_lds) {
   if (queue == nullptr) return round == 0 && (int)blockIdx.x < B ? (int)blockIdx.x : -1;
   if (threadIdx.x == 0) *slot_lds = atomicAdd(queue, 1);
@@ -380,7 +393,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   // passes, so the compiler keeps no pass-invariant value (addresses, predicates) alive across the solver loop.
   __shared__ int q_slot;
   for (int q_round = 0;; ++q_round) {   // work queue: this workgroup's next problem (queue_next)
-  const int q_pos = queue_next(A_kernarg.queue, A_kernarg.B, q_round, &q_slot);
+  const int q_pos = queue_next(A_kernarg.queue, queue_length(A_kernarg), q_round, &q_slot);
   if (q_pos < 0) break;
   int it_total = 0, best_status = 0;
   for (int pass = 0;; ++pass) {
@@ -397,6 +410,10 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
   const auto& A = *Ap;
   (void)A_kernarg;
   const int b = __builtin_amdgcn_readfirstlane(A.order ? A.order[wg_] : wg_);   // the problem this workgroup solves (a uniform value: the load alone would make it a vector register)
+  if (A.resume) {   // the launch behind the polish kernel: what it solved is done; the rest starts over (block-uniform)
+    if (A.status[b] != kStatusPolish && pass == 0) break;
+    if (pass == 0) it_total = A.iters[b];
+  }
   const int max_iter_p = pass == 0 ? A.max_iter : min(A.max_iter, A.retry_max_iter);
   const int adapt_p = pass == 0 ? A.adapt_every : 0;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave index as a SCALAR: `if (wave == 0)` is a scalar branch,
@@ -1563,6 +1580,9 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
       const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel, A.inacc_floor);
       const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= (real)scalar_const(kStallNear) * best_score;
       if (done) {
+      } else if (pass == 0 && A.polish_iters > 0 && it >= A.polish_iters) {
+        status = kStatusPolish;   // not converged after polish_iters iterations: the polish kernel takes over from (z1, y2)
+        done = true;
       } else if (it >= max_iter_p || stalled) {
         done = true;
         if (inacc) status = 5;   // solved, inaccurately
@@ -1645,6 +1665,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
     A.pri[b] = (double)pri;
     A.dua[b] = (double)dua;
     A.obj[b] = (double)o;
+    if (status == kStatusPolish) A.pol_list[atomicAdd(A.pol_count, 1)] = b;
   }
   __syncthreads();   // Red is reused by the next pass
   }

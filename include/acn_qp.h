@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define ACNQP_ABI_VERSION 7
+#define ACNQP_ABI_VERSION 8
 
 /* cone of the infrastructure rows (constraint_type at aco.py:35, 151, 165) */
 #define ACNQP_CONE_LINEAR 0
@@ -171,7 +171,18 @@ typedef struct {
                             Only when adapt_every > 0 (a caller who fixed the penalty gets that penalty only).
                             Why it works: DESIGN.md section 2 (the plateau is the adaptive penalty's doing)  */
   int32_t retry_max_iter;/* iteration limit of a retry pass (min with max_iter).  Default 8000            */
-  int32_t reserved_;     /* must be 0                                                                     */
+  /* -- ABI v8 ------------------------------------------------------------------------------------------ */
+  int32_t polish_iters;  /* a problem of a small site (N <= 64, horizon <= 32, <= 4 sessions per EVSE, no load-flattening /
+                            demand-charge row, cold start) that has not converged after this many ADMM iterations is
+                            handed to the POLISH: an active-set Newton method on the KKT conditions that starts from the
+                            working set the ADMM iterate suggests (variables on a bound, tight energy rows, site rows with a
+                            non-zero multiplier) -- a few dozen small dense solves in one workgroup, inside the same call.
+                            Its answer is accepted only with the KKT conditions verified on the full problem (status
+                            SOLVED, residuals of that check in pri_res / dua_res, iters = ADMM iterations + Newton
+                            rounds); otherwise the problem is solved as if there were no polish (from scratch, with the
+                            retry passes).  What an interior-point method -- the reference's ECOS, aco.py:318 -- gives
+                            for free: no plateau on the congested, tangentially degenerate instances.  0 = off.
+                            Default 1200                                                                     */
   double retry_rho;      /* penalty of the first retry pass.  Default 0.5                                 */
   double inaccurate_floor; /* residual tolerance (absolute and relative) below which a pass that ran out of
                             iterations still counts as SOLVED_INACCURATE even when 100x the requested tolerance
@@ -250,6 +261,11 @@ int64_t acnqp_launch_count(acnqp_handle* h);
  * atomic counter per launch); ACNQP_NO_QUEUE=1 / ACNQP_NO_ORDER=1 in the environment select the static schedule / the
  * natural order (diagnostics: results do not depend on either).                                                    */
 int64_t acnqp_ordered_launch_count(acnqp_handle* h);
+
+/* Counters of the polish over the handle's life (synchronises the device): out[0] problems handed to the polish,
+ * out[1] solved by it, out[2..5] given up because of: more tight site rows than its LDS holds, a non-positive pivot,
+ * the round limit, the final KKT check.  Returns ACNQP_OK.  Bench / test plumbing.                                   */
+int acnqp_polish_stats(acnqp_handle* h, int64_t* out, int32_t capacity);
 
 /* Anderson columns the kernels will actually use for problems of this shape
  * (t_max periods, k_sessions slots) at the given precision when `requested`

@@ -88,8 +88,10 @@ def test_default_surface_is_within_tolerance_of_the_certificate_whatever_the_sta
 @pytest.mark.gpu
 @pytest.mark.parametrize("T", [12, 24])
 def test_c_abi_alone_reaches_the_certificates(T):
-    """acnqp_solve_batch with acnqp_default_options -- no Python-side second pass exists any more: every stalled
-    instance of one horizon in ONE call; with retry_passes = 0 the same call leaves stalled problems behind."""
+    """acnqp_solve_batch with acnqp_default_options: every stalled instance of one horizon in ONE call.  Round 4: the
+    device-side polish (options.polish_iters, acn_qp_polish.hpp) takes them over after 1,200 ADMM iterations -- every case
+    SOLVED with retry_passes = 0, in a fraction of the iterations the retry passes needed; with the polish off the
+    retry passes still reach the certificates, and with both off the same call leaves stalled problems behind."""
     from adacharge_amd.backend import SiteHandle, default_options
 
     g = H.load_stalled()
@@ -98,17 +100,38 @@ def test_c_abi_alone_reaches_the_certificates(T):
     infra, iface, meta = cases[0][1], cases[0][2], cases[0][3]
     batch = build_batch([c[0] for c in cases], infra, iface, _objective(meta), "SOC")
     h = SiteHandle(batch.site, 0)
+
+    def worst_of(res):
+        return [float(np.abs(res.x[b][:, :c[5]["rates"].shape[1]] - c[5]["rates"]).max()) for b, c in enumerate(cases)]
+
+    # ---- default options
+    before = h.polish_stats()
     res = h.solve(batch, default_options())
-    worst = [float(np.abs(res.x[b][:, :c[5]["rates"].shape[1]] - c[5]["rates"]).max()) for b, c in enumerate(cases)]
-    assert np.isin(res.status, (1, 5)).all(), res.status
-    assert max(worst) <= RATE_TOL, list(zip(names, res.status.tolist(), res.iters.tolist(), worst))
+    after = h.polish_stats()
     assert (res.status == 1).all(), list(zip(names, res.status.tolist(), res.iters.tolist()))
-    single = h.solve(batch, default_options(retry_passes=0))
-    assert (single.iters <= res.iters).all()
+    assert max(worst_of(res)) <= RATE_TOL, list(zip(names, res.status.tolist(), res.iters.tolist(), worst_of(res)))
+    tried, won = after["attempted"] - before["attempted"], after["solved"] - before["solved"]
+    if T == 12:
+        # ---- the polish alone (every case SOLVED with retry_passes = 0)
+        alone = h.solve(batch, default_options(retry_passes=0))
+        assert (alone.status == 1).all() and np.array_equal(res.x, alone.x) and np.array_equal(res.iters, alone.iters)
+        assert tried >= 8 and won == tried, (before, after)
+        assert res.iters.max() <= 1200 + 96, res.iters      # ADMM iterations up to the hand-over + Newton rounds
+        assert (res.pri_res <= 1e-7).all() and (res.dua_res <= 1e-7).all()
+    else:
+        # horizon 24: one of the three has more tight site rows (198 with their tangent rows) than the polish's LDS holds
+        # (168 on this site); it takes the fallback -- the solve as it was before there was a polish
+        assert tried >= 2 and won >= tried - 1 and after["gave_up_rows"] - before["gave_up_rows"] == tried - won, (before, after)
+    # ---- the polish off: the retry passes of round 3 (the fallback) still reach every certificate
+    retry = h.solve(batch, default_options(polish_iters=0))
+    assert (retry.status == 1).all() and max(worst_of(retry)) <= RATE_TOL
+    assert retry.iters.max() > 3000 and retry.iters.sum() > 2 * res.iters.sum()
+    # ---- both off: the same call leaves stalled problems behind
+    single = h.solve(batch, default_options(retry_passes=0, polish_iters=0))
     stalled = np.isin(single.status, (2, 5)) & (single.iters >= 3000)
-    assert stalled.any(), single.status     # the fixture exercises the retry on the device as well
-    assert (res.iters[stalled] > single.iters[stalled]).all()
-    # the device entry point (HBM-resident buffers, caller's stream) runs the same passes
+    assert stalled.any(), single.status
+    assert (retry.iters[stalled] > single.iters[stalled]).all()
+    # the device entry point (HBM-resident buffers, caller's stream) runs the same three launches
     import torch
     from adacharge_amd.backend import DeviceBatch
 
@@ -118,3 +141,30 @@ def test_c_abi_alone_reaches_the_certificates(T):
     assert np.array_equal(dev.status.cpu().numpy(), res.status) and np.array_equal(dev.iters.cpu().numpy(), res.iters)
     assert np.array_equal(dev.x.cpu().numpy(), res.x)
     h.close()
+
+
+@pytest.mark.gpu
+def test_polish_agrees_with_its_numpy_specification():
+    """oracle/polish_ref.py restates the polish kernel; started from the ADMM iterate the DEVICE hands over (the same call
+    with the polish's answer discarded: polish_iters = max_iter - 1 is not reachable, so the hand-over point is rebuilt
+    with max_iter = 1200, retry_passes = 0), both reach the same optimum on every stalled instance of horizon 12."""
+    from adacharge_amd.backend import SiteHandle, default_options
+    from oracle.polish_ref import polish_batch_problem
+
+    g = H.load_stalled()
+    names = [n for n in NAMES if int(g[f"{n}_meta"][0]) == 12]
+    cases = [H.wide_case(g, n) for n in names]
+    infra, iface, meta = cases[0][1], cases[0][2], cases[0][3]
+    batch = build_batch([c[0] for c in cases], infra, iface, _objective(meta), "SOC")
+    h = SiteHandle(batch.site, 0)
+    handed = h.solve(batch, default_options(max_iter=1200, retry_passes=0, polish_iters=0), want_y=True)   # the iterate at 1,200
+    res = h.solve(batch, default_options(retry_passes=0), want_y=True)                                       # ... and polished
+    h.close()
+    for b, c in enumerate(cases):
+        if handed.status[b] == 1:
+            continue
+        xs, info = polish_batch_problem(batch, b, handed.x[b], handed.y[b])
+        T = xs.shape[1]
+        assert info["ok"], (names[b], info)
+        assert np.abs(xs - res.x[b][:, :T]).max() <= 1e-7, (names[b], float(np.abs(xs - res.x[b][:, :T]).max()))
+        assert np.abs(info["y"] - res.y[b][:, :T]).max() <= 1e-5 * max(1.0, float(np.abs(info["y"]).max())), names[b]

@@ -1,0 +1,34 @@
+"""The device-side polish on the workloads where stragglers set the launch time: per leg, one
+device-resident launch with the polish on (default), off (ACN round-3 behaviour: retry passes), and the polish's
+counters.    python3 tools/gpu_polish.py [leg ...]   (legs of bench.other_workloads; default: the on-chip ones)"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from adacharge_amd.backend import DeviceBatch, SiteHandle, default_options
+
+legs = sys.argv[1:] or ["cfg3_site3_T12_b1024", "cfg3_site0_T12_b1024", "cfg2_caltech54_T24_b4096", "cfg2_jpl52_T24_b4096"]
+dev = torch.device("cuda", 0)
+for leg in legs:
+    batch, opts, streamed, note = bench.other_workloads()[leg]()
+    out = {"leg": leg, "batch": batch.B}
+    ref = None
+    for name, o in (("polish", default_options()), ("no_polish", default_options(polish_iters=0)), ("polish_600", default_options(polish_iters=600))):
+        h = SiteHandle(batch.site, 0)
+        db = DeviceBatch(batch, dev)
+        ms = []
+        for _ in range(3):
+            h.solve_device(db, o, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            ms.append(h.last_kernel_ms())
+        it, st, x = db.iters.cpu().numpy(), db.status.cpu().numpy(), db.x.cpu().numpy()
+        stats = h.polish_stats()
+        h.close()
+        if ref is None and name == "polish":
+            ref = x
+        out[name] = {"ms": round(min(ms[1:]), 3), "iters_mean": round(float(it.mean()), 1), "iters_max": int(it.max()),
+                     "solved": int((st == 1).sum()), "inaccurate": int((st == 5).sum()), "other": int((~np.isin(st, (1, 5))).sum()),
+                     "polish": {k: v // 3 for k, v in stats.items()}}
+        if name != "polish":
+            out[name]["max_abs_diff_vs_polish_A"] = float(np.abs(x - ref).max())
+    print(json.dumps(out), flush=True)
