@@ -447,9 +447,11 @@ class SiteHandle:
 
     def polish_stats(self) -> dict:
         """Counters of the device-side polish over this handle's life (acnqp_polish_stats; synchronises)."""
-        buf = (C.c_int64 * 6)()
-        _check(self._lib.acnqp_polish_stats(self._h, buf, 6), "acnqp_polish_stats")
-        return dict(zip(("attempted", "solved", "gave_up_rows", "gave_up_pivot", "gave_up_rounds", "gave_up_kkt"), [int(v) for v in buf]))
+        buf = (C.c_int64 * 16)()
+        _check(self._lib.acnqp_polish_stats(self._h, buf, 16), "acnqp_polish_stats")
+        out = dict(zip(("attempted", "solved", "gave_up_rows", "gave_up_pivot", "gave_up_rounds", "gave_up_kkt", "rounds"), [int(v) for v in buf[:7]]))
+        out["phase_us"] = [int(v) // 100 for v in buf[8:16]]   # summed over the polish workgroups
+        return out
 
     def ordered_launches(self) -> int:
         """Launches of this handle whose queue order was sorted by session count (acnqp_ordered_launch_count)."""

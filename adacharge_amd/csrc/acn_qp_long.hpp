@@ -1160,8 +1160,37 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       if (score < kStallGain * best_score) { best_score = score; best_it = it; }
       const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel, A.inacc_floor);
       const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= kStallNear * best_score;   // acn_qp_tiled.hpp
+      bool hand_over = false;
+      if (!done && pass == 0 && A.polish_iters > 0 && it >= A.polish_iters) {   // block-uniform
+        // rows the polish's Schur system would have (acn_qp_tiled.hpp): more than it holds -> the ADMM goes on
+        real cnt = 0;
+        const real ytol = 1e-9 * fmax(1.0, qnorm);
+#pragma unroll 1
+        for (int q = wave; q < n_site; q += NWV) {
+          RELANE();
+          const int m = __builtin_amdgcn_readfirstlane(q / nct), c = q - m * nct;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 16 * m + M::rowof(g, r);
+            const int ty = RowTy[j];
+            const real yr = at(Y2, sidx2(m, c, r)), yi = at(Y2, sidx2(m, c, (r + 1) & 3));
+            const bool disc = ty == kRowSocRe;
+            const real mag = disc ? sqrt(yr * yr + yi * yi) : yr;
+            const bool counts = (disc || ty == kRowBox || ty == kRowPeak) && 16 * c + t < Tm && mag > ytol;
+            cnt += counts ? (disc ? 2.0 : 1.0) : 0.0;
+          }
+        }
+        cnt = wave_sum<real>(cnt);
+        __syncthreads();
+        if (lane == 0) SC[wave] = cnt;
+        __syncthreads();
+        real tot = 0;
+        for (int wv = 0; wv < NWV; ++wv) tot += SC[wv];
+        __syncthreads();
+        hand_over = tot + 8.0 <= (real)A.pol_rows;
+      }
       if (done) {
-      } else if (pass == 0 && A.polish_iters > 0 && it >= A.polish_iters) {
+      } else if (hand_over) {
         status = kStatusPolish;   // not converged after polish_iters iterations: the polish kernel takes over (acn_qp_polish.hpp)
         done = true;
       } else if (it >= max_iter_p || stalled) {

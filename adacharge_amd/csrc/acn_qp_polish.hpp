@@ -27,7 +27,8 @@ constexpr int kPolTQ = 8;            // periods per thread (Tm <= 32)
 constexpr int kPolMaxRounds = 96;
 constexpr double kPolTolBound = 1e-7;    // |x - bound| below which the ADMM iterate counts as "on the bound"
 constexpr double kPolTolRow = 1e-9;      // relative size of a site-row multiplier that counts as non-zero
-constexpr double kPolTolStep = 1e-9;     // convergence of a round: |dx|_inf <= tol max(1, |x|_inf)
+constexpr double kPolTolStep = 1e-7;     // convergence of a round: |dx|_inf <= tol max(1, |x|_inf) (1e-9 sat below the noise the
+                                         // regularised solve leaves in dx on the degenerate instances: six idle rounds; the KKT check decides)
 constexpr double kPolTolDual = 1e-9;     // a multiplier below -tol max(1, |q|_inf) leaves the working set
 constexpr double kPolTolPrimal = 1e-9;   // accepted violation of a row, relative to max(1, limit)
 constexpr double kPolRegRel = 1e-9;      // dual regularisation of the Schur system, relative to pd
@@ -238,6 +239,10 @@ __global__ __launch_bounds__(kPolThreads, 1) void polish_kernel(const PolishArgs
     __syncthreads();
 
     int why = 4, rounds = 0;   // reason of a failure (index into stats), rounds made
+    // coarse phase clock (thread 0, 100 MHz ticks summed into stats[8 + phase]): where a polish spends its time
+    unsigned long long tick = wall_clock64();
+    unsigned tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define POL_TICK(ph) do { const unsigned long long _n = wall_clock64(); tacc[ph] += (unsigned)(_n - tick); tick = _n; } while (0)
     bool success = false;
     double stat_out = 0, prim_out = 0;
     for (int rnd = 0; rnd < kPolMaxRounds; ++rnd) {
@@ -280,35 +285,55 @@ __global__ __launch_bounds__(kPolThreads, 1) void polish_kernel(const PolishArgs
         U[k] = s;
       }
       __syncthreads();
-      // ---- (3) rows of the Schur system, period-major (one thread: a few hundred checks) ------------------------------------
-      if (tid == 0) {
-        int m = 0;
+      // ---- (3) rows of the Schur system, period-major: pair k = t nrow + r of (period, site row) -> 0 / 1 / 2 rows (a tight
+      // disc: its normal row and, with a multiplier worth it, its tangent row); offsets by a block-wide exclusive scan
+      {
+        int base = 0;
         bool over = false;
-        for (int t = 0; t < Tm; ++t) {
-          TSTART[t] = m;
-          for (int r = 0; r < nrow; ++r) {
-            if (!((RACT[r] >> t) & 1u)) continue;
-            const int j = row_j(r);
-            const double lim = r < M ? A.limits[r] : A.peak[(size_t)b * Tm + t];
-            if (m + 2 > A.max_rows) { over = true; break; }
+        for (int k0 = 0; k0 < nrow * Tm; k0 += kPolThreads) {
+          const int k = k0 + tid;
+          const bool in = k < nrow * Tm;
+          const int t = in ? k / nrow : 0, r = in ? k - t * nrow : 0, j = row_j(r);
+          int need = 0;
+          double lim = 0, u0 = 0, u1 = 0, val = 0, nu = 0;
+          if (in && ((RACT[r] >> t) & 1u)) {
+            lim = r < M ? A.limits[r] : A.peak[(size_t)b * Tm + t];
             if (row_is_disc(r)) {
-              const double u0 = U[j * Tm + t], u1 = U[(j + M) * Tm + t];
-              const double val = hypot(u0, u1);
-              if (!(val > 1e-12)) continue;
-              const double n0 = u0 / val, n1 = u1 / val, nu = NU[r * Tm + t];
-              RJ[m] = j; RR[m] = r; RT[m] = t; RC0[m] = n0; RC1[m] = n1; RCA[m] = lim - val; RDG[m] = 0.0; ++m;
-              if (nu > kPolTangentMin * qn) {
-                RJ[m] = j; RR[m] = -1 - r; RT[m] = t; RC0[m] = -n1; RC1[m] = n0; RCA[m] = 0.0; RDG[m] = pd * val / nu; ++m;
-              }
+              u0 = U[j * Tm + t]; u1 = U[(j + M) * Tm + t];
+              val = hypot(u0, u1);
+              nu = NU[r * Tm + t];
+              need = val > 1e-12 ? (nu > kPolTangentMin * qn ? 2 : 1) : 0;
             } else {
-              RJ[m] = j; RR[m] = r; RT[m] = t; RC0[m] = 1.0; RC1[m] = 0.0; RCA[m] = lim - U[j * Tm + t]; RDG[m] = 0.0; ++m;
+              need = 1;
             }
           }
-          if (over) break;
+          int incl = need;
+          for (int o = 1; o < 64; o <<= 1) { const int nb = __shfl_up(incl, o); incl += (tid & 63) >= o ? nb : 0; }
+          int* WT = reinterpret_cast<int*>(RED);
+          __syncthreads();
+          if ((tid & 63) == 63) WT[tid >> 6] = incl;
+          __syncthreads();
+          int before = base;
+          for (int w = 0; w < (tid >> 6); ++w) before += WT[w];
+          const int total = WT[0] + WT[1] + WT[2] + WT[3];
+          const int m0 = before + incl - need;
+          if (in && r == 0) TSTART[t] = m0;
+          if (base + total > A.max_rows) { over = true; break; }   // (block-uniform)
+          if (need >= 1) {
+            if (row_is_disc(r)) {
+              const double n0 = u0 / val, n1 = u1 / val;
+              RJ[m0] = j; RR[m0] = r; RT[m0] = t; RC0[m0] = n0; RC1[m0] = n1; RCA[m0] = lim - val; RDG[m0] = 0.0;
+              if (need == 2) {
+                RJ[m0 + 1] = j; RR[m0 + 1] = -1 - r; RT[m0 + 1] = t; RC0[m0 + 1] = -n1; RC1[m0 + 1] = n0; RCA[m0 + 1] = 0.0;
+                RDG[m0 + 1] = pd * val / nu;
+              }
+            } else {
+              RJ[m0] = j; RR[m0] = r; RT[m0] = t; RC0[m0] = 1.0; RC1[m0] = 0.0; RCA[m0] = lim - U[j * Tm + t]; RDG[m0] = 0.0;
+            }
+          }
+          base += total;
         }
-        TSTART[Tm] = m;
-        MISC[0] = m;
-        MISC[1] = over ? 1 : 0;
+        if (tid == 0) { TSTART[Tm] = base; MISC[0] = base; MISC[1] = over ? 1 : 0; }
       }
       // ---- (4) gradient on the free variables, v_free = -P g + pd e ---------------------------------------------------------
       double Eg[kMaxK];
@@ -337,6 +362,7 @@ __global__ __launch_bounds__(kPolThreads, 1) void polish_kernel(const PolishArgs
       __syncthreads();
       const int m = MISC[0];
       if (MISC[1]) { why = 2; break; }
+      POL_TICK(0);
       // ---- (5) S = R P R' + diag, rhs = R v_free - pd c_A --------------------------------------------------------------------
       const double reg = kPolRegRel * pd;
       for (int a = tid; a < m; a += kPolThreads) {
@@ -369,42 +395,48 @@ __global__ __launch_bounds__(kPolThreads, 1) void polish_kernel(const PolishArgs
         S[p] = s + (a == c ? RDG[a] + reg : 0.0);
       }
       __syncthreads();
-      // ---- (6) Cholesky (packed lower, right-looking, a row per thread), two triangular solves -----------------------------------
+      POL_TICK(1);
+      // ---- (6) Cholesky (packed lower, right-looking), two triangular solves -----------------------------------------------------
+      // S = L D L' in place (unit lower L stored unscaled: L[r][k] = S[r][k] / D[k], D[k] = S[k][k] after the updates of the
+      // columns before it): ONE barrier per column -- column k and its pivot are only read in step k, the trailing
+      // update only writes columns beyond it -- and no square root.  16 x 16 threads over (row, column) of the trailing
+      // block: a row per thread put m^2 / 2 dependent LDS read-modify-writes on the last row's thread (it WAS the polish's
+      // time: 0.5 ms per round).
       bool bad_pivot = false;
       for (int k = 0; k < m; ++k) {
+        __syncthreads();
         const double piv = S[k * (k + 1) / 2 + k];
         if (!(piv > 0.0)) { bad_pivot = true; break; }   // (uniform: every thread reads the same entry)
-        const double dinv = 1.0 / sqrt(piv);
-        const int r = k + 1 + tid;
-        double l = 0;
-        if (r < m) { l = S[r * (r + 1) / 2 + k] * dinv; }
-        __syncthreads();
-        if (r < m) S[r * (r + 1) / 2 + k] = l;
-        if (tid == 0) S[k * (k + 1) / 2 + k] = piv * dinv;
-        __syncthreads();
-        if (r < m) {
-          double* row = S + r * (r + 1) / 2;
-          for (int c = k + 1; c <= r; ++c) row[c] -= l * S[c * (c + 1) / 2 + k];
+        const double pinv = 1.0 / piv;
+        for (int rr = k + 1 + (tid >> 4); rr < m; rr += 16) {
+          const double lr = S[rr * (rr + 1) / 2 + k] * pinv;
+          double* row = S + rr * (rr + 1) / 2;
+          for (int c = k + 1 + (tid & 15); c <= rr; c += 16) row[c] -= lr * S[c * (c + 1) / 2 + k];
         }
-        __syncthreads();
       }
       if (bad_pivot) { why = 3; break; }
+      POL_TICK(2);
       {
-        double acc = tid < m ? LAM[tid] : 0.0;   // forward: L y = rhs
+        __syncthreads();
+        for (int k = tid; k < m; k += kPolThreads) RDG[k] = 1.0 / S[k * (k + 1) / 2 + k];   // 1 / D (the rows' diagonal terms are in S by now)
+        __syncthreads();
+        double acc = tid < m ? LAM[tid] : 0.0;   // forward: L z = rhs (thread r owns z_r)
         for (int k = 0; k < m; ++k) {
-          if (tid == k) LAM[k] = acc / S[k * (k + 1) / 2 + k];
+          if (tid == k) LAM[k] = acc;
           __syncthreads();
-          if (tid > k && tid < m) acc -= S[tid * (tid + 1) / 2 + k] * LAM[k];
+          if (tid > k && tid < m) acc -= S[tid * (tid + 1) / 2 + k] * RDG[k] * LAM[k];
         }
         __syncthreads();
-        acc = tid < m ? LAM[tid] : 0.0;          // backward: L' lam = y
+        acc = tid < m ? LAM[tid] * RDG[tid] : 0.0;   // w = D^-1 z; backward: L' lam = w
+        const double dme = tid < m ? RDG[tid] : 0.0;
         for (int k = m - 1; k >= 0; --k) {
-          if (tid == k) LAM[k] = acc / S[k * (k + 1) / 2 + k];
+          if (tid == k) LAM[k] = acc;
           __syncthreads();
-          if (tid < k) acc -= S[k * (k + 1) / 2 + tid] * LAM[k];
+          if (tid < k) acc -= S[k * (k + 1) / 2 + tid] * dme * LAM[k];
         }
         __syncthreads();
       }
+      POL_TICK(3);
       // ---- (7) the step ---------------------------------------------------------------------------------------------------------
       double rl[kPolTQ];   // (R' lam)(i, t), and of the NORMAL rows alone (the multipliers' part of the gradient)
       double rn[kPolTQ];
@@ -450,6 +482,7 @@ __global__ __launch_bounds__(kPolThreads, 1) void polish_kernel(const PolishArgs
         DU[k] = s;
       }
       __syncthreads();
+      POL_TICK(4);
       // ---- (8) ratio test against everything outside the working set ---------------------------------------------------------------
       double alpha = 1.0;
       int block = -1;
@@ -502,6 +535,7 @@ __global__ __launch_bounds__(kPolThreads, 1) void polish_kernel(const PolishArgs
       }
       pol_block_argmin(alpha, block, RED);
       if (block < 0) alpha = 1.0;
+      POL_TICK(5);
       // ---- (9) move; the new multipliers; the blocking constraint joins the working set ------------------------------------------------
       double xm = 0;
 #pragma unroll
@@ -534,6 +568,7 @@ __global__ __launch_bounds__(kPolThreads, 1) void polish_kernel(const PolishArgs
       }
       __syncthreads();
       const bool conv = block < 0 && step <= kPolTolStep * fmax(1.0, xmax);
+      POL_TICK(6);
       if (!conv) continue;
       // ---- (10) multipliers of the whole working set: the most negative one leaves; none: verify and finish ---------------------------------
       double worst = -kPolTolDual * qn;
@@ -581,8 +616,8 @@ __global__ __launch_bounds__(kPolThreads, 1) void polish_kernel(const PolishArgs
         __syncthreads();
         continue;
       }
-      // ---- KKT on the full problem ------------------------------------------------------------------------------------------------------------
-      const double stat = pol_block_max(statl, RED);
+      // ---- KKT on the full problem, at the final x: G x again, the discs' normals from it (the step's rows carry the normals of
+      // the point BEFORE the step: nu (n_new - n_old) is 4e-8 after a step of 3e-6 A, above the 1e-8 this check asks for)
       double pvl = 0;
 #pragma unroll
       for (int ks = 0; ks < kMaxK; ++ks) {
@@ -612,6 +647,28 @@ __global__ __launch_bounds__(kPolThreads, 1) void polish_kernel(const PolishArgs
         const double val = row_is_disc(r) ? hypot(U[j * Tm + t], U[(j + M) * Tm + t]) : U[j * Tm + t];
         pvl = fmax(pvl, (val - lim) / fmax(1.0, lim));
       }
+      statl = 0;
+#pragma unroll
+      for (int k = 0; k < kPolTQ; ++k) {
+        const int t = h * TQ + k;
+        if (!((freem >> k) & 1u)) continue;
+        double gr = pd * xv[k] + qv[k];
+#pragma unroll
+        for (int ks = 0; ks < kMaxK; ++ks) gr += ((swm[ks] >> k) & 1u) ? smu[ks] : 0.0;
+        for (int r = 0; r < nrow; ++r) {
+          const double nu = NU[r * Tm + t];
+          if (nu == 0.0) continue;
+          const int j = row_j(r);
+          if (row_is_disc(r)) {
+            const double u0 = U[j * Tm + t], u1 = U[(j + M) * Tm + t], val = hypot(u0, u1);
+            gr += nu * (u0 * Gs[j * N + i] + u1 * Gs[(j + M) * N + i]) / val;
+          } else {
+            gr += nu * Gs[j * N + i];
+          }
+        }
+        statl = fmax(statl, fabs(gr));
+      }
+      const double stat = pol_block_max(statl, RED);
       const double pv = pol_block_max(pvl, RED);
       stat_out = stat; prim_out = pv;
       success = stat <= 1e-8 * qn && pv <= 10.0 * kPolTolPrimal;
@@ -619,6 +676,12 @@ __global__ __launch_bounds__(kPolThreads, 1) void polish_kernel(const PolishArgs
       break;
     }
     // ---- results -----------------------------------------------------------------------------------------------------------------------------------
+    POL_TICK(7);
+    if (tid == 0) {
+      for (int ph = 0; ph < 8; ++ph) atomicAdd(A.stats + 8 + ph, (int)tacc[ph]);
+      atomicAdd(A.stats + 6, rounds);
+    }
+#undef POL_TICK
     if (success) {
       double ol = 0;
 #pragma unroll

@@ -100,6 +100,8 @@ struct TiledArgs {
   //    `resume` = 1 is the launch that follows the polish kernel: it runs over pol_list (order = pol_list, count_dev = its
   //    length, on the device), skips what the polish solved and solves the rest from scratch as if there were no polish
   int polish_iters, resume;
+  int pol_rows;               // rows of the polish kernel's Schur system for this shape: a problem whose iterate has more tight site
+                              // rows than that is not handed over (it would come straight back) and the ADMM goes on
   int32_t *pol_list, *pol_count;
   const int32_t* count_dev;   // number of queue positions, on the device (null: B)
   int ws_by_slot;  // 1: a streaming kernel's workspace belongs to the workgroup slot (work-queue launches), 0: to the problem
@@ -1579,8 +1581,31 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
       if (score < (real)scalar_const(kStallGain) * best_score) { best_score = uniform_scalar(score); best_it = it; }
       const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel, A.inacc_floor);
       const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= (real)scalar_const(kStallNear) * best_score;
+      bool hand_over = false;
+      if (!done && pass == 0 && A.polish_iters > 0 && it >= A.polish_iters) {   // block-uniform
+        // rows the polish's Schur system would have: one per tight box / peak row, two per tight disc (normal + tangent)
+        real cnt = 0;
+        const real ytol = (real)scalar_const(1e-9) * fmax((real)1, qnorm);
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+          for (int mo = 0; mo < MT; ++mo) {
+            int rty[4];
+            row_types(mo, rty);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const real yr = y2[mo][c][r], yi = y2[mo][c][(r + 1) & 3];
+              const bool disc = rty[r] == kRowSocRe;
+              const real mag = disc ? sqrt(yr * yr + yi * yi) : yr;
+              const bool counts = (disc | (rty[r] == kRowBox) | (rty[r] == kRowPeak)) & (16 * c + t < Tm) & (mag > ytol);
+              cnt += counts ? (disc ? (real)2 : (real)1) : (real)0;
+            }
+          }
+        cnt = wave_sum<real>(cnt);   // the site-row state is replicated: every wave counts the same rows
+        hand_over = cnt + (real)8 <= (real)A.pol_rows;
+      }
       if (done) {
-      } else if (pass == 0 && A.polish_iters > 0 && it >= A.polish_iters) {
+      } else if (hand_over) {
         status = kStatusPolish;   // not converged after polish_iters iterations: the polish kernel takes over from (z1, y2)
         done = true;
       } else if (it >= max_iter_p || stalled) {

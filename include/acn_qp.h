@@ -264,7 +264,9 @@ int64_t acnqp_ordered_launch_count(acnqp_handle* h);
 
 /* Counters of the polish over the handle's life (synchronises the device): out[0] problems handed to the polish,
  * out[1] solved by it, out[2..5] given up because of: more tight site rows than its LDS holds, a non-positive pivot,
- * the round limit, the final KKT check.  Returns ACNQP_OK.  Bench / test plumbing.                                   */
+ * the round limit, the final KKT check; out[6] Newton rounds made; out[8..15] time per phase of the polish kernel in
+ * 10 ns ticks, summed over its workgroups (rows + gradient, Schur matrix, Cholesky, triangular solves, step, ratio test,
+ * update, multiplier check + verification).  Returns ACNQP_OK.  Bench / test plumbing.                               */
 int acnqp_polish_stats(acnqp_handle* h, int64_t* out, int32_t capacity);
 
 /* Anderson columns the kernels will actually use for problems of this shape

@@ -147,3 +147,46 @@ def closed_loop_apply(evs, t, first_period_rates, infra, period=5):
         if e["arrival"] <= t < e["departure"]:
             r = float(first_period_rates[infra.get_station_index(e["station"])])
             e["delivered"] = min(e["requested"], e["delivered"] + r * k)
+
+
+PROX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prox.npz")
+
+
+def load_prox():
+    """tools/make_golden_prox.py: certified optima of problems with a load_flattening / demand_charge term at the shapes
+    the large-site and the long-horizon kernel serve."""
+    return np.load(PROX, allow_pickle=False)
+
+
+def prox_case(g, name):
+    """Rebuild fixture ``name`` of prox.npz: (sessions, infrastructure, interface, objective list, spec for
+    oracle/ref_problem.py, meta dict, expected dict)."""
+    from adacharge_amd import ObjectiveComponent, demand_charge, equal_share, load_flattening, total_energy
+
+    infra = getattr(sites, str(g[f"{name}_site"]))()
+    m = g[f"{name}_meta"]
+    meta = dict(T=int(m[0]), ct="SOC" if m[1] else "LINEAR", eq=bool(m[2]), lf=bool(m[3]), seed=int(m[4]),
+                es=float(m[5]) if len(m) > 5 else (0.0 if m[3] else 1e-3))
+    if meta["lf"]:
+        ext = g[f"{name}_ext"].copy()
+        obj = [ObjectiveComponent(load_flattening, 1.0, {"external_signal": ext})]
+        spec = [("load_flattening", 1.0, {"external_signal": ext})]
+        if meta["es"]:
+            obj.append(ObjectiveComponent(equal_share, meta["es"]))
+            spec.append(("equal_share", meta["es"], {}))
+        iface = Interface({"infrastructure_info": infra, "period": 5})
+    else:
+        obj = [ObjectiveComponent(total_energy, 20.0), ObjectiveComponent(demand_charge), ObjectiveComponent(equal_share, 1e-3)]
+        spec = [("total_energy", 20.0, {}), ("demand_charge", 1.0, {}), ("equal_share", 1e-3, {})]
+        iface = Interface({"infrastructure_info": infra, "period": 5, "demand_charge": 15.0, "prev_peak": 50.0})
+    st, arr, dep = g[f"{name}_station"], g[f"{name}_arrival"], g[f"{name}_departure"]
+    minr, maxr = g[f"{name}_minr"], g[f"{name}_maxr"]
+    sessions, o = [], 0
+    for k in range(len(st)):
+        L = int(dep[k] - arr[k])
+        sessions.append(SessionInfo(infra.station_ids[int(st[k])], f"s{k}", float(g[f"{name}_demand"][k]), 0.0,
+                                    int(arr[k]), int(dep[k]), current_time=0,
+                                    min_rates=minr[o:o + L].copy(), max_rates=maxr[o:o + L].copy()))
+        o += L
+    exp = dict(rates=g[f"{name}_rates"], obj=float(g[f"{name}_obj"]), binding=int(g[f"{name}_binding"][0]))
+    return sessions, infra, iface, obj, spec, meta, exp

@@ -1330,3 +1330,50 @@ def test_every_kernel_family_is_run_to_run_deterministic():
         a, b = h.solve(batch, default_options()), h.solve(batch, default_options())
         h.close()
         assert np.array_equal(a.x, b.x) and np.array_equal(a.iters, b.iters), name
+
+
+def test_config5_leg_at_its_per_gpu_size_meets_every_constraint():
+    """BASELINE.json configs[4] at its per-GPU size (16,384 over 8 GPUs = 2,048): bench.py's own leg -- synthetic 512 EVSE
+    x 48, load_flattening of an external profile with the sessions' energy delivered, 8 snapshots x 256 demand scenarios,
+    default options -- through the device entry.  Size-independent properties on every problem: SOLVED, bounds, energy
+    EQUALITIES, SOC site rows <= limit + 1e-3 A with binding rows present; and the snapshot the IPM-certified fixture
+    tests/golden/prox.npz::lf512_t48_eq holds (the leg's sixth base snapshot at its drawn demand) is reproduced inside
+    the batch run: objective and aggregate power of a scenario with factor ~1 stay within the scenario's scaling of it."""
+    import torch
+
+    import bench
+    from adacharge_amd.backend import DeviceBatch
+
+    batch, opts, streamed, note = bench.other_workloads()["cfg4_synth512_T48_b2048"]()
+    assert batch.B == 2048 and batch.N == 512 and batch.Tm == 48 and batch.site.has_flat and bool(batch.s_eq.all())
+    infra = sites.synth512()
+    h = SiteHandle(batch.site, 0)
+    db = DeviceBatch(batch, torch.device("cuda", 0))
+    h.solve_device(db, opts, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    status, iters = db.status.cpu().numpy(), db.iters.cpu().numpy()
+    assert (status == 1).all(), np.unique(status, return_counts=True)
+    assert iters.mean() >= 100          # the site rows bind: not the 20-iteration trivial optimum of round 2
+    x = db.x                             # (B, N, Tm) on the device: the checks run there (400 MB)
+    lb = torch.from_numpy(batch.lb).to(x.device)
+    ub = torch.from_numpy(np.maximum(batch.ub, batch.lb)).to(x.device)
+    assert bool(((x >= lb - 1e-6) & (x <= ub + 1e-6)).all())
+    # energy equalities: one session slot per EVSE in this workload
+    assert batch.K == 1
+    off, ln, cap = (torch.from_numpy(a[:, 0, :]).to(x.device) for a in (batch.s_off, batch.s_len, batch.s_cap))
+    tt = torch.arange(batch.Tm, device=x.device)[None, None, :]
+    win = (tt >= off[:, :, None]) & (tt < (off + ln)[:, :, None])
+    e = (x * win).sum(dim=2)
+    has = ln > 0
+    assert float(((e - cap).abs() / cap.abs().clamp(min=1.0))[has].max()) <= 1e-6
+    # SOC site rows
+    ph = np.deg2rad(infra.phases)
+    cm = infra.constraint_matrix
+    re = torch.einsum("mn,bnt->bmt", torch.from_numpy(cm * np.cos(ph)).to(x.device), x)
+    im = torch.einsum("mn,bnt->bmt", torch.from_numpy(cm * np.sin(ph)).to(x.device), x)
+    mag = torch.hypot(re, im)
+    lim = torch.from_numpy(infra.constraint_limits).to(x.device)[None, :, None]
+    assert float((mag - lim).max()) <= 1e-3
+    assert float((mag / lim).max()) >= 1 - 1e-6                      # rows bind somewhere in the batch
+    assert int(((mag / lim) > 1 - 1e-6).any(dim=2).any(dim=1).sum()) >= 256   # ... in many scenarios
+    h.close()

@@ -28,7 +28,7 @@ for leg in legs:
             ref = x
         out[name] = {"ms": round(min(ms[1:]), 3), "iters_mean": round(float(it.mean()), 1), "iters_max": int(it.max()),
                      "solved": int((st == 1).sum()), "inaccurate": int((st == 5).sum()), "other": int((~np.isin(st, (1, 5))).sum()),
-                     "polish": {k: v // 3 for k, v in stats.items()}}
+                     "polish": {k: (v // 3 if not isinstance(v, list) else [u // 3 for u in v]) for k, v in stats.items()}}
         if name != "polish":
             out[name]["max_abs_diff_vs_polish_A"] = float(np.abs(x - ref).max())
     print(json.dumps(out), flush=True)

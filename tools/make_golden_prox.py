@@ -147,7 +147,26 @@ def main():
         infra, iface, sl, spec, obj, ct, eq, kind, seed, T, site_name = case_problem(name)
         t0 = time.time()
         prob = build_reference_problem(sl, infra, iface, spec, ct, eq)
-        r, res, cert = solve_certified(prob)
+        how = "ipm"
+        r = cert = None
+        if kind[0] != "lf":
+            r, res, cert = solve_certified(prob)
+        if cert is None or not cert.worst < 1e-9:
+            # The interior-point method stops short of 1e-9 on the load-flattening problems (costs of 1e6 with a rank-one
+            # quadratic per period: its reduced-accuracy exit, then an active-set guess the polish cannot repair in its
+            # rounds).  What makes a fixture an ORACLE value is the KKT certificate on the full problem the reference
+            # states -- sufficient for a convex program wherever the candidate came from -- so the active-set Newton
+            # (oracle.ipm.polish) is started from the C twin's answer instead, and the same certificate is demanded.
+            from adacharge_amd.builder import build_batch
+            from oracle import admm_port
+            from oracle.ipm import polish
+
+            batch = build_batch([sl], infra, iface, obj, ct, eq)
+            tw = admm_port.solve_batch(batch, eps_abs=1e-10, eps_rel=1e-10, max_iter=200000, accel_mem=5)
+            assert tw["status"][0] == 1, (name, tw["status"], tw["iters"])
+            r, cert = polish(prob, tw["x"][0][:, :prob.T], duals=None, act_tol=1e-6, max_rounds=60)
+            r = prob.rates_of(r)
+            how = "twin+polish"
         assert cert is not None and cert.worst < 1e-9, (name, cert)
         Tb = prob.T
         u = utilisation(r, infra, ct)
@@ -165,6 +184,7 @@ def main():
             "rates": r,
             "obj": np.array(prob.objective(r)),
             "cert": np.array([cert.stationarity, cert.primal, cert.dual]),
+            "how": np.array(how),
             "binding": np.array([(u > 1 - 1e-6).sum(), u.max()]),
         }
         # (re-read the file right before it is rewritten: several generators may run side by side, one case each)
@@ -174,7 +194,7 @@ def main():
         store["names"] = np.array(sorted({k.rsplit("_", 1)[0] for k in store if k.endswith("_rates")}))
         np.savez_compressed(OUT, **store)
         print(f"{name:14s} {site_name:10s} T={Tb:3d} {ct:6s} eq={int(eq)} S={len(sl):3d} obj {prob.objective(r):.9f} "
-              f"cert {cert.worst:.1e} binding rows {int(st['binding'][0])} (max util {u.max():.6f})  {time.time() - t0:.1f}s", flush=True)
+              f"cert {cert.worst:.1e} ({how}) binding rows {int(st['binding'][0])} (max util {u.max():.6f})  {time.time() - t0:.1f}s", flush=True)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 
 
