@@ -220,7 +220,8 @@ class AdaptiveChargingOptimization:
         self.solver_options = dict(solver_options or {})
         self.device = device
         self.last_result = None
-        self.last_batch = None
+        self._last_plan = None
+        self._last_batch = None
 
     # the single-problem API asks for tighter residuals than the batch default so that the
     # reference's own test tolerances (1e-7 on the peak row, t_aco.py:257) hold
@@ -345,9 +346,12 @@ class AdaptiveChargingOptimization:
     def solve_table(self, table, infrastructure, peak_limits=None, prev_peak=0, _defaults: Optional[dict] = None,
                     warm_start=None):
         """Batched solve of a ``session_table.SessionTable`` (every snapshot non-empty): the array-native entry --
-        no Python loop over sessions anywhere on the path.  Returns ``(backend.BatchResult, ProblemBatch)``."""
+        no Python loop over sessions anywhere on the path, and (round 4) no dense (B, N, T) problem array on the host
+        either: the sessions go to the library as they are (``acnqp_solve_table``) and ``charging_rate_bounds`` /
+        ``energy_constraints`` / the linear cost (aco.py:45-124, 200-218) take their array form on the device.
+        Returns ``(backend.BatchResult, builder.TablePlan)``; a warm start takes the dense entry (``plan.expand()``)."""
         from . import backend
-        from .builder import _bad_constraint_type, _objective_needs_flat, _objective_needs_max, build_batch_from_table
+        from .builder import _bad_constraint_type, _objective_needs_flat, _objective_needs_max, plan_from_table
 
         if self.constraint_type not in ("SOC", "LINEAR"):
             _bad_constraint_type(self.constraint_type)
@@ -357,16 +361,19 @@ class AdaptiveChargingOptimization:
             with_flat=_objective_needs_flat(self.objective_configuration),
             with_max=_objective_needs_max(self.objective_configuration),
         )
-        batch = build_batch_from_table(
+        plan = plan_from_table(
             table, infrastructure, self.interface, self.objective_configuration, self.constraint_type,
             self.enforce_energy_equality, peak_limits=pl, prev_peak=prev_peak, site=site,
         )
         opts = dict(_defaults or {})
         opts.update(self.solver_options)
-        warm = None
+        if not bool(opts.pop("retry_stalled", True)):   # shorthand kept from round 2: the passes live in the library now
+            opts["retry_passes"] = 0
+        self._last_plan, self._last_batch = plan, None
         if warm_start is not None and any(w is not None for w in warm_start):
             # per problem (x0, y0) or None; a problem without one starts from its own cold start's point only if all
             # are None -- mixed batches give the cold problems x0 = y0 = 0 (a valid, if plain, starting point)
+            batch = self.last_batch
             wx = np.zeros((batch.B, batch.N, batch.Tm))
             wy = np.zeros((batch.B, site.Mg, batch.Tm))
             for b, w in enumerate(warm_start):
@@ -374,13 +381,18 @@ class AdaptiveChargingOptimization:
                     x0, y0 = np.asarray(w[0], float), np.asarray(w[1], float)
                     T = min(batch.Tm, x0.shape[1], y0.shape[1])
                     wx[b, :, :T], wy[b, :, :T] = x0[:, :T], y0[:, :T]
-            warm = (wx, wy)
-        if not bool(opts.pop("retry_stalled", True)):   # shorthand kept from round 2: the passes live in the library now
-            opts["retry_passes"] = 0
-        res = handle.solve(batch, backend.default_options(**opts), warm=warm, want_y=True)
+            res = handle.solve(batch, backend.default_options(**opts), warm=(wx, wy), want_y=True)
+        else:
+            res = handle.solve_table(plan, backend.default_options(**opts), want_y=True)
         self.last_result = res
-        self.last_batch = batch   # the structured problems behind last_result (diagnostics, tests)
-        return res, batch
+        return res, plan
+
+    @property
+    def last_batch(self):
+        """The structured problems behind ``last_result`` as dense arrays (diagnostics, tests): expanded on demand."""
+        if getattr(self, "_last_batch", None) is None and getattr(self, "_last_plan", None) is not None:
+            self._last_batch = self._last_plan.expand()
+        return getattr(self, "_last_batch", None)
 
     @property
     def last_multipliers(self):

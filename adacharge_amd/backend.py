@@ -77,6 +77,14 @@ class _Problems(C.Structure):
     ]
 
 
+class _Table(C.Structure):
+    """Mirror of ``acnqp_table`` (include/acn_qp.h)."""
+
+    _fields_ = [(k, C.c_int32) for k in ("batch", "t_max", "k_sessions", "n_sessions", "n_horizons")] + [
+        (k, C.c_void_p) for k in ("horizon", "q_index", "q_table", "pdiag", "s_eq", "peak", "lf", "dc", "dfloor", "sess_seg",
+                                  "s_evse", "s_slot", "s_off", "s_len", "s_cap", "rate_seg", "min_rates", "max_rates")]
+
+
 class _Results(C.Structure):
     _fields_ = [
         ("x", C.c_void_p),
@@ -130,6 +138,7 @@ EXPORTED_SYMBOLS = (
     "acnqp_ordered_launch_count",
     "acnqp_polish_stats",
     "acnqp_solve_batches",
+    "acnqp_solve_table",
     "acnqp_host_alloc",
     "acnqp_host_free",
     "acnqp_launch_count",
@@ -188,6 +197,8 @@ def load_library():
     lib.acnqp_kernel_times.restype = C.c_int32
     lib.acnqp_solve_batches.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_Problems), C.POINTER(Options), C.POINTER(_Results)]
     lib.acnqp_solve_batches.restype = C.c_int
+    lib.acnqp_solve_table.argtypes = [C.c_void_p, C.POINTER(_Table), C.POINTER(Options), C.POINTER(_Results)]
+    lib.acnqp_solve_table.restype = C.c_int
     lib.acnqp_host_alloc.argtypes = [C.c_size_t]
     lib.acnqp_host_alloc.restype = C.c_void_p
     lib.acnqp_host_free.argtypes = [C.c_void_p]
@@ -376,6 +387,37 @@ class SiteHandle:
         del keep
         res.kernel_ms = self._kernel_ms_of_call()
         return self._finish(batch, res)
+
+    def solve_table(self, plan, options: Optional[Options] = None, pinned_results: bool = False, want_y: bool = False) -> "BatchResult":
+        """acnqp_solve_table: a ``builder.TablePlan`` (sessions + one linear cost per horizon) in, schedules out; the
+        dense (B, N, Tm) problem arrays are formed on the device.  Same results as ``solve(plan.expand())``."""
+        if plan.site is not self.site and (plan.site.N, plan.site.Mg, plan.site.cone) != (self.site.N, self.site.Mg, self.site.cone):
+            raise ValueError("plan was built for another site")
+        o = options if options is not None else default_options()
+        B, N, Tm = plan.B, plan.N, plan.Tm
+        c = lambda a, dt: None if a is None else np.ascontiguousarray(a, dt)
+        keep = dict(
+            horizon=c(plan.T, np.int32), q_index=c(plan.q_index, np.int32), q_table=c(plan.q_table, np.float64),
+            pdiag=c(plan.pdiag, np.float64), s_eq=c(plan.s_eq, np.uint8), peak=c(plan.peak, np.float64) if self.site.has_peak else None,
+            lf=c(plan.lf, np.float64) if self.site.has_flat else None, dc=c(plan.dc, np.float64) if self.site.has_max else None,
+            dfloor=c(plan.dfloor, np.float64) if self.site.has_max else None, sess_seg=c(plan.sess_seg, np.int32),
+            s_evse=c(plan.s_evse, np.int32), s_slot=c(plan.s_slot, np.int32), s_off=c(plan.s_off, np.int32), s_len=c(plan.s_len, np.int32),
+            s_cap=c(plan.s_cap, np.float64), rate_seg=c(plan.rate_seg, np.int32), min_rates=c(plan.min_rates, np.float64),
+            max_rates=c(plan.max_rates, np.float64))
+        t = _Table(B, Tm, plan.K, plan.S, len(plan.q_table), *[_ptr(keep[k]) for k in (
+            "horizon", "q_index", "q_table", "pdiag", "s_eq", "peak", "lf", "dc", "dfloor", "sess_seg", "s_evse", "s_slot", "s_off",
+            "s_len", "s_cap", "rate_seg", "min_rates", "max_rates")])
+        new = pinned_empty if pinned_results else (lambda shape, dtype=np.float64: np.zeros(shape, dtype))
+        res = BatchResult(new((B, N, Tm)), new(B, np.int32), new(B, np.int32), new(B), new(B), new(B))
+        if want_y:
+            res.y = new((B, self.site.Mg, Tm))
+        r = _Results(_ptr(res.x), _ptr(res.status), _ptr(res.iters), _ptr(res.pri_res), _ptr(res.dua_res), _ptr(res.obj), _ptr(res.y), None)
+        self.kernel_times()
+        self._launches_seen = int(self._lib.acnqp_launch_count(self._h))
+        _check(self._lib.acnqp_solve_table(self._h, C.byref(t), C.byref(o), C.byref(r)), "acnqp_solve_table")
+        del keep
+        res.kernel_ms = self._kernel_ms_of_call()
+        return self._finish(plan, res)
 
     def solve_many(self, batches, options: Optional[Options] = None, pinned_results: bool = True):
         """acnqp_solve_batches: several independent batches in ONE pipelined pass (shared launches, overlapped

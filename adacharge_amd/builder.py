@@ -265,7 +265,78 @@ def build_batch(
                                   peak_limits, prev_peak, site, alloc)
 
 
-def build_batch_from_table(
+@dataclass
+class TablePlan:
+    """What ``acnqp_solve_table`` takes (include/acn_qp.h: acnqp_table): the sessions of a ``SessionTable`` grouped by
+    problem with their EVSE slots and energy caps, the linear cost once per distinct horizon, the per-problem scalars --
+    everything ``build_batch_from_table`` computes EXCEPT the dense (B, N, Tm) arrays, which the library forms on the
+    device.  ``expand()`` forms them on the host (the ``ProblemBatch`` the other entry points take): the two paths
+    describe the same problems bit for bit (tests/test_table_entry.py)."""
+    site: SiteData
+    B: int
+    Tm: int
+    K: int
+    T: np.ndarray          # (B,) int32 horizon
+    q_index: np.ndarray    # (B,) int32 row of q_table
+    q_table: np.ndarray    # (H, N, Tm)
+    pdiag: np.ndarray
+    lf: np.ndarray
+    dc: np.ndarray
+    dfloor: np.ndarray
+    const: np.ndarray
+    s_eq: np.ndarray
+    peak: Optional[np.ndarray]
+    presolve_status: np.ndarray
+    sess_seg: np.ndarray   # (B + 1,) int32
+    s_evse: np.ndarray     # (S,) int32, sessions grouped by problem
+    s_slot: np.ndarray
+    s_off: np.ndarray
+    s_len: np.ndarray
+    s_cap: np.ndarray      # (S,) float64, A-periods
+    rate_seg: np.ndarray   # (S + 1,) int32
+    min_rates: np.ndarray
+    max_rates: np.ndarray
+
+    @property
+    def N(self) -> int:
+        return self.site.N
+
+    @property
+    def S(self) -> int:
+        return len(self.s_evse)
+
+    def expand(self, alloc=None) -> "ProblemBatch":
+        """The dense ``ProblemBatch`` of this plan (numpy twin of acn_qp_api.hip::table_expand_kernel)."""
+        if alloc is None:
+            alloc = lambda shape, dtype=np.float64: np.zeros(shape, dtype)
+        B, N, Tm, K = self.B, self.N, self.Tm, self.K
+        lb, ub, q = alloc((B, N, Tm)), alloc((B, N, Tm)), alloc((B, N, Tm))
+        prob = np.repeat(np.arange(B), np.diff(self.sess_seg))
+        rlen = np.diff(self.rate_seg)
+        owner = np.repeat(np.arange(self.S), rlen)
+        j = np.arange(len(owner)) - np.repeat(self.rate_seg[:-1], rlen)
+        flat = (prob[owner] * N + self.s_evse[owner]) * Tm + self.s_off[owner] + j
+        lb.reshape(-1)[flat] = self.min_rates     # aco.py:62-73
+        ub.reshape(-1)[flat] = self.max_rates
+        np.maximum(ub, lb, out=ub)                # aco.py:75
+        q[:] = self.q_table[self.q_index]
+        s_off, s_len, s_cap = alloc((B, K, N), np.int32), alloc((B, K, N), np.int32), alloc((B, K, N))
+        live = np.flatnonzero(self.s_len > 0)
+        slot = (prob[live] * K + self.s_slot[live]) * N + self.s_evse[live]
+        s_off.reshape(-1)[slot] = self.s_off[live]
+        s_len.reshape(-1)[slot] = self.s_len[live]
+        s_cap.reshape(-1)[slot] = self.s_cap[live]
+        Ts, pdiag, lf, dc, dfl, s_eq = alloc(B, np.int32), alloc(B), alloc(B), alloc(B), alloc(B), alloc(B, np.uint8)
+        Ts[:], pdiag[:], lf[:], dc[:], dfl[:], s_eq[:] = self.T, self.pdiag, self.lf, self.dc, self.dfloor, self.s_eq
+        peak = None
+        if self.peak is not None:
+            peak = alloc((B, Tm))
+            peak[:] = self.peak
+        return ProblemBatch(self.site, B, Tm, K, Ts, lb, ub, q, pdiag, lf, s_off, s_len, s_cap, s_eq, peak, dc, dfl,
+                            self.const.copy(), self.presolve_status.copy())
+
+
+def plan_from_table(
     table,
     infrastructure,
     interface,
@@ -275,13 +346,11 @@ def build_batch_from_table(
     peak_limits: Optional[Sequence] = None,
     prev_peak=0,
     site: Optional[SiteData] = None,
-    alloc=None,
-) -> ProblemBatch:
-    """The structured batch of a ``SessionTable`` (every snapshot needs at least one session) with no Python loop
-    over sessions: bounds by ragged scatter (aco.py:61-79), energy rows by group ranking (aco.py:105-123), the
-    objective once per distinct horizon (aco.py:200-218, 243-245)."""
-    if alloc is None:
-        alloc = lambda shape, dtype=np.float64: np.zeros(shape, dtype)
+) -> TablePlan:
+    """Everything the reference's statement needs from a ``SessionTable`` (every snapshot needs at least one session)
+    with no Python loop over sessions and no (B, N, Tm) array: the sessions grouped by snapshot, their slot = rank among
+    their EVSE's sessions and energy cap in A-periods (aco.py:105-123), the objective once per distinct horizon
+    (aco.py:200-218, 243-245)."""
     B, N = table.B, len(infrastructure.station_ids)
     if peak_limits is None:
         peak_limits = [None] * B
@@ -297,44 +366,21 @@ def build_batch_from_table(
     elif any_peak and not site.has_peak:
         raise ValueError("site was built without a peak row but a peak_limit was given")
     S = table.S
-    prob, evse, off, rem = table.prob, table.evse, table.off, table.rem
-    if S == 0 or len(np.unique(prob)) != B:
+    if S == 0 or len(np.unique(table.prob)) != B:
         raise ValueError("every snapshot of a batch needs at least one session (aco.py:310-311 handles the empty case)")
-    Ts = alloc(B, np.int32)
+    rlen_in = np.diff(table.seg)
+    if np.any(rlen_in != np.maximum(table.rem, 0)):
+        raise ValueError("min_rates / max_rates must have one entry per remaining period (aco.py:68, 73)")
+    # ---- sessions grouped by snapshot (stable: the order inside a snapshot is the caller's) ----------------------------
+    if np.any(np.diff(table.prob) < 0):
+        table = table.take(np.argsort(table.prob, kind="stable"))
+    prob, evse, off, rem = table.prob, table.evse, table.off, table.rem
     end = np.zeros(B, dtype=np.int64)
     np.maximum.at(end, prob, off + rem)            # aco.py:243-245
-    Ts[:] = end
     Tm = int(end.max())
     volt = np.asarray(infrastructure.voltages, float)
     kwh_per_amp_period = volt * interface.period / 1e3 / 60   # aco.py:114
-
-    lb = alloc((B, N, Tm), np.float64)
-    ub = alloc((B, N, Tm), np.float64)
-    q = alloc((B, N, Tm), np.float64)
-    pdiag = alloc(B, np.float64)
-    lf = alloc(B, np.float64)
-    const = np.zeros(B)
-    dc = alloc(B, np.float64)
-    dfloor = alloc(B, np.float64)
-    s_eq = alloc(B, np.uint8)
-    s_eq[:] = 1 if enforce_energy_equality else 0
-    peak = None
-    if site.has_peak:
-        peak = alloc((B, Tm), np.float64)
-        peak[:] = np.inf
     presolve = np.zeros(B, dtype=np.int32)
-
-    # ---- bounds (aco.py:62-75): session s writes its rate vectors into [off, off + rem) of its EVSE's row --------
-    rlen = np.diff(table.seg)
-    if np.any(rlen != np.maximum(rem, 0)):
-        raise ValueError("min_rates / max_rates must have one entry per remaining period (aco.py:68, 73)")
-    owner = np.repeat(np.arange(S), rlen)
-    j = np.arange(len(owner)) - np.repeat(table.seg[:-1], rlen)
-    flat = (prob[owner] * N + evse[owner]) * Tm + off[owner] + j
-    lb.reshape(-1)[flat] = table.min_rates
-    ub.reshape(-1)[flat] = table.max_rates
-    np.maximum(ub, lb, out=ub)   # aco.py:75
-
     # ---- energy rows (aco.py:105-123): slot k = rank of the session among its EVSE's sessions of that snapshot ---
     live = np.flatnonzero(rem > 0)
     dead = np.flatnonzero(rem <= 0)
@@ -359,26 +405,49 @@ def build_batch_from_table(
                 f"sessions on EVSE {infrastructure.station_ids[int(evse[w])]} overlap in time; the structured "
                 "builder needs disjoint session windows per EVSE"
             )
-    s_off = alloc((B, K, N), np.int32)
-    s_len = alloc((B, K, N), np.int32)
-    s_cap = alloc((B, K, N), np.float64)
-    sl_ = live[order]
-    slot = (prob[sl_] * K + rank) * N + evse[sl_]
-    s_off.reshape(-1)[slot] = off[sl_]
-    s_len.reshape(-1)[slot] = rem[sl_]
-    s_cap.reshape(-1)[slot] = table.demand[sl_] / kwh_per_amp_period[evse[sl_]]
-
+    s_slot = np.zeros(S, dtype=np.int32)
+    s_slot[live[order]] = rank
+    s_cap = table.demand / kwh_per_amp_period[evse]
+    sess_seg = np.zeros(B + 1, dtype=np.int32)
+    sess_seg[1:] = np.cumsum(np.bincount(prob, minlength=B))
     # ---- objective: depends on the problem only through its horizon ----------------------------------------------
-    for T in np.unique(end):
+    horizons = np.unique(end)
+    q_table = np.zeros((len(horizons), N, Tm))
+    q_index = np.searchsorted(horizons, end).astype(np.int32)
+    pdiag, lf, const, dc, dfloor = (np.zeros(B) for _ in range(5))
+    for hidx, T in enumerate(horizons):
         T = int(T)
         qb, pd, lfc, c0, dcw, dfl = objective_terms(objective, infrastructure, interface, N, T, prev_peak)
-        sel = np.flatnonzero(end == T)
-        q[sel, :, :T] = qb
+        q_table[hidx, :, :T] = qb
+        sel = q_index == hidx
         pdiag[sel], lf[sel], const[sel], dc[sel], dfloor[sel] = pd, lfc, c0, dcw, dfl
-    if peak is not None:   # aco.py:196-198
-        for b in range(B):
+    peak = None
+    if site.has_peak:
+        peak = np.full((B, Tm), np.inf)
+        for b in range(B):   # aco.py:196-198
             if peak_limits[b] is not None:
                 peak[b, : end[b]] = np.broadcast_to(np.asarray(peak_limits[b], float), (int(end[b]),))
-    return ProblemBatch(
-        site, B, Tm, K, Ts, lb, ub, q, pdiag, lf, s_off, s_len, s_cap, s_eq, peak, dc, dfloor, const, presolve
-    )
+    s_eq = np.full(B, 1 if enforce_energy_equality else 0, dtype=np.uint8)
+    i32 = lambda a: np.ascontiguousarray(a, np.int32)
+    return TablePlan(site, B, Tm, K, i32(end), q_index, q_table, pdiag, lf, dc, dfloor, const, s_eq, peak, presolve,
+                     sess_seg, i32(evse), s_slot, i32(off), i32(np.maximum(rem, 0)), np.ascontiguousarray(s_cap, np.float64),
+                     i32(table.seg), np.ascontiguousarray(table.min_rates, np.float64), np.ascontiguousarray(table.max_rates, np.float64))
+
+
+def build_batch_from_table(
+    table,
+    infrastructure,
+    interface,
+    objective,
+    constraint_type: str = "SOC",
+    enforce_energy_equality: bool = False,
+    peak_limits: Optional[Sequence] = None,
+    prev_peak=0,
+    site: Optional[SiteData] = None,
+    alloc=None,
+) -> ProblemBatch:
+    """The structured batch of a ``SessionTable`` (every snapshot needs at least one session) with no Python loop
+    over sessions: ``plan_from_table`` (energy rows by group ranking, aco.py:105-123; the objective once per distinct
+    horizon, aco.py:200-218, 243-245), then the dense arrays by ragged scatter (aco.py:61-79)."""
+    return plan_from_table(table, infrastructure, interface, objective, constraint_type, enforce_energy_equality,
+                           peak_limits, prev_peak, site).expand(alloc)

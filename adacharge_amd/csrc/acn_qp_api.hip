@@ -127,7 +127,7 @@ struct acnqp_handle {
   // host-buffer entry points: kSlots pipeline slots, each with its own stream and device staging, so that the
   // H2D copies, the kernel and the D2H copies of successive chunks of a call overlap
   static constexpr int kSlots = 4;
-  struct Slot { hipStream_t st = nullptr; DevBuf in, out; } slot[kSlots];
+  struct Slot { hipStream_t st = nullptr; DevBuf in, out, tin; } slot[kSlots];   // tin: session-table staging (acnqp_solve_table)
   // per launch stream: the kernel workspace (long-horizon, large-site, general-shape kernels) and the launch's small
   // scheduling buffer (queue counter, then sort keys and queue order).  Launches on different streams never share (or
   // regrow) each other's state, and a stream's own launches are ordered by the stream.
@@ -430,7 +430,7 @@ void acnqp_default_options(acnqp_options* o) {
   o->stall_iters = 3000;
   o->retry_passes = 2;
   o->retry_max_iter = 8000;
-  o->polish_iters = 1200;
+  o->polish_iters = 800;
   o->retry_rho = 0.5;
   o->inaccurate_floor = 1e-5;
 }
@@ -501,6 +501,7 @@ void acnqp_destroy(acnqp_handle* h) {
     if (sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
     sl.in.release();
     sl.out.release();
+    sl.tin.release();
   }
   h->release_work();
   if (h->pol_stats) (void)hipFree(h->pol_stats);
@@ -973,6 +974,210 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
 }
 
 }  // namespace
+
+// ---- session-table entry: the dense problem arrays are formed on the device ---------------------------------------------
+namespace {
+
+struct TableExpandArgs {
+  int N, Tm, K;
+  long long s_base, r_base;          // first session / rate entry of the chunk (the segment arrays hold global indices)
+  const int32_t *q_index, *sess_seg, *s_evse, *s_slot, *s_off, *s_len, *rate_seg;
+  const double *q_table, *s_cap, *min_rates, *max_rates;
+  double *lb, *ub, *q, *sc;
+  int32_t *so, *sl;
+};
+
+// One workgroup per problem of the chunk: zero its bounds and session slots, copy its horizon's linear cost, then
+// scatter its sessions -- lb / ub over the window (aco.py:62-75, ub < lb -> lb) and (offset, length, cap) into the
+// EVSE's slot (aco.py:105-123).  Windows of one EVSE are disjoint: no two sessions write one entry.
+__global__ __launch_bounds__(256) void table_expand_kernel(const TableExpandArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t nv = (size_t)a.N * a.Tm, ns = (size_t)a.K * a.N;
+  double *lb = a.lb + b * nv, *ub = a.ub + b * nv, *q = a.q + b * nv;
+  const double* qt = a.q_table + (size_t)a.q_index[b] * nv;
+  for (size_t k = tid; k < nv; k += 256) { lb[k] = 0.0; ub[k] = 0.0; q[k] = qt[k]; }
+  for (size_t k = tid; k < ns; k += 256) { a.so[b * ns + k] = 0; a.sl[b * ns + k] = 0; a.sc[b * ns + k] = 0.0; }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63;
+  const long long s0 = a.sess_seg[b] - a.s_base, s1 = a.sess_seg[b + 1] - a.s_base;
+  for (long long s = s0 + wave; s < s1; s += 4) {
+    const int ev = a.s_evse[s], off = a.s_off[s], len = a.s_len[s];
+    const long long r0 = a.rate_seg[s] - a.r_base;
+    for (int p_ = lane; p_ < len; p_ += 64) {
+      const double lo = a.min_rates[r0 + p_], hi = a.max_rates[r0 + p_];
+      lb[(size_t)ev * a.Tm + off + p_] = lo;
+      ub[(size_t)ev * a.Tm + off + p_] = hi < lo ? lo : hi;
+    }
+    if (lane == 0 && len > 0) {
+      const size_t k = (size_t)b * ns + (size_t)a.s_slot[s] * a.N + ev;
+      a.so[k] = off; a.sl[k] = len; a.sc[k] = a.s_cap[s];
+    }
+  }
+}
+
+int check_table(const acnqp_handle* h, const acnqp_table* t, const acnqp_options* o, const acnqp_results* r) {
+  if (!h || !t || !o || !r) return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: null argument");
+  if (t->batch < 0) return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: negative batch");
+  if (t->batch == 0) return ACNQP_OK;
+  if (!t->horizon || !t->q_index || !t->q_table || !t->pdiag || !t->s_eq || !t->sess_seg || !t->rate_seg ||
+      (t->n_sessions > 0 && (!t->s_evse || !t->s_slot || !t->s_off || !t->s_len || !t->s_cap)))
+    return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: null table array");
+  if (t->n_sessions < 0 || t->n_horizons < 1) return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: bad n_sessions / n_horizons");
+  // the dense view for the shared checks (pointers only tested for null there)
+  static const double dummy_d = 0;
+  static const int32_t dummy_i = 0;
+  acnqp_problems p;
+  p.batch = t->batch; p.t_max = t->t_max; p.k_sessions = t->k_sessions; p.horizon = t->horizon;
+  p.lb = p.ub = p.q = p.s_cap = &dummy_d; p.pdiag = t->pdiag; p.s_off = p.s_len = &dummy_i; p.s_eq = t->s_eq;
+  p.peak = t->peak; p.lf = t->lf; p.dc = t->dc; p.dfloor = t->dfloor; p.warm_x = p.warm_y = nullptr;
+  const int rc = check_problem_shapes(h, &p, o, r);
+  if (rc != ACNQP_OK) return rc;
+  const int B = t->batch, S = t->n_sessions, N = h->N, Tm = t->t_max, K = t->k_sessions;
+  if (t->sess_seg[0] != 0 || t->sess_seg[B] != S) return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: sess_seg must run from 0 to n_sessions");
+  for (int b = 0; b < B; ++b) {
+    if (t->sess_seg[b + 1] < t->sess_seg[b]) return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: sess_seg is not non-decreasing");
+    if (t->q_index[b] < 0 || t->q_index[b] >= t->n_horizons) return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: q_index out of range");
+    if (t->horizon[b] < 1 || t->horizon[b] > Tm) return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: horizon out of range");
+  }
+  if (t->rate_seg[0] != 0) return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: rate_seg must start at 0");
+  for (int s_ = 0; s_ < S; ++s_) {
+    const int len = t->s_len[s_] > 0 ? t->s_len[s_] : 0;
+    if (t->s_evse[s_] < 0 || t->s_evse[s_] >= N || (len > 0 && (t->s_slot[s_] < 0 || t->s_slot[s_] >= K)))
+      return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: session " + std::to_string(s_) + ": EVSE or slot out of range");
+    if (len > 0 && (t->s_off[s_] < 0 || t->s_off[s_] + len > Tm))
+      return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: session " + std::to_string(s_) + ": window outside [0, t_max)");
+    if (t->rate_seg[s_ + 1] - t->rate_seg[s_] != len)
+      return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: session " + std::to_string(s_) +
+                                     ": min_rates / max_rates must have one entry per remaining period (aco.py:68, 73)");
+  }
+  if (t->rate_seg[S] > 0 && (!t->min_rates || !t->max_rates)) return fail(ACNQP_ERR_INVALID, "acnqp_solve_table: null rate arrays");
+  return ACNQP_OK;
+}
+
+int run_table_pipeline(acnqp_handle* h, const acnqp_table* T, const acnqp_options* o, acnqp_results* R) {
+  const size_t N = h->N, Tm = T->t_max, K = T->k_sessions, Mg = (size_t)h->Mg;
+  const bool peak = h->has_peak, flat = h->has_flat, mx = h->has_max, want_y = R->y != nullptr;
+  const long long B = T->batch;
+  const size_t nv = N * Tm, nsl = K * N;
+  long long cap0 = chunk_problems(4 * nv * 8 + nsl * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K));
+  static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
+  long long lo = 0;
+  for (size_t c = 0; lo < B; ++c) {
+    long long cap = cap0;
+    if (ramp && cap0 >= 1024) cap = c == 0 ? cap0 / 4 : (c == 1 ? cap0 / 2 : cap0);
+    const long long cn = std::min(B - lo, cap);
+    acnqp_handle::Slot& S = h->slot[c % acnqp_handle::kSlots];
+    const ChunkLayout L((size_t)cn, N, Tm, K, Mg, peak, flat, mx, false, want_y);
+    const long long s0 = T->sess_seg[lo], s1 = T->sess_seg[lo + cn], ns = s1 - s0;
+    const long long r0 = T->rate_seg[s0], r1 = T->rate_seg[s1], nr = r1 - r0;
+    // table staging: q_index[cn], sess_seg[cn + 1], {evse, slot, off, len}[ns], rate_seg[ns + 1], s_cap[ns], min / max [nr], q_table
+    size_t to = 0;
+    const size_t o_qi = to; to += al256((size_t)cn * 4);
+    const size_t o_sg = to; to += al256((size_t)(cn + 1) * 4);
+    const size_t o_ev = to; to += al256((size_t)ns * 4);
+    const size_t o_sl = to; to += al256((size_t)ns * 4);
+    const size_t o_of = to; to += al256((size_t)ns * 4);
+    const size_t o_ln = to; to += al256((size_t)ns * 4);
+    const size_t o_rs = to; to += al256((size_t)(ns + 1) * 4);
+    const size_t o_cp = to; to += al256((size_t)ns * 8);
+    const size_t o_mn = to; to += al256((size_t)nr * 8);
+    const size_t o_mxr = to; to += al256((size_t)nr * 8);
+    const size_t o_qt = to; to += al256((size_t)T->n_horizons * nv * 8);
+    if (L.in_total > S.in.cap || L.out_total > S.out.cap || to > S.tin.cap) HIP_TRY(hipStreamSynchronize(S.st));   // staging still in use
+    HIP_TRY(S.in.reserve(L.in_total));
+    HIP_TRY(S.out.reserve(L.out_total));
+    HIP_TRY(S.tin.reserve(to));
+    char* di = static_cast<char*>(S.in.p);
+    char* dq = static_cast<char*>(S.out.p);
+    char* dt = static_cast<char*>(S.tin.p);
+#define TH2D(dst, src, bytes) do { if ((bytes) > 0) HIP_TRY(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, S.st)); } while (0)
+    TH2D(di + L.hz, T->horizon + lo, (size_t)cn * 4);
+    TH2D(di + L.pd, T->pdiag + lo, (size_t)cn * 8);
+    TH2D(di + L.eq, T->s_eq + lo, (size_t)cn);
+    if (peak) TH2D(di + L.pk, T->peak + lo * Tm, (size_t)cn * Tm * 8);
+    if (flat) TH2D(di + L.lf, T->lf + lo, (size_t)cn * 8);
+    if (mx) { TH2D(di + L.dc, T->dc + lo, (size_t)cn * 8); TH2D(di + L.df, T->dfloor + lo, (size_t)cn * 8); }
+    TH2D(dt + o_qi, T->q_index + lo, (size_t)cn * 4);
+    TH2D(dt + o_sg, T->sess_seg + lo, (size_t)(cn + 1) * 4);
+    TH2D(dt + o_ev, T->s_evse + s0, (size_t)ns * 4);
+    TH2D(dt + o_sl, T->s_slot + s0, (size_t)ns * 4);
+    TH2D(dt + o_of, T->s_off + s0, (size_t)ns * 4);
+    TH2D(dt + o_ln, T->s_len + s0, (size_t)ns * 4);
+    TH2D(dt + o_rs, T->rate_seg + s0, (size_t)(ns + 1) * 4);
+    TH2D(dt + o_cp, T->s_cap + s0, (size_t)ns * 8);
+    TH2D(dt + o_mn, T->min_rates + r0, (size_t)nr * 8);
+    TH2D(dt + o_mxr, T->max_rates + r0, (size_t)nr * 8);
+    TH2D(dt + o_qt, T->q_table, (size_t)T->n_horizons * nv * 8);
+#undef TH2D
+    TableExpandArgs ea;
+    ea.N = (int)N; ea.Tm = (int)Tm; ea.K = (int)K; ea.s_base = s0; ea.r_base = r0;
+    ea.q_index = reinterpret_cast<const int32_t*>(dt + o_qi); ea.sess_seg = reinterpret_cast<const int32_t*>(dt + o_sg);
+    ea.s_evse = reinterpret_cast<const int32_t*>(dt + o_ev); ea.s_slot = reinterpret_cast<const int32_t*>(dt + o_sl);
+    ea.s_off = reinterpret_cast<const int32_t*>(dt + o_of); ea.s_len = reinterpret_cast<const int32_t*>(dt + o_ln);
+    ea.rate_seg = reinterpret_cast<const int32_t*>(dt + o_rs); ea.q_table = reinterpret_cast<const double*>(dt + o_qt);
+    ea.s_cap = reinterpret_cast<const double*>(dt + o_cp); ea.min_rates = reinterpret_cast<const double*>(dt + o_mn);
+    ea.max_rates = reinterpret_cast<const double*>(dt + o_mxr);
+    ea.lb = reinterpret_cast<double*>(di + L.lb); ea.ub = reinterpret_cast<double*>(di + L.ub); ea.q = reinterpret_cast<double*>(di + L.q);
+    ea.so = reinterpret_cast<int32_t*>(di + L.so); ea.sl = reinterpret_cast<int32_t*>(di + L.sl); ea.sc = reinterpret_cast<double*>(di + L.sc);
+    hipLaunchKernelGGL(table_expand_kernel, dim3((unsigned)cn), dim3(256), 0, S.st, ea);
+    acnqp_problems dp;
+    dp.batch = (int32_t)cn; dp.t_max = (int32_t)Tm; dp.k_sessions = (int32_t)K;
+    dp.lb = ea.lb; dp.ub = ea.ub; dp.q = ea.q;
+    dp.pdiag = reinterpret_cast<const double*>(di + L.pd);
+    dp.horizon = reinterpret_cast<const int32_t*>(di + L.hz);
+    dp.s_off = ea.so; dp.s_len = ea.sl; dp.s_cap = ea.sc;
+    dp.s_eq = reinterpret_cast<const uint8_t*>(di + L.eq);
+    dp.peak = peak ? reinterpret_cast<const double*>(di + L.pk) : nullptr;
+    dp.lf = flat ? reinterpret_cast<const double*>(di + L.lf) : nullptr;
+    dp.dc = mx ? reinterpret_cast<const double*>(di + L.dc) : nullptr;
+    dp.dfloor = mx ? reinterpret_cast<const double*>(di + L.df) : nullptr;
+    dp.warm_x = nullptr; dp.warm_y = nullptr;
+    acnqp_results dr;
+    dr.x = reinterpret_cast<double*>(dq + L.x);
+    dr.status = reinterpret_cast<int32_t*>(dq + L.st);
+    dr.iters = reinterpret_cast<int32_t*>(dq + L.it);
+    dr.pri_res = reinterpret_cast<double*>(dq + L.pr);
+    dr.dua_res = reinterpret_cast<double*>(dq + L.du);
+    dr.obj = reinterpret_cast<double*>(dq + L.ob);
+    dr.x_dev = nullptr;
+    dr.y = want_y ? reinterpret_cast<double*>(dq + L.y) : nullptr;
+    const int rc = acnqp_solve_batch_device(h, &dp, o, &dr, S.st);
+    if (rc != ACNQP_OK) return rc;
+#define TD2H(field, base, elem, per)                                                                                          \
+  HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(R->field) + (size_t)lo * (per) * (elem), dq + (base), (size_t)cn * (per) * (elem), \
+                         hipMemcpyDeviceToHost, S.st))
+    TD2H(x, L.x, 8, nv);
+    TD2H(status, L.st, 4, 1);
+    TD2H(iters, L.it, 4, 1);
+    TD2H(pri_res, L.pr, 8, 1);
+    TD2H(dua_res, L.du, 8, 1);
+    TD2H(obj, L.ob, 8, 1);
+    if (want_y) TD2H(y, L.y, 8, Mg * Tm);
+#undef TD2H
+    if (R->x_dev) HIP_TRY(hipMemcpyAsync(R->x_dev + (size_t)lo * nv, dq + L.x, (size_t)cn * nv * 8, hipMemcpyDeviceToDevice, S.st));
+    lo += cn;
+  }
+  return ACNQP_OK;
+}
+
+}  // namespace
+
+int acnqp_solve_table(acnqp_handle* h, const acnqp_table* t, const acnqp_options* o, acnqp_results* r) {
+  const int rc0 = check_table(h, t, o, r);
+  if (rc0 != ACNQP_OK) return rc0;
+  if (t->batch == 0) return ACNQP_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  const int rc = run_table_pipeline(h, t, o, r);
+  hipError_t e = hipSuccess;   // drain every slot before returning, also on failure: nothing may touch the caller's buffers afterwards
+  for (auto& sl : h->slot) { const hipError_t e1 = hipStreamSynchronize(sl.st); if (e == hipSuccess) e = e1; }
+  if (rc != ACNQP_OK) return rc;
+  if (e != hipSuccess) return fail(ACNQP_ERR_HIP, std::string("acnqp_solve_table: ") + hipGetErrorString(e));
+  for (int b = 0; b < t->batch; ++b)
+    if (r->status[b] == ACNQP_STATUS_UNSET)
+      return fail(ACNQP_ERR_HIP, "acnqp_solve_table: problem " + std::to_string(b) +
+                                 " was never written by the kernel (status UNSET after synchronisation): the launch did not execute completely");
+  return ACNQP_OK;
+}
 
 int acnqp_solve_batches(acnqp_handle* h, int32_t n_batches, const acnqp_problems* p, const acnqp_options* o, acnqp_results* r) {
   if (!h || !p || !o || !r || n_batches < 0) return fail(ACNQP_ERR_INVALID, "acnqp_solve_batches: null argument or negative count");

@@ -268,6 +268,51 @@ def strict_batch256_leg(handle, batch, opts, calls=40):
             "qps": batch.B / med, "kernel_ms_median": float(np.median(k))}
 
 
+def host_inclusive_leg(infra, iface, objective, site, handle, opts, n_snapshots=16384, horizon=12, reps=3):
+    """From the caller's data to schedules, wall clock, ONE host thread: the statement -> arrays step
+    is part of `north_star`'s path ("a direct (P, q, A, l, u) builder in Python").
+      table:    a SessionTable of `n_snapshots` MPC snapshots (arrays from the start) -> builder.plan_from_table (numpy:
+                slots, energy caps, one linear cost per horizon) -> acnqp_solve_table (H2D of the sessions, the dense
+                problem arrays formed on the device, kernels, D2H of the schedules);
+      sessions: lists of SessionInfo objects -> AdaptiveSchedulingAlgorithm.schedule_batch -> one dict per snapshot
+                (reading the Python objects, pre- and post-processing included), on 2,048 snapshots."""
+    import numpy as np
+
+    from adacharge_amd import AdaptiveSchedulingAlgorithm, sites
+    from adacharge_amd.builder import plan_from_table
+
+    table = sites.snapshot_table(infra, horizon, n_snapshots, seed=424242)
+    t_plan, t_solve, solved = [], [], 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        plan = plan_from_table(table, infra, iface, objective, "SOC", site=site)
+        t1 = time.perf_counter()
+        res = handle.solve_table(plan, opts, pinned_results=False)
+        t2 = time.perf_counter()
+        t_plan.append(t1 - t0); t_solve.append(t2 - t1)
+        solved = int((res.status == 1).sum())
+    k = int(np.argmin(np.add(t_plan, t_solve)))
+    h2d = plan.S * (4 * 4 + 8) + (plan.S + 1) * 4 + plan.rate_seg[-1] * 16 + plan.B * (4 + 4 + 8 + 1 + 4) + plan.q_table.nbytes
+    out = {"table": {
+        "snapshots": n_snapshots, "sessions": int(plan.S), "qps": n_snapshots / (t_plan[k] + t_solve[k]),
+        "plan_ms": 1e3 * t_plan[k], "solve_table_ms": 1e3 * t_solve[k], "solved": solved,
+        "h2d_bytes_per_problem": float(h2d) / n_snapshots,
+        "note": "SessionTable -> plan_from_table (numpy, one thread) -> acnqp_solve_table (sessions to the device, lb / ub / q formed "
+                "there) -> schedules in host memory; best of %d" % reps}}
+    n2 = 2048
+    snaps = sites.snapshot_batch(infra, horizon, n2, seed=515151)
+    alg = AdaptiveSchedulingAlgorithm(objective, solver_options={})
+    alg.register_interface(iface)
+    alg.schedule_batch(snaps[:64])   # site handle, module load
+    t0 = time.perf_counter()
+    outs = alg.schedule_batch(snaps)
+    dt = time.perf_counter() - t0
+    out["sessions"] = {"snapshots": n2, "qps": n2 / dt, "ms": 1e3 * dt, "solved": int(sum(o is not None for o in outs)),
+                       "note": "lists of SessionInfo objects -> schedule_batch (pre-processing, table entry, post-processing) -> one "
+                               "{station: rates} dict per snapshot; one host thread"}
+    return out
+
+
 def cpu_baseline_leg(batch, gpu_x, gpu_status, target_seconds, snaps, infra, iface, accel_mem=0, first=256):
     """The ONLY place bench.py touches oracle/: the scalar C port of the device ADMM timed on the host cores over a
     bounded sample, which also serves as the parity check of the sample.
@@ -595,6 +640,8 @@ def main():
             out["cpu_baseline"] = cb
             out["parity"] = parity
         if world == 1 and not args.no_other_configs:
+            out["host_inclusive"] = host_inclusive_leg(infra, iface, objective, site, handle, opts, horizon=T)
+            out["polish"] = handle.polish_stats()
             out["strict_batch256"] = strict_batch256_leg(handle, batches[0], opts)
             out["other_configs"] = other_configs_leg(dev)
         print(json.dumps(out), file=json_out, flush=True)

@@ -182,7 +182,7 @@ typedef struct {
                             rounds); otherwise the problem is solved as if there were no polish (from scratch, with the
                             retry passes).  What an interior-point method -- the reference's ECOS, aco.py:318 -- gives
                             for free: no plateau on the congested, tangentially degenerate instances.  0 = off.
-                            Default 1200                                                                     */
+                            Default 800                                                                      */
   double retry_rho;      /* penalty of the first retry pass.  Default 0.5                                 */
   double inaccurate_floor; /* residual tolerance (absolute and relative) below which a pass that ran out of
                             iterations still counts as SOLVED_INACCURATE even when 100x the requested tolerance
@@ -215,6 +215,46 @@ int acnqp_solve_batch(acnqp_handle* h, const acnqp_problems* p,
  * the call fails with ACNQP_ERR_HIP.                                                 */
 int acnqp_solve_batches(acnqp_handle* h, int32_t n_batches, const acnqp_problems* p,
                         const acnqp_options* o, acnqp_results* r);
+
+/* A batch of problems as the SESSION TABLE the reference's statement is made of, instead of the dense arrays of
+ * acnqp_problems: what charging_rate_bounds (aco.py:45-79) and energy_constraints (aco.py:81-124) loop over -- one
+ * record per active session -- plus the linear cost once per distinct horizon (build_objective, aco.py:200-218: it
+ * depends on a problem only through T = max(offset + remaining), aco.py:243-245).  The library forms lb, ub, q and
+ * the per-EVSE session slots ON THE DEVICE (acn_qp_api.hip: table_expand_*), so that a problem costs ~1-4 KB of
+ * host-to-device traffic instead of 21.6 KB at 54 x 12 and no caller ever fills an (N, T) array per problem.
+ * Sessions are grouped by problem: problem b owns the sessions [sess_seg[b], sess_seg[b + 1]); session s owns the
+ * rate entries [rate_seg[s], rate_seg[s + 1]) -- exactly s_len[s] of them (aco.py:68, 73).  Windows of one EVSE must
+ * be disjoint (s_slot numbers them 0 .. k_sessions - 1 per EVSE and problem).  All pointers are HOST pointers.      */
+typedef struct {
+  int32_t batch;            /* B                                                                       */
+  int32_t t_max;            /* Tm >= every horizon                                                     */
+  int32_t k_sessions;       /* K: session slots per EVSE                                               */
+  int32_t n_sessions;       /* S                                                                       */
+  int32_t n_horizons;       /* H: rows of q_table                                                      */
+  const int32_t* horizon;   /* [B]       T_b                                                           */
+  const int32_t* q_index;   /* [B]       row of q_table holding this problem's linear cost             */
+  const double* q_table;    /* [H*N*Tm]  linear cost (minimisation form) per distinct horizon          */
+  const double* pdiag;      /* [B]                                                                     */
+  const uint8_t* s_eq;      /* [B]                                                                     */
+  const double* peak;       /* [B*Tm] or NULL                                                          */
+  const double* lf;         /* [B] or NULL                                                             */
+  const double* dc;         /* [B] or NULL                                                             */
+  const double* dfloor;     /* [B] or NULL                                                             */
+  const int32_t* sess_seg;  /* [B+1]     sessions of problem b: [sess_seg[b], sess_seg[b+1])           */
+  const int32_t* s_evse;    /* [S]       EVSE index                                                    */
+  const int32_t* s_slot;    /* [S]       slot of the session among its EVSE's sessions (0 .. K-1)      */
+  const int32_t* s_off;     /* [S]       arrival_offset                                                */
+  const int32_t* s_len;     /* [S]       remaining_time (<= 0: no window, no energy row)               */
+  const double* s_cap;      /* [S]       remaining_demand in A-periods (aco.py:114)                    */
+  const int32_t* rate_seg;  /* [S+1]     rate entries of session s: [rate_seg[s], rate_seg[s+1])       */
+  const double* min_rates;  /* [rate_seg[S]]  aco.py:68                                                */
+  const double* max_rates;  /* [rate_seg[S]]  aco.py:73 (ub < lb -> lb, aco.py:75, is applied here)     */
+} acnqp_table;
+
+/* acnqp_solve_table -- acnqp_solve_batch for a session table: same pipeline (chunks over internal streams, copies
+ * overlapped with kernels), same kernels, same results bit for bit as the dense arrays the table stands for
+ * (tests/test_table_entry.py).  Cold start only; results as acnqp_solve_batch (r->y and r->x_dev honoured).        */
+int acnqp_solve_table(acnqp_handle* h, const acnqp_table* t, const acnqp_options* o, acnqp_results* r);
 
 /* Pinned (page-locked) host memory for problem / result arrays; NULL on failure.    */
 void* acnqp_host_alloc(size_t bytes);

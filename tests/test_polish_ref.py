@@ -1,5 +1,5 @@
 """oracle/polish_ref.py -- the numpy specification of the device-side polish (adacharge_amd/csrc/acn_qp_polish.hpp) --
-against the IPM certificates of tests/golden/stalled.npz, on the CPU: started from the C twin's iterate after 1,200
+against the IPM certificates of tests/golden/stalled.npz, on the CPU: started from the C twin's iterate after 800
 iterations of its single adaptive pass (what the solver kernel hands over), the active-set Newton method reaches every
 certified optimum of horizon 12 and verifies the KKT conditions; the Schur-complement step it is built on equals the
 plain KKT solve.  The GPU twin of this test is tests/test_golden_stalled.py::test_polish_agrees_with_its_numpy_specification."""
@@ -22,7 +22,7 @@ def test_spec_reaches_the_certificate_from_the_twins_iterate(name):
     sl, infra, iface, meta, peak, exp = H.wide_case(g, name)
     obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, meta["es"])]
     batch = build_batch([sl], infra, iface, obj, meta["ct"], meta["eq"])
-    one = admm_port.solve_batch(batch, accel_mem=5, retry_passes=0, max_iter=1200)
+    one = admm_port.solve_batch(batch, accel_mem=5, retry_passes=0, max_iter=800)
     x, info = polish_ref.polish_batch_problem(batch, 0, one["x"][0], one["y"][0])
     assert info["ok"] and info["why"] == "kkt", info
     assert info["rounds"] <= 40 and info["rows"] <= polish_ref.MAX_ROWS
@@ -62,7 +62,7 @@ def test_spec_gives_up_cleanly():
     batch = build_batch([sl], infra, iface, obj, meta["ct"], meta["eq"])
     from oracle import admm_port
 
-    one = admm_port.solve_batch(batch, accel_mem=5, retry_passes=0, max_iter=1200)
+    one = admm_port.solve_batch(batch, accel_mem=5, retry_passes=0, max_iter=800)
     old = polish_ref.MAX_ROWS
     try:
         polish_ref.MAX_ROWS = 16
