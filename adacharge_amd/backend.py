@@ -388,9 +388,12 @@ class SiteHandle:
         res.kernel_ms = self._kernel_ms_of_call()
         return self._finish(batch, res)
 
-    def solve_table(self, plan, options: Optional[Options] = None, pinned_results: bool = False, want_y: bool = False) -> "BatchResult":
+    def solve_table(self, plan, options: Optional[Options] = None, pinned_results: bool = False, want_y: bool = False,
+                    out: Optional["BatchResult"] = None) -> "BatchResult":
         """acnqp_solve_table: a ``builder.TablePlan`` (sessions + one linear cost per horizon) in, schedules out; the
-        dense (B, N, Tm) problem arrays are formed on the device.  Same results as ``solve(plan.expand())``."""
+        dense (B, N, Tm) problem arrays are formed on the device.  Same results as ``solve(plan.expand())``.
+        ``out``: a BatchResult of an earlier call of the same shape to write into (a service that solves every control
+        period keeps its -- pinned -- result arrays instead of allocating 85 MB per call)."""
         if plan.site is not self.site and (plan.site.N, plan.site.Mg, plan.site.cone) != (self.site.N, self.site.Mg, self.site.cone):
             raise ValueError("plan was built for another site")
         o = options if options is not None else default_options()
@@ -408,10 +411,14 @@ class SiteHandle:
             "horizon", "q_index", "q_table", "pdiag", "s_eq", "peak", "lf", "dc", "dfloor", "sess_seg", "s_evse", "s_slot", "s_off",
             "s_len", "s_cap", "rate_seg", "min_rates", "max_rates")])
         new = pinned_empty if pinned_results else (lambda shape, dtype=np.float64: np.zeros(shape, dtype))
-        res = BatchResult(new((B, N, Tm)), new(B, np.int32), new(B, np.int32), new(B), new(B), new(B))
-        if want_y:
-            res.y = new((B, self.site.Mg, Tm))
-        r = _Results(_ptr(res.x), _ptr(res.status), _ptr(res.iters), _ptr(res.pri_res), _ptr(res.dua_res), _ptr(res.obj), _ptr(res.y), None)
+        if out is not None and out.x.shape == (B, N, Tm) and (not want_y or (out.y is not None and out.y.shape == (B, self.site.Mg, Tm))):
+            res = out
+        else:
+            res = BatchResult(new((B, N, Tm)), new(B, np.int32), new(B, np.int32), new(B), new(B), new(B))
+            if want_y:
+                res.y = new((B, self.site.Mg, Tm))
+        r = _Results(_ptr(res.x), _ptr(res.status), _ptr(res.iters), _ptr(res.pri_res), _ptr(res.dua_res), _ptr(res.obj),
+                     _ptr(res.y) if want_y else None, None)
         self.kernel_times()
         self._launches_seen = int(self._lib.acnqp_launch_count(self._h))
         _check(self._lib.acnqp_solve_table(self._h, C.byref(t), C.byref(o), C.byref(r)), "acnqp_solve_table")

@@ -572,6 +572,13 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   a.pbuf_single = 0;
   a.order = nullptr;
   a.queue = nullptr;
+  {
+    // launches of the handle's own pipeline streams (the host-buffer entries: several launches in flight) keep their
+    // workgroups only for a few problems each; a launch on a caller's stream is fully persistent
+    bool own = false;
+    for (auto& sl : h->slot) own = own || sl.st == st;
+    a.grid_oversub = own ? 4 : 1;
+  }
   a.polish_iters = 0; a.resume = 0; a.pol_rows = 0; a.pol_list = nullptr; a.pol_count = nullptr; a.count_dev = nullptr;
   (void)hipGetLastError();   // drop any stale error so the checks below report this launch only
   // a problem whose workgroup never ran must not look solved (or carry the previous call's status)
@@ -675,7 +682,13 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   static const bool no_polish = std::getenv("ACNQP_NO_POLISH") != nullptr;   // diagnostic
   if (!no_polish && o->polish_iters > 0 && o->polish_iters < o->max_iter && on_chip && h->N <= 64 && p->t_max <= 32 &&
       p->k_sessions <= acnqp::kMaxK && !h->has_flat && !h->has_max && !a.warm_x)
-    pol_rows = acnqp::polish_rows_that_fit(h->N, p->t_max, h->Mg, nrow_site);
+  {
+    // LDS of a polish workgroup: where the solver kernel runs two workgroups per CU (the headline shape: one column tile,
+    // one row tile, one session slot: 77 KB each) the polish takes no more than one of those slots, so that it starts as
+    // soon as ANY solver workgroup of a neighbouring stream's launch ends; elsewhere the whole CU
+    const bool two_per_cu = tiled && p->t_max <= 16 && d->MR == 16 && p->k_sessions == 1;
+    pol_rows = acnqp::polish_rows_that_fit(h->N, p->t_max, h->Mg, nrow_site, two_per_cu ? 76 * 1024 : 160 * 1024);
+  }
   hipError_t e = hipSuccess;
   if (pol_rows >= 32) {
     // [0] queue of the polish kernel, [1] queue of the resume launch, [2] list length; list[B]; multipliers [B][Mg][Tm]
@@ -703,7 +716,9 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
       pa.s_off = p->s_off; pa.s_len = p->s_len; pa.s_cap = p->s_cap; pa.s_eq = p->s_eq; pa.peak = h->has_peak ? p->peak : nullptr;
       pa.x = r->x; pa.y = ybuf; pa.status = r->status; pa.iters = r->iters; pa.pri = r->pri_res; pa.dua = r->dua_res; pa.obj = r->obj;
       pa.list = list; pa.count = ctr + 2; pa.queue = ctr + 0; pa.stats = h->pol_stats; pa.reg_rel = o->reg_rel;
-      e = acnqp::launch_polish(pa, h->cus, st);
+      // (pipelined chunks hand a handful of problems over: few workgroups, so that the launch does not queue for 256 slots
+      //  behind the neighbouring streams' solver launches)
+      e = acnqp::launch_polish(pa, a.grid_oversub > 1 ? 32 : h->cus, st);
     }
     if (e == hipSuccess) {
       acnqp::TiledArgs a3 = a;
@@ -712,7 +727,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
       // retry passes that may follow start cold, as always).  Measured on jpl52 x 24 x 4,096, where two problems have more
       // tight rows than the polish holds: from scratch the launch took 93 ms against 61 ms without a polish.
       a3.warm_x = r->x; a3.warm_y = ybuf;
-      a3.ws_by_slot = 1; a3.grid_cap = std::min(p->batch, 2 * h->cus);   // (<= the grid the workspace was sized for)
+      a3.ws_by_slot = 1; a3.grid_cap = std::min(p->batch, a.grid_oversub > 1 ? 64 : 2 * h->cus);   // (<= the grid the workspace was sized for)
       if (!a.ws_by_slot) a3.grid_cap = std::min(a3.grid_cap, a.grid_cap);
       e = launch_solver(a3);
     }

@@ -41,13 +41,54 @@ inline int accel_capacity_best(int NW, int MT, int CT, int NP, int K, int* pbuf_
 // Grid of a launch.  With the work queue (a.queue set) it is the number of workgroups the chip keeps RESIDENT for this
 // kernel -- occupancy x compute units, never more than the problems or than `a.grid_cap` -- and the workgroups fetch
 // problems until the queue is empty (queue_next, acn_qp_tiled.hpp); without it one workgroup per problem.
+// (occupancy and device queries cost tens of microseconds each: with three launches per pipelined chunk they made the
+//  host thread the bottleneck -- 18 chunks per step -- so both are cached per (kernel, block size, LDS) and per device)
+inline int resident_per_cu(const void* kern, int threads, size_t lds) {
+  struct Key { const void* k; int t; size_t l; int dev; int v; };
+  static thread_local Key cache[16];
+  static thread_local int used = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  for (int i = 0; i < used; ++i)
+    if (cache[i].k == kern && cache[i].t == threads && cache[i].l == lds && cache[i].dev == dev) return cache[i].v;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+  cache[used < 16 ? used++ : 15] = Key{kern, threads, lds, dev, per_cu};
+  return per_cu;
+}
+inline int device_cus() {
+  static thread_local int cache[16] = {0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && cache[dev] > 0) return cache[dev];
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+  if (dev >= 0 && dev < 16) cache[dev] = cus;
+  return cus;
+}
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) and growing size, not once per launch
+inline hipError_t ensure_dynamic_lds(const void* kern, size_t lds) {
+  struct Key { const void* k; int dev; size_t l; };
+  static thread_local Key cache[32];
+  static thread_local int used = 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  for (int i = 0; i < used; ++i)
+    if (cache[i].k == kern && cache[i].dev == dev) {
+      if (cache[i].l >= lds) return hipSuccess;
+      const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess) cache[i].l = lds;
+      return e;
+    }
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess && used < 32) cache[used++] = Key{kern, dev, lds};
+  return e;
+}
 template <typename Kern>
 inline int launch_grid(Kern kern, int threads, size_t lds, const TiledArgs& a) {
   if (!a.queue) return a.B;
-  int per_cu = 0, dev = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-  return std::max(1, std::min(std::min(a.B, a.grid_cap > 0 ? a.grid_cap : a.B), per_cu * cus));
+  const int per_cu = resident_per_cu(reinterpret_cast<const void*>(kern), threads, lds), cus = device_cus();
+  return std::max(1, std::min(std::min(a.B, a.grid_cap > 0 ? a.grid_cap : a.B), per_cu * cus * std::max(1, a.grid_oversub)));
 }
 
 // register-resident kernel (acn_qp_tiled.hpp): N <= 64, one / two column tiles; a.accel_mem = columns requested
@@ -60,8 +101,8 @@ int long_tiles(int t_max);
 hipError_t launch_long(const StreamArgs& sa, hipStream_t st, bool lds_resident);
 // polish kernel (acn_qp_polish.hpp): rows of the Schur system its LDS holds for a shape (0: does not fit); launch over
 // the list the solver kernel left
-int polish_rows_that_fit(int N, int Tm, int Mg, int nrow);
-hipError_t launch_polish(const PolishArgs& pa, int cus, hipStream_t st);
+int polish_rows_that_fit(int N, int Tm, int Mg, int nrow, int lds_bytes);
+hipError_t launch_polish(const PolishArgs& pa, int max_grid, hipStream_t st);
 // general-shape kernel (acn_qp_general.hpp), `threads` in {256, 512, 1024}
 hipError_t launch_general(const GeneralArgs& ga, int threads, hipStream_t st);
 

@@ -15,7 +15,7 @@ static hipError_t launch_long_one(const StreamArgs& sa, hipStream_t st) {
   const size_t lds = (size_t)2 * MT * CTL * 256 * sizeof(double);   // e^, h^
   auto kern = &admm_long_kernel<CTL, MT, NWV>;
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(kern, dim3(launch_grid(kern, NWV * 64, lds, sa.t)), dim3(NWV * 64), lds, st, sa);
@@ -29,7 +29,7 @@ static hipError_t launch_long_rzl(const StreamArgs& sa, hipStream_t st) {
   const int NE = sa.t.NP / 16;
   const size_t lds = (size_t)256 * CTL * (2 * MT + NE) * sizeof(double);
   auto kern = &admm_long_kernel<CTL, MT, NWV, false, true>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(launch_grid(kern, NWV * 64, lds, sa.t)), dim3(NWV * 64), lds, st, sa);
   return hipGetLastError();
@@ -41,7 +41,7 @@ static hipError_t launch_long_xsl(const StreamArgs& sa, hipStream_t st) {
   const int NE = sa.t.NP / 16;
   const size_t lds = (size_t)256 * CTL * (2 * MT + 2 * NE) * sizeof(double);
   auto kern = &admm_long_kernel<CTL, MT, NWV, false, true, true>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(launch_grid(kern, NWV * 64, lds, sa.t)), dim3(NWV * 64), lds, st, sa);
   return hipGetLastError();
@@ -61,7 +61,7 @@ static hipError_t launch_long_lds(const StreamArgs& sa, hipStream_t st) {
   const int NE = sa.t.NP / 16;
   const size_t lds = (size_t)256 * CTL * (5 * MT + 7 * NE) * sizeof(double);   // e^, h^, site rows; 7 iterate arrays
   auto kern = &admm_long_kernel<CTL, MT, NWV, true>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(launch_grid(kern, NWV * 64, lds, sa.t)), dim3(NWV * 64), lds, st, sa);
   return hipGetLastError();

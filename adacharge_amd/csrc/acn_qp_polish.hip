@@ -3,18 +3,22 @@
 
 namespace acnqp {
 
-int polish_rows_that_fit(int N, int Tm, int Mg, int nrow) {
-  return PolishLds::rows_that_fit(N, Tm, Mg, nrow, kLdsPerCu - 2048);
+int polish_rows_that_fit(int N, int Tm, int Mg, int nrow, int lds_bytes) {
+  return PolishLds::rows_that_fit(N, Tm, Mg, nrow, std::min(lds_bytes, kLdsPerCu - 2048));
 }
 
-hipError_t launch_polish(const PolishArgs& pa, int cus, hipStream_t st) {
+hipError_t launch_polish(const PolishArgs& pa, int max_grid, hipStream_t st) {
   const int nrow = pa.M + (pa.has_peak ? 1 : 0);
   const PolishLds L(pa.N, pa.Tm, pa.Mg, nrow, pa.max_rows);
   const size_t lds = (size_t)L.total * sizeof(double);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polish_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const bool small = pa.Tm <= 16;
+  hipError_t e = small ? ensure_dynamic_lds(reinterpret_cast<const void*>(&polish_kernel<4>), lds)
+                       : ensure_dynamic_lds(reinterpret_cast<const void*>(&polish_kernel<8>), lds);
   if (e != hipSuccess) return e;
-  // one workgroup per CU at most (the Schur system fills the LDS); the workgroups share the list through the queue
-  hipLaunchKernelGGL(polish_kernel<0>, dim3(std::max(1, std::min(pa.B, cus))), dim3(kPolThreads), lds, st, pa);
+  // `max_grid` workgroups share the list through the queue (a lone launch: one per CU; a pipelined one: a few -- its list is short)
+  const dim3 grid(std::max(1, std::min(pa.B, max_grid)));
+  if (small) hipLaunchKernelGGL(polish_kernel<4>, grid, dim3(kPolThreads), lds, st, pa);
+  else hipLaunchKernelGGL(polish_kernel<8>, grid, dim3(kPolThreads), lds, st, pa);
   return hipGetLastError();
 }
 

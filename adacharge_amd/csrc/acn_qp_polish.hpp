@@ -23,7 +23,6 @@
 namespace acnqp {
 
 constexpr int kPolThreads = 256;
-constexpr int kPolTQ = 8;            // periods per thread (Tm <= 32)
 constexpr int kPolMaxRounds = 96;
 constexpr double kPolTolBound = 1e-7;    // |x - bound| below which the ADMM iterate counts as "on the bound"
 constexpr double kPolTolRow = 1e-9;      // relative size of a site-row multiplier that counts as non-zero
@@ -136,8 +135,12 @@ __device__ inline void pol_block_argmin(double& v, int& code, double* red) {
 constexpr int kPolLb = 0, kPolUb = 1, kPolSess = 2, kPolRow = 3;
 __device__ inline int pol_code(int kind, int p0, int p1) { return (kind << 24) | (p0 << 8) | p1; }
 
-template <int kVariant>   // (a template only so that the header can be included by every translation unit; instantiated in acn_qp_polish.hip)
-__global__ __launch_bounds__(kPolThreads, 1) void polish_kernel(const PolishArgs A) {
+// kPolTQ: periods per thread, 4 (horizons <= 16) or 8 (<= 32).  Two workgroups per CU: a polish workgroup then takes ONE of
+// the two slots the register-resident solver kernel's workgroups take (256 registers, <= 76 KB of LDS on its shapes) and
+// starts as soon as any of them ends -- at one per CU (362 registers) it needed a CU to itself and, in the pipelined host
+// path, held 32 CUs away from the neighbouring streams' solver launches: -10 % end to end.
+template <int kPolTQ>
+__global__ __launch_bounds__(kPolThreads, kPolTQ == 4 ? 2 : 1) void polish_kernel(const PolishArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char pol_smem[];
   double* sm = reinterpret_cast<double*>(pol_smem);
   const int N = A.N, Tm = A.Tm, K = A.K, M = A.M, Mg = A.Mg;

@@ -9,7 +9,7 @@ static hipError_t launch_stream_nwv(const StreamArgs& sa, hipStream_t st) {
   const size_t lds = (size_t)L.total * sizeof(double);
   auto kern = &admm_stream_kernel<CT, MT, NWV>;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(kern, dim3(launch_grid(kern, NWV * 64, lds, sa.t)), dim3(NWV * 64), lds, st, sa);

@@ -105,6 +105,9 @@ struct TiledArgs {
   int32_t *pol_list, *pol_count;
   const int32_t* count_dev;   // number of queue positions, on the device (null: B)
   int ws_by_slot;  // 1: a streaming kernel's workspace belongs to the workgroup slot (work-queue launches), 0: to the problem
+  int grid_oversub; // host side only: workgroups of a work-queue launch per resident slot (1: fully persistent; the pipelined
+                    // host entries use 4, so that slots come free while a launch runs and the next stream's small launches --
+                    // the polish, the resume -- do not wait for a whole persistent launch to drain)
   int grid_cap;    // host side only: most workgroups a launch may have (the kernels that stream their state own one
                    // workspace per workgroup slot)
 };

@@ -12,8 +12,7 @@ hipError_t launch_tiled_occ(const TiledArgs& a, hipStream_t st) {
   const size_t lds = (size_t)L.total * 8;
   auto kern = &admm_tiled_kernel<double, NW, CT, MT, KS, OCC, AM>;
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(kern, dim3(launch_grid(kern, NW * 64, lds, a)), dim3(NW * 64), lds, st, a);

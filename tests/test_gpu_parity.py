@@ -362,7 +362,7 @@ def test_config3_horizon24_batch4096(site_name):
     sb = batch.subset(slice(0, 4))
     # ... near-bitwise without Anderson acceleration (same arithmetic, same iteration counts) ...
     ref = admm_port.solve_batch(sb, threads=4, accel_mem=0)
-    plain = h.solve(sb, default_options(accel_mem=0))
+    plain = h.solve(sb, default_options(accel_mem=0, polish_iters=0))
     assert np.abs(ref["x"] - plain.x).max() <= 1e-5
     assert (ref["iters"] == plain.iters).all()
     # ... and to solver tolerance with it (the extrapolation amplifies rounding differences)
@@ -445,7 +445,7 @@ def test_wide_site_stream_kernel():
         res = h.solve(batch, default_options())
         assert (res.status == 1).all()
         # plain iteration: near-bitwise against the C port; accelerated (the default): to solver tolerance
-        plain = h.solve(batch, default_options(accel_mem=0))
+        plain = h.solve(batch, default_options(accel_mem=0, polish_iters=0))
         ref = admm_port.solve_batch(batch, threads=8, accel_mem=0)
         assert (ref["status"] == 1).all() and (plain.status == 1).all()
         assert np.abs(ref["x"] - plain.x).max() <= 1e-5
@@ -917,7 +917,7 @@ def test_accel_columns_and_kernel_times():
     assert h.kernel_times() == []
     assert abs(h.last_kernel_ms() - times[-1]) < 1e-6
     # acceleration on/off: same schedule to solver tolerance, fewer iterations with it
-    plain = h.solve(batch, default_options(accel_mem=0))
+    plain = h.solve(batch, default_options(accel_mem=0, polish_iters=0))
     fast = h.solve(batch, o)
     assert (plain.status == 1).all() and (fast.status == 1).all()
     assert np.abs(plain.x - fast.x).max() <= 1e-4 * 32
