@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     pd = effective_pdiag<real>(pd_user, A.reg_rel, qnorm, f[1], A.horizon[b], lfb > 0.0 || dcb > 0.0);
     if (f[2] > 0) {
       for (size_t k = tid; k < (size_t)N * Tm; k += NWV * 64) A.x[(size_t)b * N * Tm + k] = 0;
-      if (A.y_out)
+      if (A.y_out && !A.y_for_polish_only)
         for (size_t k = tid; k < (size_t)A.Mg * Tm; k += NWV * 64) A.y_out[(size_t)b * A.Mg * Tm + k] = 0;
       if (tid == 0) { A.status[b] = 4; A.iters[b] = 0; A.pri[b] = M::big; A.dua[b] = M::big; A.obj[b] = 0; }
       break;   // (block-uniform) out of the pass loop: the next problem of the queue
@@ -918,6 +918,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       for (int pi = wave; pi < 2 * NE; pi += NWV) {
         RELANE();
         const int e = pi >> 1, r0_ = (pi & 1) * 2;
+        // an item whose eight EVSEs are all padding (54 EVSEs: rows 56..63, one item in eight) holds zeros in every array
+        // and keeps them (lb = ub = q = 0, zero columns of Ghat): it is not streamed at all -- 1/8 of this phase's bytes
+        // on the Caltech-shaped site, where the kernel is bandwidth-bound at 2,048 problems (block-uniform per wave)
+        if (16 * e + 4 * r0_ >= N) continue;
         real zh2[2][CTL], lb2[2][CTL], ub2[2][CTL], z1p[2][CTL];
 #pragma unroll
         for (int c = 0; c < CTL; ++c) {   // padding columns hold zeros and stay zero
@@ -947,6 +951,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
     for (int ri = wave; ri < 4 * NE; ri += NWV) {
       RELANE();
       const int e = ri >> 2, r = ri & 3;
+      if (16 * e + 4 * r >= N) continue;   // four padding EVSEs: zeros that stay zeros (see the pair-row loop)
       real zh[CTL], lbv[CTL], ubv[CTL], z1[CTL];
 #pragma unroll
       for (int c = 0; c < CTL; ++c) {   // padding columns hold zeros and stay zero
@@ -1232,7 +1237,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   for (int q = wave; q < n_tile; q += NWV) {
     RELANE();
     if (q < n_site) {
-      if (A.y_out) {   // site-row multipliers in the caller's row order and units
+      if (A.y_out && (!A.y_for_polish_only || status == kStatusPolish)) {   // site-row multipliers in the caller's row order and units
         const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {

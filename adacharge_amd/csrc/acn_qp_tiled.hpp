@@ -100,6 +100,8 @@ struct TiledArgs {
   //    `resume` = 1 is the launch that follows the polish kernel: it runs over pol_list (order = pol_list, count_dev = its
   //    length, on the device), skips what the polish solved and solves the rest from scratch as if there were no polish
   int polish_iters, resume;
+  int y_for_polish_only;      // 1: y_out is the polish's internal buffer -- only a problem that is handed over writes it (the
+                              // multipliers of every problem were 5.4 KB of HBM writes per problem for 1.5 KB of payload)
   int pol_rows;               // rows of the polish kernel's Schur system for this shape: a problem whose iterate has more tight site
                               // rows than that is not handed over (it would come straight back) and the ADMM goes on
   int32_t *pol_list, *pol_count;
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
           const int tt = 16 * c + t, ev = 16 * wave + M::rowof(g, r);
           if (evact[r] && tt < Tm) A.x[((size_t)b * N + ev) * Tm + tt] = 0;
         }
-      if (A.y_out)
+      if (A.y_out && !A.y_for_polish_only)
         for (int k = tid; k < A.Mg * Tm; k += NW * 64) A.y_out[(size_t)b * A.Mg * Tm + k] = 0;
       if (tid == 0) {
         A.status[b] = 4; A.iters[b] = 0;
@@ -1669,7 +1671,7 @@ __global__ __launch_bounds__(NW * 64, OCC) void admm_tiled_kernel(const TiledArg
         ol += ((real)0.5 * pd_user * z1[c][r] + qv[c][r]) * z1[c][r];
       }
     }
-  if (A.y_out && wave == 0) {   // site-row multipliers in the caller's row order and units (the state is replicated: wave 0 writes)
+  if (A.y_out && wave == 0 && (!A.y_for_polish_only || status == kStatusPolish)) {   // site-row multipliers in the caller's row order and units (the state is replicated: wave 0 writes)
     const real* RS = static_cast<const real*>(A.rowscale);
 #pragma unroll
     for (int m = 0; m < MT; ++m)

@@ -170,3 +170,64 @@ def test_polish_agrees_with_its_numpy_specification():
         # (the multipliers of a degenerate vertex are the least-norm ones of a regularised, nearly singular system: they
         #  agree to three digits between two summation orders, the schedule to seven)
         assert np.abs(info["y"] - res.y[b][:, :T]).max() <= 2e-3 * max(1.0, float(np.abs(info["y"]).max())), names[b]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ct,with_peak", [("LINEAR", False), ("LINEAR", True), ("SOC", True)])
+def test_polish_on_box_rows_and_peak_rows_agrees_with_the_unpolished_solve(ct, with_peak):
+    """The stalled fixtures are SOC sites without a peak limit; the polish also serves LINEAR rows (|C| r <= limit,
+    aco.py:165-172) and the peak row (aco.py:196-198).  256 demand scenarios of the congested 36-EVSE site with a low
+    hand-over (polish_iters = 200 / 60, so that dozens of problems take it): every problem SOLVED, the polished schedules
+    within the north star's 1e-4 x 32 A of the schedules the ADMM alone reaches (polish_iters = 0), every row met, and two
+    of the polished problems against the IPM oracle."""
+    from adacharge_amd.acn import Interface
+    from adacharge_amd.backend import SiteHandle, default_options
+    from adacharge_amd.builder import scenario_batch
+    from adacharge_amd import sites
+    from oracle.ipm import solve_certified
+    from oracle.ref_problem import build_reference_problem
+
+    infra = sites.eight_sites()[3]
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    rng = np.random.default_rng(503)
+    base_sl = sites.random_sessions(infra, 12, rng)
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    peak = 0.55 * 32.0 * len(base_sl) if with_peak else None
+    base = build_batch([base_sl], infra, iface, obj, ct, peak_limits=[peak])
+    batch = scenario_batch(base, rng.lognormal(0.0, 0.25, size=(256, base.K, base.N)))
+    h = SiteHandle(batch.site, 0)
+    s0 = h.polish_stats()
+    P = 200 if ct == "SOC" else 60    # (box rows converge sooner: an earlier hand-over so that the polish gets problems at all)
+    pol = h.solve(batch, default_options(polish_iters=P))
+    s1 = h.polish_stats()
+    ref = h.solve(batch, default_options(polish_iters=0))
+    h.close()
+    tried, won = s1["attempted"] - s0["attempted"], s1["solved"] - s0["solved"]
+    assert tried >= 10 and won >= 0.9 * tried, (s0, s1)
+    assert (pol.status == 1).all() and (ref.status == 1).all()
+    assert np.abs(pol.x - ref.x).max() <= RATE_TOL, float(np.abs(pol.x - ref.x).max())
+    assert pol.iters.sum() < ref.iters.sum()
+    T = int(batch.T[0])
+    if ct == "SOC":
+        for b in range(0, 256, 17):
+            H.assert_infrastructure_satisfied(pol.x[b][:, :T], infra, tol=1e-5)
+    else:
+        assert (np.einsum("mn,bnt->bmt", np.abs(infra.constraint_matrix), pol.x) <= infra.constraint_limits[None, :, None] + 1e-5).all()
+    if with_peak:
+        assert (pol.x.sum(axis=1) <= peak + 1e-5).all()
+    # two polished problems (iters = P + Newton rounds) against the IPM on the problem the reference states
+    polished = np.flatnonzero((pol.iters > P) & (pol.iters < P + 97))[:2]
+    assert len(polished) == 2
+    k = float(infra.voltages[0]) * 5 / 1e3 / 60
+    for b in polished:
+        from adacharge_amd.acn import SessionInfo
+
+        sl = []
+        for s in base_sl:
+            i = infra.get_station_index(s.station_id)
+            sl.append(SessionInfo(s.station_id, s.session_id, float(batch.s_cap[b, 0, i]) * k, 0.0, s.arrival, s.departure,
+                                  current_time=0, min_rates=s.min_rates.copy(), max_rates=s.max_rates.copy()))
+        prob = build_reference_problem(sl, infra, iface, [("quick_charge", 1, {}), ("equal_share", 1e-3, {})], ct, False, peak_limit=peak)
+        r, _, cert = solve_certified(prob)
+        assert cert is not None and cert.worst < 1e-7
+        assert np.abs(pol.x[b][:, :T] - r).max() <= RATE_TOL, (int(b), float(np.abs(pol.x[b][:, :T] - r).max()))

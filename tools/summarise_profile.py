@@ -14,6 +14,8 @@ import sys
 tag = sys.argv[1]
 KERNEL = sys.argv[2] if len(sys.argv) > 2 else "admm_tiled_kernel"
 TRAFFIC_FILE = sys.argv[3] if len(sys.argv) > 3 else "hbm_traffic.json"
+MIN_PROBLEMS = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # skip dispatches of fewer workgroups (round 4: the resume launch
+                                                              # behind the polish is the same kernel on a handful of problems)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -33,6 +35,8 @@ for f in sorted(newest.values()):
     per = {}
     for row in csv.DictReader(open(f)):
         if KERNEL not in row["Kernel_Name"]:
+            continue
+        if MIN_PROBLEMS and int(row["Grid_Size"]) // max(int(row["Workgroup_Size"]), 1) < MIN_PROBLEMS:
             continue
         per.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
         per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
