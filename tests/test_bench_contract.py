@@ -1,5 +1,5 @@
 """The JSON line bench.py prints is a contract with the driver: check the committed record of the last GPU run
-(profiles/r03_bench.json, written by `python bench.py` on an MI355X) and the bookkeeping helpers, on the CPU."""
+(profiles/r04_bench.json, written by `python bench.py` on an MI355X) and the bookkeeping helpers, on the CPU."""
 import json
 import os
 
@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -49,7 +49,8 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["traffic"] is None or r["traffic"] > h["algorithmic_bytes_per_launch"]
     # the other BASELINE.json configurations are in the driver's line
     legs = d["other_configs"]
-    for name in ("cfg2_caltech54_T24_b4096", "cfg2_jpl52_T24_b4096", "cfg3_site3_T12_b1024", "cfg4_synth512_T48_b2048", "stress_caltech54_T144_b256"):
+    for name in ("cfg2_caltech54_T24_b4096", "cfg2_jpl52_T24_b4096", "cfg3_site3_T12_b1024", "cfg4_synth512_T48_b2048", "stress_caltech54_T144_b256",
+                 "stress_caltech54_T144_b2048"):
         leg = legs[name]
         for k in ("kernel_ms", "iters_mean", "iters_max", "solved", "algorithmic_bytes_per_launch", "hbm_frac", "fp64_frac"):
             assert k in leg, (name, k)
@@ -58,6 +59,18 @@ def test_committed_bench_line_has_the_contract_fields():
     assert legs["cfg4_synth512_T48_b2048"]["anderson_columns"] == 5
     sb = d["strict_batch256"]
     assert sb["batch"] == 256 and sb["qps"] > 0 and sb["ms_per_call_median"] > sb["kernel_ms_median"]
+    # round 4: the straggler tail is gone from the congested configs[3] site (<= 2,500 iterations, <= 15 ms)
+    s3 = legs["cfg3_site3_T12_b1024"]
+    assert s3["iters_max"] <= 2500 and s3["kernel_ms"] <= 15.0, s3
+    # ... the host side is in the driver's line (item 4: >= 200 k QP/s from a SessionTable, the builder inside the clock)
+    hi = d["host_inclusive"]
+    assert hi["table"]["solved"] == hi["table"]["snapshots"] == 16384 and hi["table"]["qps"] >= 200e3, hi["table"]
+    assert hi["table"]["h2d_bytes_per_problem"] < 0.3 * r["hbm"]["bytes_per_qp"]
+    assert hi["sessions"]["solved"] == hi["sessions"]["snapshots"]
+    # ... the polish's counters, and a CPU baseline that is not tail-bound (item 7: >= 32 problems per thread)
+    pol = d["polish"]
+    assert pol["attempted"] > 0 and pol["solved"] >= 0.98 * pol["attempted"], pol
+    assert c["problems_per_thread_per_pass"] >= 32 and c["one_thread_qps"] > 0 and c["highs_linear_ms_per_solve_1thread"] > 0
 
 
 def test_bench_gpus_flag_needs_matching_world_size(monkeypatch):
