@@ -678,21 +678,23 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   // the list -> solver kernel again over the list for what the polish gave up on (from scratch, with the retry passes:
   // the answer it had before there was a polish).  Three launches on the stream, the last two nearly empty as a rule.
   const int nrow_site = h->M + h->has_peak;
-  int pol_rows = 0;
+  int pol_blk = -1;   // LDS doubles for the blocks of the polish's system; -1: no polish for this launch
   static const bool no_polish = std::getenv("ACNQP_NO_POLISH") != nullptr;   // diagnostic
   if (!no_polish && o->polish_iters > 0 && o->polish_iters < o->max_iter && on_chip && h->N <= 64 && p->t_max <= 32 &&
-      p->k_sessions <= acnqp::kMaxK && !h->has_flat && !h->has_max && !a.warm_x)
-  {
+      p->k_sessions <= acnqp::kMaxK && !h->has_flat && !h->has_max && !a.warm_x && nrow_site > 0) {
     // LDS of a polish workgroup: where the solver kernel runs two workgroups per CU (the headline shape: one column tile,
     // one row tile, one session slot: 77 KB each) the polish takes no more than one of those slots, so that it starts as
     // soon as ANY solver workgroup of a neighbouring stream's launch ends; elsewhere the whole CU
     const bool two_per_cu = tiled && p->t_max <= 16 && d->MR == 16 && p->k_sessions == 1;
-    pol_rows = acnqp::polish_rows_that_fit(h->N, p->t_max, h->Mg, nrow_site, two_per_cu ? 76 * 1024 : 160 * 1024);
+    pol_blk = acnqp::polish_blocks_that_fit(h->N, p->t_max, h->Mg, nrow_site, two_per_cu ? 76 * 1024 : 160 * 1024);
+    if (pol_blk < 2 * nrow_site * (2 * nrow_site + 1) / 2) pol_blk = -1;   // not even one full block
   }
   hipError_t e = hipSuccess;
-  if (pol_rows >= 32) {
+  if (pol_blk >= 0) {
     // [0] queue of the polish kernel, [1] queue of the resume launch, [2] list length; list[B]; multipliers [B][Mg][Tm]
-    // unless the caller wants them anyway
+    // unless the caller wants them anyway; then the polish's global scratch for Schur systems beyond its LDS
+    const int pol_max = acnqp::polish_max_rows(nrow_site, p->t_max);
+    const int pol_grid = std::max(1, std::min(p->batch, a.grid_oversub > 1 ? 32 : h->cus));
     const size_t ybytes = r->y ? 0 : (size_t)p->batch * h->Mg * p->t_max * sizeof(double);
     const size_t lbytes = ((size_t)p->batch * sizeof(int32_t) + 255) & ~(size_t)255;
     const size_t need = 256 + lbytes + ybytes;
@@ -705,13 +707,13 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     acnqp::TiledArgs a1 = a;
     a1.polish_iters = o->polish_iters - o->polish_iters % std::max(1, o->check_every);   // the exit is taken at a residual check
     if (a1.polish_iters < o->check_every) a1.polish_iters = o->check_every;
-    a1.pol_list = list; a1.pol_count = ctr + 2; a1.y_out = ybuf; a1.pol_rows = pol_rows;
+    a1.pol_list = list; a1.pol_count = ctr + 2; a1.y_out = ybuf; a1.pol_rows = pol_max;
     a1.y_for_polish_only = r->y ? 0 : 1;
     e = launch_solver(a1);
     if (e == hipSuccess) {
       acnqp::PolishArgs pa;
       pa.B = p->batch; pa.N = h->N; pa.Tm = p->t_max; pa.K = p->k_sessions; pa.M = h->M; pa.Mg = h->Mg; pa.cone = h->cone;
-      pa.has_peak = h->has_peak; pa.max_rows = pol_rows;
+      pa.has_peak = h->has_peak; pa.max_rows = pol_max; pa.blk_doubles = pol_blk;
       pa.G = d->Gabi; pa.limits = d->limabi;
       pa.horizon = p->horizon; pa.lb = p->lb; pa.ub = p->ub; pa.q = p->q; pa.pdiag = p->pdiag;
       pa.s_off = p->s_off; pa.s_len = p->s_len; pa.s_cap = p->s_cap; pa.s_eq = p->s_eq; pa.peak = h->has_peak ? p->peak : nullptr;
@@ -719,7 +721,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
       pa.list = list; pa.count = ctr + 2; pa.queue = ctr + 0; pa.stats = h->pol_stats; pa.reg_rel = o->reg_rel;
       // (pipelined chunks hand a handful of problems over: few workgroups, so that the launch does not queue for 256 slots
       //  behind the neighbouring streams' solver launches)
-      e = acnqp::launch_polish(pa, a.grid_oversub > 1 ? 32 : h->cus, st);
+      e = acnqp::launch_polish(pa, pol_grid, st);
     }
     if (e == hipSuccess) {
       acnqp::TiledArgs a3 = a;

@@ -28,7 +28,7 @@ from __future__ import annotations
 
 import numpy as np
 
-MAX_ROWS = 112          # rows of the Schur system the kernel's LDS holds
+MAX_ROWS = 256          # rows of the Schur system at most (the kernel keeps it in LDS up to what fits, in L2 beyond)
 MAX_ROUNDS = 96
 TOL_BOUND = 1e-7        # |x - bound| below which the ADMM iterate counts as "on the bound"
 TOL_ROW = 1e-9          # relative size of a site-row multiplier that counts as non-zero
@@ -36,7 +36,10 @@ TOL_STEP = 1e-7         # convergence of a round: |dx|_inf <= TOL_STEP max(1, |x
                         # ~4e-8 A of noise in dx on the degenerate instances: 1e-9 cost six idle rounds; the KKT check decides)
 TOL_DUAL = 1e-9         # a multiplier below -TOL_DUAL max(1, |q|_inf) leaves the working set
 TOL_PRIMAL = 1e-9       # accepted violation of a row, relative to max(1, limit)
-REG_REL = 1e-9          # dual regularisation of the Schur system, relative to pd
+STALL_ROUNDS = 4        # full steps without progress that count as the noise floor
+REG_REL = 1e-9          # dual regularisation of the Schur system, relative to pd ...
+REG_DIAG = 1e-12        # ... and relative to the largest |R_a|^2, whichever is larger (1e-11 already biases the answer
+                        # beyond the KKT check; 1e-12 halves the rounds of the worst horizon-24 instance)
 TANGENT_MIN = 1e-7      # a disc whose multiplier is below TANGENT_MIN max(1, |q|_inf) gets no curvature row
 
 
@@ -71,6 +74,82 @@ def cholesky_solve(S, rhs, reg):
         y[k] /= L[k, k]
         y[:k] -= L[k, :k] * y[k]
     return y
+
+
+def ldl_factor(A):
+    """In-place unit-lower L D L' of a symmetric matrix (no pivoting); returns (L with unit diagonal implied, D) or None
+    when a pivot is not positive.  L[r][k] is stored UNSCALED as the kernel stores it: A[r][k] after the updates of the
+    columns before k; the scaled factor is A[r][k] / D[k]."""
+    n = len(A)
+    A = A.copy()
+    for k in range(n):
+        piv = A[k, k]
+        if not piv > 0.0:
+            return None
+        l = A[k + 1:, k] / piv
+        A[k + 1:, k + 1:] -= np.outer(l, A[k + 1:, k])
+    return A
+
+
+def ldl_solve(F, b):
+    n = len(b)
+    D = np.diag(F).copy()
+    z = b.copy()
+    for k in range(n):                      # L z = b
+        z[k + 1:] -= F[k + 1:, k] / D[k] * z[k]
+    z = z / D
+    for k in range(n - 1, -1, -1):          # L' x = D^-1 z
+        z[:k] -= F[k, :k] / D[:k] * z[k]
+    return z
+
+
+def structured_solve(R, Rm, diag, rhs, reg, sessions, on, nfree, free, T):
+    """(R P R' + diag + reg I) lam = rhs without forming the matrix (the kernel's phases 5-6).  With the rows ordered by
+    period, R R' + diag + reg I = B is BLOCK DIAGONAL (a row lives on one period's variables: blocks of at most two rows
+    per site row), and the session projector takes a low-rank term away:  R P R' = R R' - V V',  V[:, s] = R 1_s / sqrt(n_s)
+    (one column per tight session with free variables; its entry in row a is R_a at the session's EVSE when the row's
+    period lies in the window and that variable is free).  Woodbury:
+        lam = y + B^-1 V w,   y = B^-1 rhs,   (I - V' B^-1 V) w = V' y
+    -- per-period L D L' factors of <= 34 x 34 and one of the size of the tight sessions (<= 64), instead of a dense
+    factorisation of the size of all tight site rows (<= 256).  Returns None on a non-positive pivot."""
+    m = len(R)
+    t_of = np.array([t for (_, t, _, _, _) in R])
+    blocks = [np.flatnonzero(t_of == t) for t in range(T)]
+    Fs = {}
+    for t, idx in enumerate(blocks):
+        if len(idx) == 0:
+            continue
+        Rt = Rm[idx][:, :, t]                                  # (m_t, N)
+        F = ldl_factor(Rt @ Rt.T + np.diag(diag[idx] + reg))
+        if F is None:
+            return None
+        Fs[t] = F
+
+    def b_solve(v):                                            # B^-1 v, block by block
+        out = np.zeros(m)
+        for t, idx in enumerate(blocks):
+            if len(idx):
+                out[idx] = ldl_solve(Fs[t], v[idx])
+        return out
+
+    act = [s for s in range(len(sessions)) if on[s]]
+    V = np.zeros((m, len(act)))
+    for c, s in enumerate(act):
+        i, o, L = sessions[s][0], sessions[s][1], sessions[s][2]
+        for a in range(m):
+            t = t_of[a]
+            if o <= t < o + L and free[i, t]:
+                V[a, c] = Rm[a, i, t] / np.sqrt(nfree[s])
+    y = b_solve(rhs)
+    if not act:
+        return y
+    BV = np.column_stack([b_solve(V[:, c]) for c in range(len(act))])
+    C = np.eye(len(act)) - V.T @ BV
+    FC = ldl_factor(C)
+    if FC is None:
+        return None
+    w = ldl_solve(FC, V.T @ y)
+    return y + BV @ w
 
 
 def polish(lb, ub, q, pd, sessions, eq, G, M, cone_soc, limits, peak, x0, y0, verbose=False):
@@ -111,13 +190,14 @@ def polish(lb, ub, q, pd, sessions, eq, G, M, cone_soc, limits, peak, x0, y0, ve
         nu[r] = np.where(r_act[r], mag, 0.0)
     mu = np.zeros(len(sessions))
     info = dict(ok=False, rounds=0, rows=0, why="rounds")
+    stall, best_step = 0, np.inf
     for rnd in range(MAX_ROUNDS):
         free = ~(at_lb | at_ub)
-        # ---- rows of the Schur system, in (row, period) order: the normal row of a tight site row, then its tangent
+        # ---- rows of the Schur system, PERIOD-major: the normal row of a tight site row, then its tangent
         R = []       # (r, t, c0, c1, j) : R_a[i] = c0 G[j][i] + c1 G[j + M][i] on period t
         c_A, diag = [], []
-        for r, (kind, j) in enumerate(rows):
-            for t in range(T):
+        for t in range(T):
+            for r, (kind, j) in enumerate(rows):
                 if not r_act[r, t]:
                     continue
                 val, u = row_value(kind, j, x[:, t])
@@ -158,11 +238,13 @@ def polish(lb, ub, q, pd, sessions, eq, G, M, cone_soc, limits, peak, x0, y0, ve
             if on[s]:
                 e[i, o:o + L] += np.where(free[i, o:o + L], c_E[s] / nfree[s], 0.0)
         vfree = -project(g) + pd * e
-        Rf = Rm.reshape(m, -1)
-        PRt = np.stack([project(Rm[a]) for a in range(m)]).reshape(m, -1) if m else np.zeros((0, N * T))
-        S = Rf @ PRt.T + np.diag(np.array(diag)) if m else np.zeros((0, 0))
-        rhs = Rf @ vfree.reshape(-1) - pd * np.array(c_A) if m else np.zeros(0)
-        lam = cholesky_solve(S, rhs, REG_REL * pd)
+        rhs = Rm.reshape(m, -1) @ vfree.reshape(-1) - pd * np.array(c_A) if m else np.zeros(0)
+        # (a PROXIMAL form, (S + reg I) lam = rhs + reg lam_prev, would carry no bias and allow a larger reg -- but it keeps the
+        #  null-space component of the previous multipliers instead of the least-norm one, and on these degenerate vertices the
+        #  wandering multipliers then trip the sign test: every stalled fixture failed with it)
+        dmax = float(np.max(np.sum(Rm.reshape(m, -1) ** 2, axis=1))) if m else 0.0
+        reg = max(REG_REL * pd, REG_DIAG * dmax)
+        lam = structured_solve(R, Rm, np.array(diag), rhs, reg, sessions, on, nfree, free, T) if m else np.zeros(0)
         if lam is None:
             info["why"] = "pivot"
             return x, info
@@ -232,7 +314,17 @@ def polish(lb, ub, q, pd, sessions, eq, G, M, cone_soc, limits, peak, x0, y0, ve
             else:
                 r_act[p0, p1] = True
             changed = True
-        conv = block is None and step <= TOL_STEP * max(1.0, float(np.abs(x).max()))
+        # noise floor: on the degenerate instances the regularised solve leaves 1e-5 A of noise in dx now and then; full
+        # steps that have stopped shrinking (STALL_ROUNDS of them within 2x of the smallest so far on this working set) go to
+        # the multiplier test and the KKT check like a converged one -- the check decides, and a failure there ends the polish
+        # instead of burning the round limit
+        if block is None:
+            stall = stall + 1 if step >= 0.5 * best_step else 0
+            best_step = min(best_step, step)
+        else:
+            stall, best_step = 0, np.inf
+        floor_hit = block is None and stall >= STALL_ROUNDS and step <= 1e-3
+        conv = block is None and (step <= TOL_STEP * max(1.0, float(np.abs(x).max())) or floor_hit)
         if verbose:
             print(f"  round {rnd:2d} free {int(free.sum()):4d} rows {m:3d} step {step:.2e} alpha {alpha:.3f} block {block}")
         if not changed and conv:
@@ -295,6 +387,7 @@ def polish(lb, ub, q, pd, sessions, eq, G, M, cone_soc, limits, peak, x0, y0, ve
                             y[j, t] = nu[r, t]
                 info["y"] = y
                 return x, info
+            stall, best_step = 0, np.inf
             kd, p0, p1 = who
             if kd == "lb":
                 at_lb[p0, p1] = False

@@ -119,9 +119,10 @@ def test_c_abi_alone_reaches_the_certificates(T):
         assert res.iters.max() <= 800 + 96, res.iters      # ADMM iterations up to the hand-over + Newton rounds
         assert (res.pri_res <= 1e-6).all() and (res.dua_res <= 1e-6).all()
     else:
-        # horizon 24: one of the three has more tight site rows (198 with their tangent rows) than the polish's LDS holds
-        # (168 on this site); it takes the fallback -- the solve as it was before there was a polish
-        assert tried >= 2 and won >= tried - 1 and after["gave_up_rows"] - before["gave_up_rows"] == tried - won, (before, after)
+        # horizon 24: up to 198 tight rows with their tangents -- per-period blocks + the sessions' capacitance matrix
+        # (Woodbury), so the size of the system is not a limit
+        assert tried >= 2 and won == tried, (before, after)
+        assert res.iters.max() <= 800 + 96, res.iters
     # ---- the polish off: the retry passes of round 3 (the fallback) still reach every certificate
     retry = h.solve(batch, default_options(polish_iters=0))
     assert (retry.status == 1).all() and max(worst_of(retry)) <= RATE_TOL
