@@ -686,7 +686,8 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     // one row tile, one session slot: 77 KB each) the polish takes no more than one of those slots, so that it starts as
     // soon as ANY solver workgroup of a neighbouring stream's launch ends; elsewhere the whole CU
     const bool two_per_cu = tiled && p->t_max <= 16 && d->MR == 16 && p->k_sessions == 1;
-    pol_blk = acnqp::polish_blocks_that_fit(h->N, p->t_max, h->Mg, nrow_site, two_per_cu ? 76 * 1024 : 160 * 1024);
+    pol_blk = acnqp::polish_blocks_that_fit(h->N, p->t_max, h->Mg, nrow_site, acnqp::polish_max_sess(h->N, p->k_sessions),
+                                            two_per_cu ? 76 * 1024 : 160 * 1024);
     if (pol_blk < 2 * nrow_site * (2 * nrow_site + 1) / 2) pol_blk = -1;   // not even one full block
   }
   hipError_t e = hipSuccess;
@@ -713,7 +714,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     if (e == hipSuccess) {
       acnqp::PolishArgs pa;
       pa.B = p->batch; pa.N = h->N; pa.Tm = p->t_max; pa.K = p->k_sessions; pa.M = h->M; pa.Mg = h->Mg; pa.cone = h->cone;
-      pa.has_peak = h->has_peak; pa.max_rows = pol_max; pa.blk_doubles = pol_blk;
+      pa.has_peak = h->has_peak; pa.max_rows = pol_max; pa.blk_doubles = pol_blk; pa.max_sess = acnqp::polish_max_sess(h->N, p->k_sessions);
       pa.G = d->Gabi; pa.limits = d->limabi;
       pa.horizon = p->horizon; pa.lb = p->lb; pa.ub = p->ub; pa.q = p->q; pa.pdiag = p->pdiag;
       pa.s_off = p->s_off; pa.s_len = p->s_len; pa.s_cap = p->s_cap; pa.s_eq = p->s_eq; pa.peak = h->has_peak ? p->peak : nullptr;

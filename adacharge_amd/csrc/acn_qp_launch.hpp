@@ -101,7 +101,8 @@ int long_tiles(int t_max);
 hipError_t launch_long(const StreamArgs& sa, hipStream_t st, bool lds_resident);
 // polish kernel (acn_qp_polish.hpp): rows of the Schur system its LDS holds for a shape (0: does not fit); launch over
 // the list the solver kernel left
-int polish_blocks_that_fit(int N, int Tm, int Mg, int nrow, int lds_bytes);   // LDS doubles for the per-period blocks of the Schur system (<= the worst case)
+int polish_blocks_that_fit(int N, int Tm, int Mg, int nrow, int max_sess, int lds_bytes);   // LDS doubles for the per-period blocks (<= the worst case)
+int polish_max_sess(int N, int K);                                            // session columns the capacitance matrix holds
 int polish_max_rows(int nrow, int Tm);                                        // rows the row tables hold
 hipError_t launch_polish(const PolishArgs& pa, int max_grid, hipStream_t st);
 // general-shape kernel (acn_qp_general.hpp), `threads` in {256, 512, 1024}

@@ -5,13 +5,15 @@ namespace acnqp {
 
 int polish_max_rows(int nrow, int Tm) { return std::min(kPolMaxRows, ((2 * nrow * Tm + 7) / 8) * 8); }
 
-int polish_blocks_that_fit(int N, int Tm, int Mg, int nrow, int lds_bytes) {
-  return PolishLds::blocks_that_fit(N, Tm, Mg, nrow, polish_max_rows(nrow, Tm), std::min(lds_bytes, kLdsPerCu - 2048));
+int polish_max_sess(int N, int K) { return std::min(kPolMaxSess, ((N * K + 7) / 8) * 8); }
+
+int polish_blocks_that_fit(int N, int Tm, int Mg, int nrow, int max_sess, int lds_bytes) {
+  return PolishLds::blocks_that_fit(N, Tm, Mg, nrow, polish_max_rows(nrow, Tm), max_sess, std::min(lds_bytes, kLdsPerCu - 2048));
 }
 
 hipError_t launch_polish(const PolishArgs& pa, int max_grid, hipStream_t st) {
   const int nrow = pa.M + (pa.has_peak ? 1 : 0);
-  const PolishLds L(pa.N, pa.Tm, pa.Mg, nrow, pa.max_rows, pa.blk_doubles);
+  const PolishLds L(pa.N, pa.Tm, pa.Mg, nrow, pa.max_rows, pa.blk_doubles, pa.max_sess);
   const size_t lds = (size_t)L.total * sizeof(double);
   const bool small = pa.Tm <= 16;
   hipError_t e = small ? ensure_dynamic_lds(reinterpret_cast<const void*>(&polish_kernel<4>), lds)

@@ -40,6 +40,7 @@ struct PolishArgs {
   int B, N, Tm, K, M, Mg, cone, has_peak;
   int max_rows;      // rows of the Schur system the row tables hold (<= kPolMaxRows)
   int blk_doubles;   // LDS doubles for the per-period blocks of the system (phase 5)
+  int max_sess;      // columns of V (tight sessions with free variables) the capacitance matrix holds
   const double *G, *limits;        // acnqp_site.G [Mg][N] and limits [M] as the caller gave them (no equilibration)
   const int32_t* horizon;
   const double *lb, *ub, *q, *pdiag;
@@ -56,13 +57,13 @@ struct PolishArgs {
   double reg_rel;
 };
 
-constexpr int kPolMaxSess = 64;       // tight sessions with free variables (columns of V) at most: the capacitance matrix is 64 x 64
+constexpr int kPolMaxSess = 128;      // tight sessions with free variables (columns of V) at most (PolishArgs.max_sess <= this)
 
 // LDS carve-up in doubles (host: size; device: offsets)
 struct PolishLds {
   int xs, ds, gs, u, du, nu, invn, rc0, rc1, rca, rdg, lam, blk, cap, zb, zv, sisq, red, ints, total;
   int mt_max;   // rows of one period's block at most: two per site row
-  __host__ __device__ PolishLds(int N, int Tm, int Mg, int nrow, int max_rows, int blk_doubles) {
+  __host__ __device__ PolishLds(int N, int Tm, int Mg, int nrow, int max_rows, int blk_doubles, int max_sess) {
     int o = 0;
     mt_max = 2 * nrow;
     xs = o; o += N * Tm;
@@ -78,20 +79,20 @@ struct PolishLds {
     rdg = o; o += max_rows;
     lam = o; o += max_rows;
     blk = o; o += blk_doubles;                               // the per-period blocks of B, packed lower, one after the other
-    cap = o; o += kPolMaxSess * (kPolMaxSess + 1) / 2;       // C = I - V' B^-1 V, packed lower
-    zb = o; o += mt_max * kPolMaxSess;                       // L_t^-1 V_t of the block in work
-    zv = o; o += kPolMaxSess;                                // V' y, then w
-    sisq = o; o += kPolMaxSess;                              // 1 / sqrt(n_s) of the session columns
+    cap = o; o += max_sess * (max_sess + 1) / 2;             // C = I - V' B^-1 V, packed lower
+    zb = o; o += mt_max * max_sess;                          // L_t^-1 V_t of the block in work
+    zv = o; o += max_sess;                                   // V' y, then w
+    sisq = o; o += max_sess;                                 // 1 / sqrt(n_s) of the session columns
     red = o; o += 16;
-    ints = o;   // ints from here: rj, rr, rt [max_rows], tstart[Tm + 1], boff[Tm + 1], ract[nrow], misc[8], si / sks [kPolMaxSess]; then cs[N * Tm] bytes
-    const int nint = 3 * max_rows + 2 * (Tm + 1) + nrow + 8 + 2 * kPolMaxSess;
+    ints = o;   // ints from here: rj, rr, rt [max_rows], tstart[Tm + 1], boff[Tm + 1], ract[nrow], misc[8], si / sks [max_sess]; then cs[N * Tm] bytes
+    const int nint = 3 * max_rows + 2 * (Tm + 1) + nrow + 8 + 2 * max_sess;
     o += (nint + 1) / 2 + (N * Tm + 7) / 8;
     total = o;
   }
   // doubles for the blocks that fit `bytes` of LDS, at most what the worst case needs (every site row tight in every period)
-  __host__ static int blocks_that_fit(int N, int Tm, int Mg, int nrow, int max_rows, int bytes) {
+  __host__ static int blocks_that_fit(int N, int Tm, int Mg, int nrow, int max_rows, int max_sess, int bytes) {
     const int worst = Tm * (2 * nrow) * (2 * nrow + 1) / 2;
-    const long long fixed = (long long)PolishLds(N, Tm, Mg, nrow, max_rows, 0).total * 8;
+    const long long fixed = (long long)PolishLds(N, Tm, Mg, nrow, max_rows, 0, max_sess).total * 8;
     const long long room = ((long long)bytes - fixed) / 8;
     return (int)(room < 0 ? 0 : (room < worst ? room : worst));
   }
@@ -183,7 +184,8 @@ __global__ __launch_bounds__(kPolThreads, kPolTQ == 4 ? 2 : 1) void polish_kerne
   const int N = A.N, Tm = A.Tm, K = A.K, M = A.M, Mg = A.Mg;
   const bool soc = A.cone == 1;
   const int nrow = M + (A.has_peak ? 1 : 0);
-  const PolishLds L(N, Tm, Mg, nrow, A.max_rows, A.blk_doubles);
+  const PolishLds L(N, Tm, Mg, nrow, A.max_rows, A.blk_doubles, A.max_sess);
+  const int MS = A.max_sess;
   double *Xs = sm + L.xs, *Ds = sm + L.ds, *Gs = sm + L.gs, *U = sm + L.u, *DU = sm + L.du, *NU = sm + L.nu, *INVN = sm + L.invn;
   double *RC0 = sm + L.rc0, *RC1 = sm + L.rc1, *RCA = sm + L.rca, *RDG = sm + L.rdg, *LAM = sm + L.lam, *RED = sm + L.red;
   double *BLK = sm + L.blk, *CAP = sm + L.cap, *ZB = sm + L.zb, *ZV = sm + L.zv, *SISQ = sm + L.sisq;
@@ -195,8 +197,8 @@ __global__ __launch_bounds__(kPolThreads, kPolTQ == 4 ? 2 : 1) void polish_kerne
   unsigned* RACT = reinterpret_cast<unsigned*>(BOFF + Tm + 1);   // per site row: bit t = tight at period t
   int* MISC = reinterpret_cast<int*>(RACT + nrow);     // [0] m, [1] fail flag, [2] session columns, [3] bad pivot
   int* SI = MISC + 8;                                  // session columns of V: EVSE, slot
-  int* SKS = SI + kPolMaxSess;
-  signed char* CS = reinterpret_cast<signed char*>(SKS + kPolMaxSess);   // per (i, t): -2 not free, -1 free, k >= 0 free in tight session k
+  int* SKS = SI + MS;
+  signed char* CS = reinterpret_cast<signed char*>(SKS + MS);   // per (i, t): -2 not free, -1 free, k >= 0 free in tight session k
   __shared__ int q_slot;
 
   const int tid = threadIdx.x;
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(kPolThreads, kPolTQ == 4 ? 2 : 1) void polish_kerne
 #pragma unroll
           for (int ks = 0; ks < kMaxK; ++ks)
             if (son[ks]) {
-              if (pos < kPolMaxSess) { SI[pos] = i; SKS[pos] = ks; SISQ[pos] = 1.0 / sqrt(nfree[ks]); }
+              if (pos < MS) { SI[pos] = i; SKS[pos] = ks; SISQ[pos] = 1.0 / sqrt(nfree[ks]); }
               ++pos;
             }
         }
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(kPolThreads, kPolTQ == 4 ? 2 : 1) void polish_kerne
       }
       __syncthreads();
       const int m = MISC[0], nsa = MISC[2];
-      if (MISC[1] || nsa > kPolMaxSess) { why = 2; break; }
+      if (MISC[1] || nsa > MS) { why = 2; break; }
       if (tid == 0) {   // packed blocks of B, one per period, one after the other
         int o = 0;
         for (int t = 0; t < Tm; ++t) { BOFF[t] = o; const int mt = TSTART[t + 1] - TSTART[t]; o += mt * (mt + 1) / 2; }
@@ -528,14 +530,14 @@ __global__ __launch_bounds__(kPolThreads, kPolTQ == 4 ? 2 : 1) void polish_kerne
         for (int idx = tid; idx < mt * nsa; idx += kPolThreads) {
           const int k = idx / nsa, c = idx - k * nsa;
           const int ic = SI[c];
-          ZB[k * kPolMaxSess + c] = CS[ic * Tm + t] == SKS[c] ? row_at(a0 + k, ic) * SISQ[c] : 0.0;
+          ZB[k * MS + c] = CS[ic * Tm + t] == SKS[c] ? row_at(a0 + k, ic) * SISQ[c] : 0.0;
         }
         __syncthreads();
         for (int c = tid; c < nsa; c += kPolThreads) {
           if (CS[SI[c] * Tm + t] != SKS[c]) continue;
           for (int k = 0; k < mt; ++k) {
-            const double zk = ZB[k * kPolMaxSess + c] * RDG[a0 + k];
-            for (int r = k + 1; r < mt; ++r) ZB[r * kPolMaxSess + c] -= blk[r * (r + 1) / 2 + k] * zk;
+            const double zk = ZB[k * MS + c] * RDG[a0 + k];
+            for (int r = k + 1; r < mt; ++r) ZB[r * MS + c] -= blk[r * (r + 1) / 2 + k] * zk;
           }
         }
         __syncthreads();
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(kPolThreads, kPolTQ == 4 ? 2 : 1) void polish_kerne
           const int c2 = p - c * (c + 1) / 2;
           if (CS[SI[c] * Tm + t] != SKS[c] || CS[SI[c2] * Tm + t] != SKS[c2]) continue;
           double sacc = 0;
-          for (int k = 0; k < mt; ++k) sacc += ZB[k * kPolMaxSess + c] * RDG[a0 + k] * ZB[k * kPolMaxSess + c2];
+          for (int k = 0; k < mt; ++k) sacc += ZB[k * MS + c] * RDG[a0 + k] * ZB[k * MS + c2];
           CAP[p] -= sacc;
         }
         __syncthreads();

@@ -20,7 +20,7 @@ E: tight energy rows, A: linearised tight site rows (a disc row: its outward nor
 (tangent rows, D = |u| / nu), by block elimination: the energy rows have disjoint supports, so they reduce to the
 projector P = I - sum_s 1_s 1_s' / n_s (n_s: free variables of the session's window), and what is left is the SPD system
     (R P R' + pd diag(0, D)) lam = R (-P g + pd e) - pd (c_A, 0),     R = [A; W],  e = E' (c_E / n)
-of the size of the tight site rows: a dense Cholesky.  Then a ratio test against everything NOT in the
+of the size of the tight site rows -- solved without forming it (structured_solve: per-period blocks + Woodbury).  Then a ratio test against everything NOT in the
 working set (step length alpha <= 1 to the first blocking constraint, which joins W), and -- once a full step has
 converged -- the most negative multiplier leaves W.  KKT on the full problem is verified before the answer is accepted.
 """

@@ -12,12 +12,14 @@ from tests.test_gpu_parity import _random_sessions_general
 
 B0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 0     # second argument: seed offset (other instances of the same classes)
+POLISH = int(sys.argv[3]) if len(sys.argv) > 3 else 800  # third: polish_iters (a low value soaks the polish: more hand-overs)
+LAST = int(sys.argv[4]) if len(sys.argv) > 4 else 20     # fourth: cases 0 .. LAST - 1
 bad_total = 0
 # cases 8-13: the long-horizon kernel (horizons 40 ... 200, two session slots, peaks, equality rows) and its
 # LDS-resident variant (jpl52 at horizons 24 / 30); cases 14-19: the large-site kernel (128 / 192 / 512 EVSE, horizons
 # 12 ... 48, one / two / three column tiles, two session slots, equality rows, peaks)
 WIDE = {14: ("wide128", 12), 15: ("wide128", 30), 16: ("wide192", 48), 17: ("synth512", 24), 18: ("synth512", 48), 19: ("wide192", 16)}
-for case in range(20):
+for case in range(LAST):
     rng = np.random.default_rng(5000 + case + 100 * SEED)
     B = B0
     T = [12, 16, 24, 30, 12, 20, 9, 32, 40, 72, 144, 200, 24, 30, 12, 30, 48, 24, 48, 16][case]
@@ -41,7 +43,14 @@ for case in range(20):
     peaks = [p if (p is None or np.isscalar(p)) else p[:t] for p, t in zip(peaks, Ts)]
     batch = build_batch(snaps, infra, iface, obj, ct, eq, peak_limits=peaks)
     h = SiteHandle(batch.site, 0)
-    r = h.solve(batch, default_options(max_iter=30000))
+    r = h.solve(batch, default_options(max_iter=30000, polish_iters=POLISH))
+    ps = h.polish_stats()
+    pdiff = -1.0
+    if ps["attempted"]:   # the polish took problems: the same batch without it must give the same schedules (to tolerance)
+        r0 = h.solve(batch, default_options(max_iter=30000, polish_iters=0))
+        both = np.isin(r.status, (1,)) & np.isin(r0.status, (1,))
+        pdiff = float(np.abs(r.x[both] - r0.x[both]).max()) if both.any() else 0.0
+        bad_total += int(pdiff > 1e-4 * 32) + int((r.status != r0.status).sum() > 0 and not np.isin(r0.status[r.status != r0.status], (2, 5)).all())
     ok = np.isin(r.status, (1, 5))
     finite = np.isfinite(r.x).all()
     x = r.x[ok]
@@ -55,7 +64,9 @@ for case in range(20):
     pk = float((x.sum(axis=1) - batch.peak[ok]).max()) if with_peak and len(x) else 0.0
     counts = np.bincount(r.status, minlength=6)[1:]
     print(f"case {case} {ct} T={T} eq={eq} K={batch.K} peak={with_peak}: status counts(1..5) {counts.tolist()} finite {finite} box {box} "
-          f"max row violation {viol:.2e} max peak violation {pk:.2e} iters mean {r.iters.mean():.0f} max {r.iters.max()} kernel {r.kernel_ms:.1f} ms", flush=True)
+          f"max row violation {viol:.2e} max peak violation {pk:.2e} iters mean {r.iters.mean():.0f} max {r.iters.max()} kernel {r.kernel_ms:.1f} ms "
+          f"polish {ps['attempted']}/{ps['solved']} gave up {ps['gave_up_rows']}/{ps['gave_up_pivot']}/{ps['gave_up_rounds']}/{ps['gave_up_kkt']} "
+          f"max |x - x(no polish)| {pdiff:.2e}", flush=True)
     bad_total += int(not finite) + int(not box) + int(viol > 5e-3) + int(pk > 5e-3)
     h.close()
 print("anomalies:", bad_total)
