@@ -457,9 +457,13 @@ __global__ __launch_bounds__(kPolThreads, kPolTQ == 4 ? 2 : 1) void polish_kerne
       double dloc = 0;
       for (int a = tid; a < m; a += kPolThreads) {
         const int ta = RT[a];
+        const double* g0 = Gs + RJ[a] * N;          // (the row's constants once, not once per EVSE: this loop and the block
+        const double* g1 = g0 + M * N;              //  build below were 20 us of a 79 us round as chains of LDS reads)
+        const double c0 = RC0[a], c1 = RC1[a];
+        const bool two = c1 != 0.0;
         double sacc = 0, d2 = 0;
         for (int e = 0; e < N; ++e) {
-          const double ra = row_at(a, e);
+          const double ra = c0 * g0[e] + (two ? c1 * g1[e] : 0.0);
           sacc += ra * Ds[e * Tm + ta];
           d2 += CS[e * Tm + ta] != -2 ? ra * ra : 0.0;
         }
@@ -477,9 +481,15 @@ __global__ __launch_bounds__(kPolThreads, kPolTQ == 4 ? 2 : 1) void polish_kerne
           while (ar * (ar + 1) / 2 > q_) --ar;
           const int cr = q_ - ar * (ar + 1) / 2;
           const int a = TSTART[t] + ar, c = TSTART[t] + cr;
+          const double *ga0 = Gs + RJ[a] * N, *ga1 = ga0 + M * N, *gc0 = Gs + RJ[c] * N, *gc1 = gc0 + M * N;
+          const double a0c = RC0[a], a1c = RC1[a], c0c = RC0[c], c1c = RC1[c];
+          const bool atwo = a1c != 0.0, ctwo = c1c != 0.0;
           double sacc = 0;
-          for (int e = 0; e < N; ++e)
-            if (CS[e * Tm + t] != -2) sacc += row_at(a, e) * row_at(c, e);
+          for (int e = 0; e < N; ++e) {
+            const double ra = a0c * ga0[e] + (atwo ? a1c * ga1[e] : 0.0);
+            const double rc = c0c * gc0[e] + (ctwo ? c1c * gc1[e] : 0.0);
+            sacc += CS[e * Tm + t] != -2 ? ra * rc : 0.0;
+          }
           BLK[p] = sacc + (a == c ? RDG[a] + reg : 0.0);
         }
       }
