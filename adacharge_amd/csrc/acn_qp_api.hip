@@ -689,6 +689,12 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     pol_blk = acnqp::polish_blocks_that_fit(h->N, p->t_max, h->Mg, nrow_site, acnqp::polish_max_sess(h->N, p->k_sessions),
                                             two_per_cu ? 76 * 1024 : 160 * 1024);
     if (pol_blk < 2 * nrow_site * (2 * nrow_site + 1) / 2) pol_blk = -1;   // not even one full block
+    // The polish is a remedy for a launch's TAIL, and its phase runs behind the solver launch.  A launch of many problems
+    // per resident slot of a one-workgroup-per-CU shape is throughput-bound -- its stragglers overlap the bulk of the work
+    // -- so the polish phase (horizon-24 rounds: 0.1 ms each, up to 30 of them) only adds to it: jpl52 x 24 x 4,096
+    // 61.0 -> 67.8 ms with it.  Such launches keep the ADMM alone (ACNQP_POLISH_ALWAYS=1: diagnostic).
+    static const bool polish_always = std::getenv("ACNQP_POLISH_ALWAYS") != nullptr;
+    if (!two_per_cu && p->batch > 8 * h->cus && !polish_always) pol_blk = -1;
   }
   hipError_t e = hipSuccess;
   if (pol_blk >= 0) {

@@ -24,7 +24,10 @@ def headline():
 PS = [int(a[2:]) for a in sys.argv[1:] if a.startswith("P=")] or [800, 0, 1200]
 legs = [a for a in legs if not a.startswith("P=")] or ["cfg3_site3_T12_b1024"]
 for leg in legs:
-    batch = headline() if leg == "headline" else bench.other_workloads()[leg]()[0]
+    name, _, first = leg.partition("@")          # "<leg>@<n>": the first n problems of the leg
+    batch = headline() if name == "headline" else bench.other_workloads()[name]()[0]
+    if first:
+        batch = batch.subset(slice(0, int(first)))
     out = {"leg": leg, "batch": batch.B}
     ref = None
     for name, o in [(f"P={P}", default_options(polish_iters=P)) for P in PS]:
