@@ -21,7 +21,7 @@ INC = os.path.join(ROOT, "include")
 LIBDIR = os.path.join(ROOT, "adacharge_amd", "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libacn_qp_hip.so")
-UNITS = ("acn_qp_api", "acn_qp_tiled_ct1", "acn_qp_tiled_ct2", "acn_qp_stream", "acn_qp_long", "acn_qp_general", "acn_qp_polish")
+UNITS = ("acn_qp_api", "acn_qp_wave", "acn_qp_tiled_ct1", "acn_qp_tiled_ct2", "acn_qp_stream", "acn_qp_long", "acn_qp_general", "acn_qp_polish")
 SOURCES = [os.path.join(CSRC, u + ".hip") for u in UNITS]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-honor-nans", "-mno-amdgpu-ieee", "-fPIC"]
 

@@ -664,6 +664,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     ga.t = a;
   }
   auto launch_solver = [&](const acnqp::TiledArgs& aa) -> hipError_t {
+    if (tiled && acnqp::wave_shape(h->N, p->t_max, p->k_sessions, d->MR, h->has_flat || h->has_max)) return acnqp::launch_wave(aa, st);
     if (tiled) return p->t_max <= 16 ? acnqp::launch_tiled_ct1(aa, st) : acnqp::launch_tiled_ct2(aa, st);
     if (stream) { sa.t = aa; return acnqp::launch_stream(sa, st); }
     if (lng) { sa.t = aa; return acnqp::launch_long(sa, st, lds_long_shape(h, p->t_max)); }

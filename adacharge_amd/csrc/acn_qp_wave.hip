@@ -1,0 +1,43 @@
+// Wave-per-problem kernel (acn_qp_wave.hpp): instantiation and launcher.
+#include "acn_qp_launch.hpp"
+#include "acn_qp_wave.hpp"
+
+namespace acnqp {
+
+// shapes the wave-per-problem kernel takes: a lane per EVSE, twelve period registers, one session slot, one row tile,
+// box / disc / peak rows
+bool wave_shape(int N, int t_max, int k_sessions, int MR, bool has_prox) {
+  static const bool off = std::getenv("ACNQP_NO_WAVE") != nullptr;   // diagnostic / A-B: the register-resident tiled kernel instead
+  return !off && N <= 64 && t_max <= kWaveTS && k_sessions == 1 && MR == 16 && !has_prox;
+}
+
+hipError_t launch_wave(const TiledArgs& a_in, hipStream_t st) {
+  TiledArgs a = a_in;
+  a.accel_mem = std::min(a.accel_mem, kWaveAM);
+  const WaveLds L(a.accel_mem);
+  const size_t lds = (size_t)L.total * 8;
+  auto kern = &admm_wave_kernel<kWaveAM>;
+  if (lds > 64 * 1024) {
+    hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
+    if (e != hipSuccess) return e;
+  }
+  // one queue position per WAVE: a workgroup serves kWaveNW positions at a time
+  const int groups = (a.B + kWaveNW - 1) / kWaveNW;
+  int grid = groups;
+  if (a.queue) {
+    const int per_cu = resident_per_cu(reinterpret_cast<const void*>(kern), kWaveNW * 64, lds), cus = device_cus();
+    const int cap = a.grid_cap > 0 ? a.grid_cap : groups;   // (a cap on WORKGROUPS: the resume launches of pipelined chunks keep theirs small)
+    grid = std::max(1, std::min(std::min(groups, cap), per_cu * cus * std::max(1, a.grid_oversub)));
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaveNW * 64), lds, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace acnqp
+
+#ifdef ACNQP_STAMPS
+/* diagnostic build only: the per-phase cycle counters of the wave-per-problem kernel (this unit's own g_stamps) */
+extern "C" int acnqp_debug_read_wave_stamps(unsigned long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(acnqp::g_stamps), sizeof(unsigned long long) * n);
+}
+#endif
