@@ -1,6 +1,9 @@
 // Host side of the C ABI declared in include/acn_qp.h.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -87,6 +90,26 @@ struct DevBuf {
   }
 };
 
+// pinned host staging, grow-only
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 }  // namespace
 
 // Site data in the kernel's internal row order, one copy per arithmetic type (the MFMA C-operand
@@ -128,6 +151,11 @@ struct acnqp_handle {
   // H2D copies, the kernel and the D2H copies of successive chunks of a call overlap
   static constexpr int kSlots = 4;
   struct Slot { hipStream_t st = nullptr; DevBuf in, out, tin; } slot[kSlots];   // tin: session-table staging (acnqp_solve_table)
+  // pinned mirrors of a call's SMALL per-problem arrays (scalars, session slots; status ... obj): one H2D and one D2H per
+  // chunk instead of nine and five per batch of the call -- a stream operation costs tens of microseconds whatever its size,
+  // and a step of 64 batches was 960 of them (run_pipeline)
+  HostBuf small_in, small_out;
+  hipEvent_t h2d_done[kSlots] = {nullptr, nullptr, nullptr, nullptr};   // chunk c's inputs have landed (run_pipeline: the next chunk's copies queue behind them)
   // per launch stream: the kernel workspace (long-horizon, large-site, general-shape kernels) and the launch's small
   // scheduling buffer (queue counter, then sort keys and queue order).  Launches on different streams never share (or
   // regrow) each other's state, and a stream's own launches are ordered by the stream.
@@ -472,8 +500,10 @@ int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) 
     e = hipEventCreate(&h->ev_start[k]);
     if (e == hipSuccess) e = hipEventCreate(&h->ev_stop[k]);
   }
-  for (int k = 0; k < acnqp_handle::kSlots && e == hipSuccess; ++k)
+  for (int k = 0; k < acnqp_handle::kSlots && e == hipSuccess; ++k) {
     e = hipStreamCreateWithFlags(&h->slot[k].st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->h2d_done[k], hipEventDisableTiming);
+  }
   if (e != hipSuccess) {
     std::string msg = std::string("acnqp_create: ") + hipGetErrorString(e);
     acnqp_destroy(h);
@@ -503,6 +533,9 @@ void acnqp_destroy(acnqp_handle* h) {
     sl.out.release();
     sl.tin.release();
   }
+  h->small_in.release();
+  h->small_out.release();
+  for (auto& ev : h->h2d_done) if (ev) (void)hipEventDestroy(ev);
   h->release_work();
   if (h->pol_stats) (void)hipFree(h->pol_stats);
   delete h;
@@ -872,11 +905,14 @@ struct ChunkLayout {
 
 // per_problem_bytes: inputs + results staged per problem -- every one of the kSlots pipeline slots holds a chunk of
 // each, so a chunk is capped at 1 GiB of the sum
-long long chunk_problems(size_t per_problem_bytes, bool on_chip) {
+long long chunk_problems(size_t per_problem_bytes, bool on_chip, bool wave = false) {
   // problems per launch: large enough that the launch tail (its slowest problems) is short.  The register-resident
   // kernel takes 1,024 (two per workgroup slot): with the launches sorted longest-first (order_sort_kernel) and four
   // streams in flight the shorter pipeline head and tail outweigh the per-launch tails (bench: 441 -> 455 k QP/s)
   long long want = on_chip ? 1024 : 2048;
+  // the wave-per-problem kernel's launches are persistent (four problems in flight per CU, one wave each): a launch ends
+  // with its slowest problem whatever its size, so few large chunks (sweep: 3,072 / 4,096 / 6,144 -> 21.7 / 20.5 / 20.0 ms)
+  if (wave) want = 6144;
   if (const char* e = std::getenv("ACNQP_CHUNK")) { const long long v = std::atoll(e); if (v > 0) want = v; }
   const long long by_mem = (long long)((size_t)1024 * 1024 * 1024 / std::max<size_t>(per_problem_bytes, 1));
   long long n = std::max<long long>(1, std::min(want, by_mem));
@@ -884,7 +920,10 @@ long long chunk_problems(size_t per_problem_bytes, bool on_chip) {
   return n;
 }
 
-int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_options* o, acnqp_results* R) {
+// what the caller's small result arrays still need after the streams have drained: a copy out of the pinned mirror
+struct Scatter { int g; size_t lo, n, pos; const char* host; size_t st, it, pr, du, ob; };
+
+int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_options* o, acnqp_results* R, std::vector<Scatter>* scatter) {
   const size_t N = h->N;
   const bool peak = h->has_peak, flat = h->has_flat, mx = h->has_max;
   // chunks: consecutive batches of one shape (t_max, k_sessions) share launches of up to chunk_problems() problems
@@ -901,7 +940,8 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
         chunks.emplace_back();
         cur_T = (int)Tm; cur_K = (int)K; cur_opt = opt; fill = 0;
         // (the kernels' workspaces belong to the resident workgroup slots since the work queue: no per-problem term)
-        cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K));
+        cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K),
+                             tiled_shape(h, (int)Tm, (int)K) && acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max));
         // ramp: the first kernel cannot start before its chunk's H2D has landed, and nothing overlaps that copy -- a
         // quarter-size first chunk (then a half-size one) shortens the exposed head of the pipeline
         static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
@@ -915,6 +955,25 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
       fill += n; lo += n;
     }
   }
+  // pinned mirrors of the chunks' small arrays (device ranges [pd, wx) and [st, y) of ChunkLayout), whole call; beyond
+  // kSmallCap the per-batch copies of old (a call that large is not bound by their latency)
+  const size_t Mg0 = (size_t)h->Mg;
+  constexpr size_t kSmallCap = (size_t)1 << 30;
+  std::vector<size_t> in_off(chunks.size()), out_off(chunks.size());
+  size_t in_sum = 0, out_sum = 0;
+  for (size_t c = 0; c < chunks.size(); ++c) {
+    const std::vector<Piece>& pcs = chunks[c];
+    const size_t cn = (size_t)(pcs.back().pos + pcs.back().n);
+    const ChunkLayout L(cn, N, P[pcs[0].g].t_max, P[pcs[0].g].k_sessions, Mg0, peak, flat, mx, P[pcs[0].g].warm_x != nullptr, R[pcs[0].g].y != nullptr);
+    in_off[c] = in_sum; in_sum += L.wx - L.pd;
+    out_off[c] = out_sum; out_sum += L.y - L.st;
+  }
+  static const bool no_stage = std::getenv("ACNQP_NO_STAGING") != nullptr;   // diagnostic: the per-batch copies
+  const bool staged = !no_stage && scatter != nullptr && in_sum + out_sum <= kSmallCap;
+  if (staged) {
+    HIP_TRY(h->small_in.reserve(in_sum));
+    HIP_TRY(h->small_out.reserve(out_sum));
+  }
   for (size_t c = 0; c < chunks.size(); ++c) {
     acnqp_handle::Slot& S = h->slot[c % acnqp_handle::kSlots];
     const std::vector<Piece>& pcs = chunks[c];
@@ -923,11 +982,16 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
     const bool warm = P[pcs[0].g].warm_x != nullptr, want_y = R[pcs[0].g].y != nullptr;
     const size_t Mg = (size_t)h->Mg;
     const ChunkLayout L(cn, N, Tm, K, Mg, peak, flat, mx, warm, want_y);
+    char* hs = staged ? static_cast<char*>(h->small_in.p) + in_off[c] - L.pd : nullptr;   // hs + L.field = the mirror of di + L.field
     if (L.in_total > S.in.cap || L.out_total > S.out.cap) HIP_TRY(hipStreamSynchronize(S.st));   // staging still in use
     HIP_TRY(S.in.reserve(L.in_total));
     HIP_TRY(S.out.reserve(L.out_total));
     char* di = static_cast<char*>(S.in.p);
     char* dq = static_cast<char*>(S.out.p);
+    // the chunks' input copies one chunk after the other (they share the link anyway): the first kernel's inputs do not
+    // wait for a share of the bandwidth the second chunk's copies would take
+    static const bool chain = std::getenv("ACNQP_NO_H2D_CHAIN") == nullptr;
+    if (chain && c > 0) HIP_TRY(hipStreamWaitEvent(S.st, h->h2d_done[(c - 1) % acnqp_handle::kSlots], 0));
     for (const Piece& pc : pcs) {
       const acnqp_problems& p = P[pc.g];
       const size_t lo = (size_t)pc.lo, n = (size_t)pc.n, pos = (size_t)pc.pos;
@@ -935,21 +999,30 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
 #define H2D(field, base, elem, per)                                                                             \
   HIP_TRY(hipMemcpyAsync(di + (base) + pos * (per) * (elem), reinterpret_cast<const char*>(p.field) + lo * (per) * (elem), \
                          n * (per) * (elem), hipMemcpyHostToDevice, S.st))
+// small arrays: into the pinned mirror (one H2D per chunk below); without staging, a copy each
+#define H2S(field, base, elem, per)                                                                             \
+  do {                                                                                                          \
+    if (staged) std::memcpy(hs + (base) + pos * (per) * (elem), reinterpret_cast<const char*>(p.field) + lo * (per) * (elem), n * (per) * (elem)); \
+    else H2D(field, base, elem, per);                                                                           \
+  } while (0)
       H2D(lb, L.lb, 8, nv);
       H2D(ub, L.ub, 8, nv);
       H2D(q, L.q, 8, nv);
-      H2D(pdiag, L.pd, 8, 1);
-      H2D(horizon, L.hz, 4, 1);
-      H2D(s_off, L.so, 4, ns);
-      H2D(s_len, L.sl, 4, ns);
-      H2D(s_cap, L.sc, 8, ns);
-      H2D(s_eq, L.eq, 1, 1);
-      if (peak) H2D(peak, L.pk, 8, Tm);
-      if (flat) H2D(lf, L.lf, 8, 1);
-      if (mx) { H2D(dc, L.dc, 8, 1); H2D(dfloor, L.df, 8, 1); }
+      H2S(pdiag, L.pd, 8, 1);
+      H2S(horizon, L.hz, 4, 1);
+      H2S(s_off, L.so, 4, ns);
+      H2S(s_len, L.sl, 4, ns);
+      H2S(s_cap, L.sc, 8, ns);
+      H2S(s_eq, L.eq, 1, 1);
+      if (peak) H2S(peak, L.pk, 8, Tm);
+      if (flat) H2S(lf, L.lf, 8, 1);
+      if (mx) { H2S(dc, L.dc, 8, 1); H2S(dfloor, L.df, 8, 1); }
       if (warm) { H2D(warm_x, L.wx, 8, nv); H2D(warm_y, L.wy, 8, Mg * Tm); }
+#undef H2S
 #undef H2D
     }
+    if (staged) HIP_TRY(hipMemcpyAsync(di + L.pd, hs + L.pd, L.wx - L.pd, hipMemcpyHostToDevice, S.st));
+    if (chain) HIP_TRY(hipEventRecord(h->h2d_done[c % acnqp_handle::kSlots], S.st));
     acnqp_problems dp;
     dp.batch = (int32_t)cn; dp.t_max = (int32_t)Tm; dp.k_sessions = (int32_t)K;
     dp.lb = reinterpret_cast<const double*>(di + L.lb);
@@ -978,6 +1051,8 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
     dr.y = want_y ? reinterpret_cast<double*>(dq + L.y) : nullptr;
     const int rc = acnqp_solve_batch_device(h, &dp, o, &dr, S.st);
     if (rc != ACNQP_OK) return rc;
+    char* ho = staged ? static_cast<char*>(h->small_out.p) + out_off[c] - L.st : nullptr;   // ho + L.field = the mirror of dq + L.field
+    if (staged) HIP_TRY(hipMemcpyAsync(ho + L.st, dq + L.st, L.y - L.st, hipMemcpyDeviceToHost, S.st));
     for (const Piece& pc : pcs) {
       const acnqp_results& r = R[pc.g];
       const size_t lo = (size_t)pc.lo, n = (size_t)pc.n, pos = (size_t)pc.pos;
@@ -985,11 +1060,15 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
   HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(r.field) + lo * (per) * (elem), dq + (base) + pos * (per) * (elem), \
                          n * (per) * (elem), hipMemcpyDeviceToHost, S.st))
       D2H(x, L.x, 8, N * Tm);
-      D2H(status, L.st, 4, 1);
-      D2H(iters, L.it, 4, 1);
-      D2H(pri_res, L.pr, 8, 1);
-      D2H(dua_res, L.du, 8, 1);
-      D2H(obj, L.ob, 8, 1);
+      if (staged) {
+        scatter->push_back(Scatter{pc.g, lo, n, pos, ho, L.st, L.it, L.pr, L.du, L.ob});
+      } else {
+        D2H(status, L.st, 4, 1);
+        D2H(iters, L.it, 4, 1);
+        D2H(pri_res, L.pr, 8, 1);
+        D2H(dua_res, L.du, 8, 1);
+        D2H(obj, L.ob, 8, 1);
+      }
       if (want_y) D2H(y, L.y, 8, Mg * Tm);
 #undef D2H
       if (r.x_dev)
@@ -1085,7 +1164,8 @@ int run_table_pipeline(acnqp_handle* h, const acnqp_table* T, const acnqp_option
   const bool peak = h->has_peak, flat = h->has_flat, mx = h->has_max, want_y = R->y != nullptr;
   const long long B = T->batch;
   const size_t nv = N * Tm, nsl = K * N;
-  long long cap0 = chunk_problems(4 * nv * 8 + nsl * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K));
+  long long cap0 = chunk_problems(4 * nv * 8 + nsl * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K),
+                                  tiled_shape(h, (int)Tm, (int)K) && acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max));
   static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
   long long lo = 0;
   for (size_t c = 0; lo < B; ++c) {
@@ -1212,12 +1292,29 @@ int acnqp_solve_batches(acnqp_handle* h, int32_t n_batches, const acnqp_problems
     if (rc != ACNQP_OK) return rc;
   }
   HIP_TRY(hipSetDevice(h->device));
-  const int rc = run_pipeline(h, n_batches, p, o, r);
+  static const bool trace = std::getenv("ACNQP_TRACE") != nullptr;   // diagnostic: host enqueue time vs the whole call, on stderr
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<Scatter> scatter;
+  const int rc = run_pipeline(h, n_batches, p, o, r, &scatter);
+  const auto t1 = std::chrono::steady_clock::now();
   // drain every slot before returning, also on failure: nothing may touch the caller's buffers afterwards
   hipError_t e = hipSuccess;
   for (auto& sl : h->slot) { const hipError_t e1 = hipStreamSynchronize(sl.st); if (e == hipSuccess) e = e1; }
+  if (trace) {
+    const auto t2 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[acnqp] solve_batches: enqueue %.3f ms, drained after %.3f ms\n",
+                 std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t0).count());
+  }
   if (rc != ACNQP_OK) return rc;
   if (e != hipSuccess) return fail(ACNQP_ERR_HIP, std::string("acnqp_solve_batches: ") + hipGetErrorString(e));
+  for (const Scatter& sc : scatter) {   // the small result arrays: pinned mirror -> the caller's arrays
+    const acnqp_results& rr = r[sc.g];
+    std::memcpy(rr.status + sc.lo, sc.host + sc.st + sc.pos * 4, sc.n * 4);
+    std::memcpy(rr.iters + sc.lo, sc.host + sc.it + sc.pos * 4, sc.n * 4);
+    std::memcpy(rr.pri_res + sc.lo, sc.host + sc.pr + sc.pos * 8, sc.n * 8);
+    std::memcpy(rr.dua_res + sc.lo, sc.host + sc.du + sc.pos * 8, sc.n * 8);
+    std::memcpy(rr.obj + sc.lo, sc.host + sc.ob + sc.pos * 8, sc.n * 8);
+  }
   for (int g = 0; g < n_batches; ++g)
     for (int b = 0; b < p[g].batch; ++b)
       if (r[g].status[b] == ACNQP_STATUS_UNSET)

@@ -27,7 +27,15 @@ hipError_t launch_wave(const TiledArgs& a_in, hipStream_t st) {
   if (a.queue) {
     const int per_cu = resident_per_cu(reinterpret_cast<const void*>(kern), kWaveNW * 64, lds), cus = device_cus();
     const int cap = a.grid_cap > 0 ? a.grid_cap : groups;   // (a cap on WORKGROUPS: the resume launches of pipelined chunks keep theirs small)
-    grid = std::max(1, std::min(std::min(groups, cap), per_cu * cus * std::max(1, a.grid_oversub)));
+    // A wave takes its problems one after the other, so a workgroup is as slow as the slowest of its four waves' shares:
+    // only PERSISTENT workgroups level that (a workgroup per four problems wastes max-of-four against mean-of-four, 40 %).
+    // The pipelined host entries (grid_oversub > 1 for the other kernels) therefore keep this kernel's grid at the resident
+    // slots too; the next stream's launch moves in as this one's workgroups retire (measured, 16,384 problems per step:
+    // half the chip per launch 21.4-21.8 ms, the whole chip 20.0-20.5 ms; tools/sweep_wave_pipeline.sh).
+    int resident = per_cu * cus;
+    static const int grid_env = std::getenv("ACNQP_WAVE_GRID") ? std::atoi(std::getenv("ACNQP_WAVE_GRID")) : 0;   // diagnostic: workgroups per pipelined launch
+    if (a.grid_oversub > 1 && grid_env > 0) resident = grid_env;
+    grid = std::max(1, std::min(std::min(groups, cap), resident));
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaveNW * 64), lds, st, a);
   return hipGetLastError();
