@@ -155,6 +155,9 @@ struct acnqp_handle {
   // chunk instead of nine and five per batch of the call -- a stream operation costs tens of microseconds whatever its size,
   // and a step of 64 batches was 960 of them (run_pipeline)
   HostBuf small_in, small_out;
+  // problems of the host-entry call a launch belongs to (0: a launch of its own): the kernel family is chosen for the
+  // CALL, so that a call's last, short chunk does not run on a different kernel than its first ones (wave_shape)
+  int route_hint = 0;
   hipEvent_t h2d_done[kSlots] = {nullptr, nullptr, nullptr, nullptr};   // chunk c's inputs have landed (run_pipeline: the next chunk's copies queue behind them)
   // per launch stream: the kernel workspace (long-horizon, large-site, general-shape kernels) and the launch's small
   // scheduling buffer (queue counter, then sort keys and queue order).  Launches on different streams never share (or
@@ -697,7 +700,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     ga.t = a;
   }
   auto launch_solver = [&](const acnqp::TiledArgs& aa) -> hipError_t {
-    if (tiled && acnqp::wave_shape(h->N, p->t_max, p->k_sessions, d->MR, h->has_flat || h->has_max)) return acnqp::launch_wave(aa, st);
+    if (tiled && acnqp::wave_shape(h->N, p->t_max, p->k_sessions, d->MR, h->has_flat || h->has_max, std::max(p->batch, h->route_hint))) return acnqp::launch_wave(aa, st);
     if (tiled) return p->t_max <= 16 ? acnqp::launch_tiled_ct1(aa, st) : acnqp::launch_tiled_ct2(aa, st);
     if (stream) { sa.t = aa; return acnqp::launch_stream(sa, st); }
     if (lng) { sa.t = aa; return acnqp::launch_long(sa, st, lds_long_shape(h, p->t_max)); }
@@ -926,6 +929,8 @@ struct Scatter { int g; size_t lo, n, pos; const char* host; size_t st, it, pr, 
 int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_options* o, acnqp_results* R, std::vector<Scatter>* scatter) {
   const size_t N = h->N;
   const bool peak = h->has_peak, flat = h->has_flat, mx = h->has_max;
+  long long call_total = 0;
+  for (int g = 0; g < nb; ++g) call_total += P[g].batch;
   // chunks: consecutive batches of one shape (t_max, k_sessions) share launches of up to chunk_problems() problems
   std::vector<std::vector<Piece>> chunks;
   long long fill = 0, cap = 0;
@@ -941,7 +946,7 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
         cur_T = (int)Tm; cur_K = (int)K; cur_opt = opt; fill = 0;
         // (the kernels' workspaces belong to the resident workgroup slots since the work queue: no per-problem term)
         cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K),
-                             tiled_shape(h, (int)Tm, (int)K) && acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max));
+                             tiled_shape(h, (int)Tm, (int)K) && acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(call_total, 1 << 30)));
         // ramp: the first kernel cannot start before its chunk's H2D has landed, and nothing overlaps that copy -- a
         // quarter-size first chunk (then a half-size one) shortens the exposed head of the pipeline
         static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
@@ -1049,7 +1054,9 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
     dr.obj = reinterpret_cast<double*>(dq + L.ob);
     dr.x_dev = nullptr;
     dr.y = want_y ? reinterpret_cast<double*>(dq + L.y) : nullptr;
+    h->route_hint = (int)std::min<long long>(call_total, 1 << 30);
     const int rc = acnqp_solve_batch_device(h, &dp, o, &dr, S.st);
+    h->route_hint = 0;
     if (rc != ACNQP_OK) return rc;
     char* ho = staged ? static_cast<char*>(h->small_out.p) + out_off[c] - L.st : nullptr;   // ho + L.field = the mirror of dq + L.field
     if (staged) HIP_TRY(hipMemcpyAsync(ho + L.st, dq + L.st, L.y - L.st, hipMemcpyDeviceToHost, S.st));
@@ -1165,7 +1172,7 @@ int run_table_pipeline(acnqp_handle* h, const acnqp_table* T, const acnqp_option
   const long long B = T->batch;
   const size_t nv = N * Tm, nsl = K * N;
   long long cap0 = chunk_problems(4 * nv * 8 + nsl * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K),
-                                  tiled_shape(h, (int)Tm, (int)K) && acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max));
+                                  tiled_shape(h, (int)Tm, (int)K) && acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(B, 1 << 30)));
   static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
   long long lo = 0;
   for (size_t c = 0; lo < B; ++c) {
@@ -1247,7 +1254,9 @@ int run_table_pipeline(acnqp_handle* h, const acnqp_table* T, const acnqp_option
     dr.obj = reinterpret_cast<double*>(dq + L.ob);
     dr.x_dev = nullptr;
     dr.y = want_y ? reinterpret_cast<double*>(dq + L.y) : nullptr;
+    h->route_hint = (int)std::min<long long>(B, 1 << 30);
     const int rc = acnqp_solve_batch_device(h, &dp, o, &dr, S.st);
+    h->route_hint = 0;
     if (rc != ACNQP_OK) return rc;
 #define TD2H(field, base, elem, per)                                                                                          \
   HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(R->field) + (size_t)lo * (per) * (elem), dq + (base), (size_t)cn * (per) * (elem), \

@@ -12,9 +12,10 @@ One "step" = ONE call of the product entry point `acnqp_solve_batches` over `--b
 batches per GPU, i.e. 16,384 problems per GPU per step, from pinned HOST buffers to pinned HOST buffers:
 H2D of every problem array + kernels + D2H of schedules, statuses, iterations, residuals and objectives,
 all inside the timed region (the metric SURVEY.md section 8d defines; `acnqp_create` -- the one-time site
-upload -- is outside).  The library pipelines the call internally (chunks of up to 2,048 problems -- 512 and 1,024
-for the first two, which shortens the exposed head of the pipeline -- rotate over four streams with their own
-device staging), so there is nothing for the bench to overlap by hand and
+upload -- is outside).  The library pipelines the call internally (chunks of up to 6,144 problems on this shape --
+1,536 and 3,072 for the first two, which shortens the exposed head of the pipeline -- rotate over four streams with
+their own device staging; the small per-problem arrays travel through pinned mirrors, one copy per chunk and
+direction), so there is nothing for the bench to overlap by hand and
 `value` is what any caller of the API gets.  Weak scaling: every rank owns its own 64 x 256 snapshots.
 For N > 1 each step leaves the rank's schedules in HBM as well (acnqp_results.x_dev) and ends with the
 job's single collective, one RCCL all-gather of the schedules over xGMI, overlapped with the next step's
@@ -606,12 +607,13 @@ def main():
             "roofline": {
                 # register / LDS-resident iterative solver: HBM is touched once per problem, so the roof that
                 # can bind is the fp64 arithmetic one (vector = matrix peak on MI355X); the HBM view is reported beside it
-                "bound": "mfma", "binding_unit": "valu (fp64: the vector ALU and the matrix cores share the 78.6 TF peak; the kernel's "
-                                                 "instruction count, not its MFMA chains, is what binds: DESIGN.md 3.1)",
+                "bound": "mfma", "binding_unit": "valu (fp64: the vector ALU and the matrix cores share the 78.6 TF peak; one wave per "
+                                                 "SIMD issues a double-precision vector instruction every 8 cycles, the matrix pipe is "
+                                                 "busy a quarter of the iteration: DESIGN.md 3.1)",
                 "achieved": tf_sparse, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tf_sparse / FP64_VALU_PEAK_TF,
                 "traffic": None if traffic is None else traffic / launch_b * per_step,
-                "kernel": "acnqp::admm_tiled_kernel<double, 4, 1, 1, 1, 2, 5>",
+                "kernel": "acnqp::admm_wave_kernel<5>",
                 "launch_ms": lone_ms, "problems_per_launch": per_step,
                 "flops_per_iteration_sparse": fl_sparse, "flops_per_iteration_dense": fl_dense,
                 "achieved_dense_count": tf_dense, "frac_dense_count": tf_dense / FP64_VALU_PEAK_TF,

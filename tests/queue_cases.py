@@ -13,7 +13,8 @@ if ROOT not in sys.path:
 
 # name -> (site, horizon, batch, equal_share weight, snapshot_batch keywords)
 CASES = {
-    "tiled":    ("caltech54", 12, 1024, 1e-12, {}),
+    "wave":     ("caltech54", 12, 1024, 1e-12, {}),    # the headline shape: one wave per problem (acn_qp_wave.hpp)
+    "tiled":    ("caltech54", 16, 1024, 1e-12, {}),    # horizon 13 ... 16 stays with the register-resident tiled kernel
     "long-lds": ("jpl52", 24, 800, 1e-3, {}),
     "long-96":  ("caltech54", 96, 800, 1e-12, dict(demand_range=(5.0, 60.0))),
     "stream":   ("wide128", 12, 800, 1e-3, dict(min_sessions=40)),

@@ -1,0 +1,120 @@
+"""The wave-per-problem kernel (acn_qp_wave.hpp) against the register-resident tiled kernel it
+replaces on the headline shape -- the same algorithm in another data layout -- and against the C twin.  Each case of
+tests/wave_cases.py is solved in two child processes (ACNQP_WAVE_MIN_BATCH=1: the wave kernel whatever the launch size;
+ACNQP_NO_WAVE=1: the tiled kernel); in this process launches of 512 problems or more take the wave kernel by default."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from adacharge_amd import ObjectiveComponent, equal_share, quick_charge, sites
+from adacharge_amd.builder import build_batch
+from tests import helpers as H
+from tests import wave_cases
+
+RATE_TOL = 1e-4 * 32.0   # north_star: rates within 1e-4 of the maximum rate
+
+
+def _both(tmp_path, name):
+    out = {}
+    for tag, env in (("wave", {"ACNQP_WAVE_MIN_BATCH": "1"}), ("tiled", {"ACNQP_NO_WAVE": "1"})):
+        f = tmp_path / f"{name}_{tag}.npz"
+        e = {k: v for k, v in os.environ.items() if k not in ("ACNQP_WAVE_MIN_BATCH", "ACNQP_NO_WAVE")}
+        subprocess.run([sys.executable, wave_cases.__file__, name, str(f)], check=True, env=dict(e, **env), timeout=900)
+        out[tag] = np.load(f)
+    return out["wave"], out["tiled"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["soc", "linear", "equality", "short", "site30", "peak", "general_windows"])
+def test_wave_kernel_agrees_with_the_tiled_kernel(tmp_path, name):
+    """Same statuses, schedules within the rate tolerance, iteration counts that differ only where rounding moved a
+    residual check (the two kernels sum in different orders): feasible shapes the wave kernel routes -- SOC and LINEAR
+    rows, energy equalities, a short horizon with minimum rates, a 30-EVSE site, a peak row, windows that start late."""
+    w, t = _both(tmp_path, name)
+    assert np.array_equal(w["status"], t["status"]), (w["status"], t["status"])
+    assert (w["status"] == 1).all()
+    assert np.abs(w["x"] - t["x"]).max() <= RATE_TOL
+    same = (w["iters"] == t["iters"]).mean()
+    assert same >= 0.85 and abs(w["iters"].mean() - t["iters"].mean()) <= 0.03 * t["iters"].mean(), (same, w["iters"].mean(), t["iters"].mean())
+    assert np.allclose(w["obj"], t["obj"], rtol=1e-6, atol=1e-6 * np.abs(t["obj"]).max())
+
+
+@pytest.mark.gpu
+def test_wave_kernel_certifies_the_same_infeasible_problems(tmp_path):
+    """Energy equalities the site cannot carry once enough EVSEs are busy: the same problems end INFEASIBLE (the
+    certificate) on both kernels, the rest are solved to the same schedules; and a batch whose sessions cannot be served
+    inside their own bounds ends EMPTY_SET with an all-zero schedule on both."""
+    w, t = _both(tmp_path, "infeasible")
+    assert np.array_equal(w["status"], t["status"])
+    assert (w["status"] == 3).sum() >= 10 and np.isin(w["status"], (1, 3)).all(), np.bincount(w["status"])
+    ok = w["status"] == 1
+    assert ok.sum() >= 10 and np.abs(w["x"][ok] - t["x"][ok]).max() <= RATE_TOL
+    w4, t4 = _both(tmp_path, "empty_set")
+    assert (w4["status"] == 4).all() and (t4["status"] == 4).all() and (w4["x"] == 0).all() and (w4["iters"] == 0).all()
+
+
+@pytest.mark.gpu
+def test_wave_kernel_warm_start_and_multipliers(tmp_path):
+    """A warm start (schedule + site-row multipliers of an earlier solve) is taken and shortens the solve on both kernels
+    alike; the multipliers returned agree."""
+    w, t = _both(tmp_path, "warm")
+    assert (w["status"] == 1).all() and (t["status"] == 1).all()
+    assert np.abs(w["x"] - t["x"]).max() <= RATE_TOL
+    scale = max(1.0, np.abs(t["y"]).max())
+    assert np.abs(w["y"] - t["y"]).max() <= 1e-5 * scale
+    assert abs(w["iters"].mean() - t["iters"].mean()) <= 0.1 * t["iters"].mean()
+
+
+@pytest.mark.gpu
+def test_wave_kernel_hands_stalled_problems_to_the_polish(tmp_path):
+    """The congested horizon-12 fixtures of tests/golden/stalled.npz: the wave kernel leaves them to the polish kernel
+    after polish_iters iterations like the tiled kernel does (three launches: solver, polish, resume), every case SOLVED
+    within the rate tolerance of its certificate."""
+    w, t = _both(tmp_path, "stalled")
+    assert (w["status"] == 1).all() and (t["status"] == 1).all()
+    assert w["iters"].max() <= 800 + 96 and t["iters"].max() <= 800 + 96
+    g = H.load_stalled()
+    names = [str(n) for n in g["names"] if int(g[f"{n}_meta"][0]) == 12]
+    for b, n in enumerate(names):
+        exp = g[f"{n}_rates"]
+        assert np.abs(w["x"][b][:, :exp.shape[1]] - exp).max() <= RATE_TOL, n
+
+
+@pytest.mark.gpu
+def test_default_routing_takes_the_wave_kernel_from_512_problems_and_matches_the_twin():
+    """In this process (no diagnostic variable set): a launch of 1,024 headline problems runs on the wave kernel, one of
+    256 on the tiled kernel -- the kernel times say which (a wave solves its problem alone: 4 us per iteration against 3
+    for the tiled kernel's four waves) -- and both follow the C twin iteration for iteration on most problems."""
+    import torch
+
+    from adacharge_amd.backend import DeviceBatch, SiteHandle, default_options
+    from oracle import admm_port
+
+    assert not os.environ.get("ACNQP_NO_WAVE") and not os.environ.get("ACNQP_WAVE_MIN_BATCH")
+    infra, iface = H.caltech_interface()
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
+    batch = build_batch(sites.snapshot_batch(infra, 12, 1024, seed=20240), infra, iface, obj, "SOC")
+    h = SiteHandle(batch.site, 0)
+    opts = default_options(polish_iters=0)
+    big = h.solve(batch, opts)
+    small = h.solve(batch.subset(slice(0, 256)), opts)
+    assert (big.status == 1).all() and (small.status == 1).all()
+    assert np.abs(big.x[:256] - small.x).max() <= RATE_TOL
+    ref = admm_port.solve_batch(batch.subset(slice(0, 256)), threads=8, accel_mem=5)
+    for res in (big, small):
+        assert (res.iters[:256] == ref["iters"]).mean() >= 0.9
+        assert np.abs(res.x[:256] - ref["x"]).max() <= RATE_TOL
+    # the two launches ran on different kernels: not the same bits, and the 1,024-problem launch took less than four
+    # times the 256-problem one per problem-iteration
+    assert not np.array_equal(big.x[:256], small.x)
+    dev = DeviceBatch(batch, "cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    h.solve_device(dev, opts, stream=st); torch.cuda.synchronize()
+    h.solve_device(dev, opts, stream=st); torch.cuda.synchronize()
+    ms_big = h.last_kernel_ms()
+    assert np.array_equal(dev.x.cpu().numpy(), big.x)
+    h.close()
+    assert ms_big < 6.0, ms_big   # 1,024 problems, one per wave: the slowest problem's ~800 iterations at ~4.3 us

@@ -1,0 +1,98 @@
+"""Cases for the wave-per-problem kernel (acn_qp_wave.hpp), each solved through the host entry acnqp_solve_batch.  Run
+as a script it solves one case under the environment it was started with and saves the result:
+  ACNQP_WAVE_MIN_BATCH=1   every launch of a fitting shape goes to the wave kernel, whatever its size
+  ACNQP_NO_WAVE=1          the register-resident tiled kernel instead (the round-1..3 path)
+tests/test_wave_kernel.py compares the two -- the same algorithm in two data layouts -- and the C twin."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CASES = ("soc", "linear", "equality", "short", "site30", "peak", "infeasible", "empty_set", "warm", "general_windows", "stalled")
+
+
+def build(name):
+    """(batch, options keywords, solve keywords)"""
+    from adacharge_amd import ObjectiveComponent, equal_share, quick_charge, sites
+    from adacharge_amd.acn import Interface
+    from adacharge_amd.builder import build_batch
+
+    infra = sites.caltech54()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
+    rng = np.random.default_rng(9100)
+    if name == "soc":
+        return build_batch(sites.snapshot_batch(infra, 12, 192, seed=911), infra, iface, obj, "SOC"), {}, {}
+    if name == "linear":
+        return build_batch(sites.snapshot_batch(infra, 12, 192, seed=912), infra, iface, obj, "LINEAR"), {}, {}
+    if name == "equality":   # energy DELIVERED (s_eq = 1), small demands so that every instance is feasible
+        snaps = sites.snapshot_batch(infra, 12, 96, seed=913, demand_range=(0.1, 0.5))   # (a one-period session takes at most 0.55 kWh)
+        return build_batch(snaps, infra, iface, obj, "SOC", True), {}, {}
+    if name == "short":      # horizon 7 (five dead period registers per lane), 40 % of the sessions with a minimum rate
+        snaps = sites.snapshot_batch(infra, 7, 96, seed=914, min_rate_fraction=0.4)
+        return build_batch(snaps, infra, iface, obj, "SOC"), {}, {}
+    if name == "site30":     # 30 EVSEs: half a wave of dead lanes, two all-padding EVSE tiles
+        infra30 = sites.eight_sites()[2]
+        iface30 = Interface({"infrastructure_info": infra30, "period": 5})
+        snaps = sites.snapshot_batch(infra30, 12, 96, seed=915)
+        return build_batch(snaps, infra30, iface30, obj, "SOC"), {}, {}
+    if name == "peak":       # LINEAR rows + a peak row (9 of 16 padded rows), the limit binding in about half the periods
+        snaps = sites.snapshot_batch(infra, 12, 96, seed=916)
+        peaks = [rng.uniform(150.0, 600.0, size=12) for _ in snaps]
+        return build_batch(snaps, infra, iface, obj, "LINEAR", False, peaks), {}, {}
+    if name == "infeasible":   # equalities the SITE cannot carry once enough EVSEs are busy (every session alone is feasible:
+                               # whole-horizon windows, 3 ... 6 of the 6.6 kWh one EVSE can take): certificates (status 3)
+        from adacharge_amd.sites import SessionInfo
+
+        snaps = []
+        for b in range(128):
+            evses = rng.choice(infra.num_stations, size=int(rng.integers(6, 55)), replace=False)
+            snaps.append([SessionInfo(infra.station_ids[int(e)], f"s{k}", float(rng.uniform(3.0, 6.0)), 0.0, 0, 12, current_time=0,
+                                      min_rates=np.zeros(12), max_rates=32.0) for k, e in enumerate(evses)])
+        return build_batch(snaps, infra, iface, obj, "LINEAR", True), dict(max_iter=30000), {}
+    if name == "empty_set":   # demands no session can take inside its own window: status 4 before the first iteration
+        snaps = sites.snapshot_batch(infra, 12, 64, seed=917, demand_range=(10.0, 45.0))
+        return build_batch(snaps, infra, iface, obj, "LINEAR", True), {}, {}
+    if name == "warm":       # warm start from a perturbed earlier answer, multipliers returned
+        b = build_batch(sites.snapshot_batch(infra, 12, 64, seed=918), infra, iface, obj, "SOC")
+        return b, {}, dict(warm="self", want_y=True)
+    if name == "general_windows":   # delayed arrivals and minimum rates over a prefix: lb != 0, windows that do not start at 0
+        snaps = [sites.random_sessions_general(infra, 12, rng, False, min_rates=True) for _ in range(96)]
+        return build_batch(snaps, infra, iface, obj, "SOC"), {}, {}
+    if name == "stalled":    # the congested fixtures the polish exists for (hand-over at polish_iters, resume behind it)
+        from tests import helpers as H
+
+        g = H.load_stalled()
+        names = [str(n) for n in g["names"] if int(g[f"{n}_meta"][0]) == 12]
+        cases = [H.wide_case(g, n) for n in names]
+        meta = cases[0][3]
+        sobj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, meta["es"])]
+        return build_batch([c[0] for c in cases], cases[0][1], cases[0][2], sobj, "SOC"), {}, {}
+    raise KeyError(name)
+
+
+def solve(name):
+    from adacharge_amd.backend import SiteHandle, default_options
+
+    batch, okw, skw = build(name)
+    h = SiteHandle(batch.site, 0)
+    opts = default_options(**okw)
+    warm = None
+    if skw.get("warm") == "self":
+        first = h.solve(batch, opts, want_y=True)
+        rng = np.random.default_rng(5)
+        warm = (first.x * rng.uniform(0.9, 1.0, size=first.x.shape), first.y)
+    res = h.solve(batch, opts, warm=warm, want_y=bool(skw.get("want_y")))
+    out = dict(x=res.x, iters=res.iters, status=res.status, pri=res.pri_res, dua=res.dua_res, obj=res.obj)
+    if res.y is not None:
+        out["y"] = res.y
+    h.close()
+    return out
+
+
+if __name__ == "__main__":
+    np.savez(sys.argv[2], **solve(sys.argv[1]))

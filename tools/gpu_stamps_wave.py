@@ -20,10 +20,12 @@ for NB in [int(a) for a in sys.argv[1:]] or [256]:
     buf = (C.c_ulonglong * (1024 * 16 * 12))()
     lib.acnqp_debug_read_wave_stamps(buf, 1024 * 16 * 12)
     nb = min(NB, 1024)
-    st = np.array(buf, dtype=np.float64).reshape(1024, 16, 12)[:nb, 0]
+    st = np.array(buf, dtype=np.float64).reshape(1024, 16 * 12)[:nb, :24]
     per_iter = st / res.iters[:nb, None]
     print("B", NB, "kernel_ms %.2f" % res.kernel_ms, "iters mean %.1f max %d" % (res.iters.mean(), res.iters.max()))
     tot = per_iter[:, :8].sum(-1).mean()
     for k, n in enumerate(names):
         print("   %-22s %8.0f ticks/iter  %.1f%%" % (n, per_iter[:, k].mean(), 100 * per_iter[:, k].mean() / tot))
+    for k, n in ((12, "aa: f, column, stores"), (13, "aa: dots, wave sums"), (14, "aa: bookkeeping, solve"), (15, "aa: correction")):
+        print("   %-22s %8.0f ticks/iter" % (n, per_iter[:, k].mean()))
     print("   total %.0f s_memtime ticks/iter; s_memtime rate %.0f MHz; us/iter %.2f" % (tot, 100.0 * st[:, 10].sum() / st[:, 9].sum(), (st[:, 9] / 100.0 / res.iters[:nb]).mean()))

@@ -25,7 +25,7 @@ d = {
         "waiting_for_issue_lds": m["SQ_WAIT_INST_LDS"] / wc,
     },
     "mfma_pipe_busy_share_of_sq_busy_cycles_x4": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * m["SQ_BUSY_CYCLES"]),
-    "reading": "two waves per SIMD: the vector ALU of a SIMD is busy ~2 x executing_valu of the time; no single wait dominates",
+    "reading": sys.argv[4] if len(sys.argv) > 4 else "two waves per SIMD: the vector ALU of a SIMD is busy ~2 x executing_valu of the time; no single wait dominates",
 }
 json.dump(d, open(out, "w"), indent=1)
 print(json.dumps(d["per_wave_per_iteration"]), json.dumps(d["share_of_wave_resident_cycles"]))

@@ -3,6 +3,7 @@ summaries under profiles/: <tag>_kernel_stats.csv, <tag>_pmc_summary.json, <traf
 
     python tools/summarise_profile.py r02a_bench admm_tiled_kernel hbm_traffic.json
     python tools/summarise_profile.py r02a_cfg5 admm_stream_kernel r02a_cfg5_traffic.json
+    python tools/summarise_profile.py r04w_bench admm_wave_kernel hbm_traffic.json 4096 4   (four problems per workgroup)
 """
 import csv
 import glob
@@ -14,8 +15,9 @@ import sys
 tag = sys.argv[1]
 KERNEL = sys.argv[2] if len(sys.argv) > 2 else "admm_tiled_kernel"
 TRAFFIC_FILE = sys.argv[3] if len(sys.argv) > 3 else "hbm_traffic.json"
-MIN_PROBLEMS = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # skip dispatches of fewer workgroups (round 4: the resume launch
+MIN_PROBLEMS = int(sys.argv[4]) if len(sys.argv) > 4 else 0   # skip dispatches of fewer problems (round 4: the resume launch
                                                               # behind the polish is the same kernel on a handful of problems)
+PER_WG = int(sys.argv[5]) if len(sys.argv) > 5 else 1         # problems per workgroup of the static schedule (4: acn_qp_wave.hpp)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -36,12 +38,12 @@ for f in sorted(newest.values()):
     for row in csv.DictReader(open(f)):
         if KERNEL not in row["Kernel_Name"]:
             continue
-        if MIN_PROBLEMS and int(row["Grid_Size"]) // max(int(row["Workgroup_Size"]), 1) < MIN_PROBLEMS:
+        if MIN_PROBLEMS and PER_WG * int(row["Grid_Size"]) // max(int(row["Workgroup_Size"]), 1) < MIN_PROBLEMS:
             continue
         per.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
         per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
         try:   # one workgroup per problem: problems of the dispatch = grid / workgroup size
-            problems.setdefault(row["Counter_Name"], {})[row["Dispatch_Id"]] = int(row["Grid_Size"]) // int(row["Workgroup_Size"])
+            problems.setdefault(row["Counter_Name"], {})[row["Dispatch_Id"]] = PER_WG * int(row["Grid_Size"]) // int(row["Workgroup_Size"])
         except (KeyError, ValueError, ZeroDivisionError):
             pass
         if meta is None:
