@@ -155,9 +155,6 @@ struct acnqp_handle {
   // chunk instead of nine and five per batch of the call -- a stream operation costs tens of microseconds whatever its size,
   // and a step of 64 batches was 960 of them (run_pipeline)
   HostBuf small_in, small_out;
-  // problems of the host-entry call a launch belongs to (0: a launch of its own): the kernel family is chosen for the
-  // CALL, so that a call's last, short chunk does not run on a different kernel than its first ones (wave_shape)
-  int route_hint = 0;
   hipEvent_t h2d_done[kSlots] = {nullptr, nullptr, nullptr, nullptr};   // chunk c's inputs have landed (run_pipeline: the next chunk's copies queue behind them)
   // per launch stream: the kernel workspace (long-horizon, large-site, general-shape kernels) and the launch's small
   // scheduling buffer (queue counter, then sort keys and queue order).  Launches on different streams never share (or
@@ -700,7 +697,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     ga.t = a;
   }
   auto launch_solver = [&](const acnqp::TiledArgs& aa) -> hipError_t {
-    if (tiled && acnqp::wave_shape(h->N, p->t_max, p->k_sessions, d->MR, h->has_flat || h->has_max, std::max(p->batch, h->route_hint))) return acnqp::launch_wave(aa, st);
+    if (tiled && acnqp::wave_shape(h->N, p->t_max, p->k_sessions, d->MR, h->has_flat || h->has_max, p->batch)) return acnqp::launch_wave(aa, st);
     if (tiled) return p->t_max <= 16 ? acnqp::launch_tiled_ct1(aa, st) : acnqp::launch_tiled_ct2(aa, st);
     if (stream) { sa.t = aa; return acnqp::launch_stream(sa, st); }
     if (lng) { sa.t = aa; return acnqp::launch_long(sa, st, lds_long_shape(h, p->t_max)); }
@@ -1054,9 +1051,7 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
     dr.obj = reinterpret_cast<double*>(dq + L.ob);
     dr.x_dev = nullptr;
     dr.y = want_y ? reinterpret_cast<double*>(dq + L.y) : nullptr;
-    h->route_hint = (int)std::min<long long>(call_total, 1 << 30);
     const int rc = acnqp_solve_batch_device(h, &dp, o, &dr, S.st);
-    h->route_hint = 0;
     if (rc != ACNQP_OK) return rc;
     char* ho = staged ? static_cast<char*>(h->small_out.p) + out_off[c] - L.st : nullptr;   // ho + L.field = the mirror of dq + L.field
     if (staged) HIP_TRY(hipMemcpyAsync(ho + L.st, dq + L.st, L.y - L.st, hipMemcpyDeviceToHost, S.st));
@@ -1254,9 +1249,7 @@ int run_table_pipeline(acnqp_handle* h, const acnqp_table* T, const acnqp_option
     dr.obj = reinterpret_cast<double*>(dq + L.ob);
     dr.x_dev = nullptr;
     dr.y = want_y ? reinterpret_cast<double*>(dq + L.y) : nullptr;
-    h->route_hint = (int)std::min<long long>(B, 1 << 30);
     const int rc = acnqp_solve_batch_device(h, &dp, o, &dr, S.st);
-    h->route_hint = 0;
     if (rc != ACNQP_OK) return rc;
 #define TD2H(field, base, elem, per)                                                                                          \
   HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(R->field) + (size_t)lo * (per) * (elem), dq + (base), (size_t)cn * (per) * (elem), \

@@ -5,15 +5,15 @@
 namespace acnqp {
 
 // shapes the wave-per-problem kernel takes: a lane per EVSE, twelve period registers, one session slot, one row tile,
-// box / disc / peak rows -- and launches of at least kWaveMinBatch problems.  A problem is ONE wave's dependent chain here
-// (4.3 us per iteration) and four waves' in the tiled kernel (3.1 us alone on a CU, 4.6 us with a second workgroup
-// beside it): up to one problem per CU the tiled kernel finishes a launch sooner (256 problems: 2.3 against 2.9 ms),
-// from two per CU on the wave kernel's four problems per CU win (16,384: 26.5 -> 15.5 ms).  Both run the same algorithm
-// with the same parameters; their answers agree to the solver tolerance, not bit for bit (tests/test_wave_kernel.py).
-constexpr int kWaveMinBatch = 512;
+// box / disc / peak rows.  A function of the SHAPE only, never of the batch size: a problem's result does not depend on
+// what it is batched with (tests/test_gpu_parity.py asserts the bits).  The price: a problem is ONE wave's dependent chain
+// here (4.3 us per iteration) and four waves' in the tiled kernel (3.1 us alone on a CU), so a launch of at most one
+// problem per CU ends later than it did (256 problems: 2.9 against 2.3 ms; one problem: 0.85 against 0.6 ms) -- from two
+// problems per CU on, four problems in flight per CU win (16,384: 26.5 -> 15.5 ms).  ACNQP_WAVE_MIN_BATCH=n (diagnostic)
+// sends launches of fewer than n problems to the tiled kernel.
 bool wave_shape(int N, int t_max, int k_sessions, int MR, bool has_prox, int batch) {
   static const bool off = std::getenv("ACNQP_NO_WAVE") != nullptr;   // diagnostic / A-B: the register-resident tiled kernel instead
-  static const int min_batch = std::getenv("ACNQP_WAVE_MIN_BATCH") ? std::atoi(std::getenv("ACNQP_WAVE_MIN_BATCH")) : kWaveMinBatch;
+  static const int min_batch = std::getenv("ACNQP_WAVE_MIN_BATCH") ? std::atoi(std::getenv("ACNQP_WAVE_MIN_BATCH")) : 1;
   return !off && N <= 64 && t_max <= kWaveTS && k_sessions == 1 && MR == 16 && !has_prox && batch >= min_batch;
 }
 

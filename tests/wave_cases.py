@@ -1,6 +1,6 @@
 """Cases for the wave-per-problem kernel (acn_qp_wave.hpp), each solved through the host entry acnqp_solve_batch.  Run
 as a script it solves one case under the environment it was started with and saves the result:
-  ACNQP_WAVE_MIN_BATCH=1   every launch of a fitting shape goes to the wave kernel, whatever its size
+  ACNQP_WAVE_MIN_BATCH=1   every launch of a fitting shape goes to the wave kernel (the default; pinned here)
   ACNQP_NO_WAVE=1          the register-resident tiled kernel instead (the round-1..3 path)
 tests/test_wave_kernel.py compares the two -- the same algorithm in two data layouts -- and the C twin."""
 import os
