@@ -366,7 +366,8 @@ def plan_from_table(
     elif any_peak and not site.has_peak:
         raise ValueError("site was built without a peak row but a peak_limit was given")
     S = table.S
-    if S == 0 or len(np.unique(table.prob)) != B:
+    per_snapshot = np.bincount(table.prob, minlength=B) if S and table.prob.min() >= 0 else np.zeros(0, np.int64)
+    if S == 0 or len(per_snapshot) != B or (per_snapshot == 0).any():
         raise ValueError("every snapshot of a batch needs at least one session (aco.py:310-311 handles the empty case)")
     rlen_in = np.diff(table.seg)
     if np.any(rlen_in != np.maximum(table.rem, 0)):
@@ -388,13 +389,17 @@ def plan_from_table(
         bad = (table.demand[dead] < 0) | (enforce_energy_equality & (table.demand[dead] != 0))
         presolve[prob[dead[bad]]] = 1
     key = prob[live] * N + evse[live]
-    order = np.argsort(key, kind="stable")
-    ks = key[order]
-    first = np.r_[0, np.flatnonzero(np.diff(ks)) + 1]
-    counts = np.diff(np.r_[first, len(ks)])
-    rank = np.arange(len(ks)) - np.repeat(first, counts)
-    K = int(rank.max()) + 1 if len(ks) else 1
-    if K > 1:   # sessions sharing an EVSE must not overlap in time
+    s_slot = np.zeros(S, dtype=np.int32)
+    if len(key) == 0 or np.bincount(key, minlength=B * N).max() <= 1:
+        K = 1   # one session per (snapshot, EVSE) at most -- the usual case: every slot is 0, no sort (13 + 6 of 54 ms)
+    else:
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        first = np.r_[0, np.flatnonzero(np.diff(ks)) + 1]
+        counts = np.diff(np.r_[first, len(ks)])
+        rank = np.arange(len(ks)) - np.repeat(first, counts)
+        K = int(rank.max()) + 1
+        # sessions sharing an EVSE must not overlap in time
         lo = live[order]
         o2 = np.lexsort((off[lo], ks))                 # by EVSE group, then window start
         so, sr, sk = off[lo][o2], rem[lo][o2], ks[o2]
@@ -405,11 +410,10 @@ def plan_from_table(
                 f"sessions on EVSE {infrastructure.station_ids[int(evse[w])]} overlap in time; the structured "
                 "builder needs disjoint session windows per EVSE"
             )
-    s_slot = np.zeros(S, dtype=np.int32)
-    s_slot[live[order]] = rank
+        s_slot[live[order]] = rank
     s_cap = table.demand / kwh_per_amp_period[evse]
     sess_seg = np.zeros(B + 1, dtype=np.int32)
-    sess_seg[1:] = np.cumsum(np.bincount(prob, minlength=B))
+    sess_seg[1:] = np.cumsum(per_snapshot)
     # ---- objective: depends on the problem only through its horizon ----------------------------------------------
     horizons = np.unique(end)
     q_table = np.zeros((len(horizons), N, Tm))

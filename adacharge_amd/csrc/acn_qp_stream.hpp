@@ -96,7 +96,10 @@ __device__ inline void stream_block_max(double (&v)[NV], double* S, int lane, in
 }
 
 template <int CT, int MT, int NWV>
-__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 1) void admm_stream_kernel(const StreamArgs SA_kernarg) {
+#ifndef ACNQP_STREAM_OCC
+#define ACNQP_STREAM_OCC 2
+#endif
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void admm_stream_kernel(const StreamArgs SA_kernarg) {
   constexpr int kStreamWaves = NWV;
   using M = Mfma<double>;
   using vec4 = M::vec4;
