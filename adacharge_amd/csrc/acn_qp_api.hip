@@ -697,7 +697,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     ga.t = a;
   }
   auto launch_solver = [&](const acnqp::TiledArgs& aa) -> hipError_t {
-    if (tiled && acnqp::wave_shape(h->N, p->t_max, p->k_sessions, d->MR, h->has_flat || h->has_max, p->batch)) return acnqp::launch_wave(aa, st);
+    if (tiled && acnqp::wave_shape(h->N, p->t_max, p->k_sessions, d->MR, h->has_flat || h->has_max, p->batch) > 0) return acnqp::launch_wave(aa, st);
     if (tiled) return p->t_max <= 16 ? acnqp::launch_tiled_ct1(aa, st) : acnqp::launch_tiled_ct2(aa, st);
     if (stream) { sa.t = aa; return acnqp::launch_stream(sa, st); }
     if (lng) { sa.t = aa; return acnqp::launch_long(sa, st, lds_long_shape(h, p->t_max)); }
@@ -943,7 +943,7 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
         cur_T = (int)Tm; cur_K = (int)K; cur_opt = opt; fill = 0;
         // (the kernels' workspaces belong to the resident workgroup slots since the work queue: no per-problem term)
         cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K),
-                             tiled_shape(h, (int)Tm, (int)K) && acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(call_total, 1 << 30)));
+                             tiled_shape(h, (int)Tm, (int)K) && acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(call_total, 1 << 30)) > 0);
         // ramp: the first kernel cannot start before its chunk's H2D has landed, and nothing overlaps that copy -- a
         // quarter-size first chunk (then a half-size one) shortens the exposed head of the pipeline
         static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
@@ -1167,7 +1167,7 @@ int run_table_pipeline(acnqp_handle* h, const acnqp_table* T, const acnqp_option
   const long long B = T->batch;
   const size_t nv = N * Tm, nsl = K * N;
   long long cap0 = chunk_problems(4 * nv * 8 + nsl * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K),
-                                  tiled_shape(h, (int)Tm, (int)K) && acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(B, 1 << 30)));
+                                  tiled_shape(h, (int)Tm, (int)K) && acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(B, 1 << 30)) > 0);
   static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
   long long lo = 0;
   for (size_t c = 0; lo < B; ++c) {

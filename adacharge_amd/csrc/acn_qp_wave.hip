@@ -10,25 +10,31 @@ namespace acnqp {
 // here (4.3 us per iteration) and four waves' in the tiled kernel (3.1 us alone on a CU), so a launch of at most one
 // problem per CU ends later than it did (256 problems: 2.9 against 2.3 ms; one problem: 0.85 against 0.6 ms) -- from two
 // problems per CU on, four problems in flight per CU win (16,384: 26.5 -> 15.5 ms).  ACNQP_WAVE_MIN_BATCH=n (diagnostic)
-// sends launches of fewer than n problems to the tiled kernel.
-bool wave_shape(int N, int t_max, int k_sessions, int MR, bool has_prox, int batch) {
+// sends launches of fewer than n problems to the tiled kernel.  Returns the waves per problem (0: not this kernel; 1:
+// horizon <= 12; 2: horizon 13 ... 24).
+int wave_shape(int N, int t_max, int k_sessions, int MR, bool has_prox, int batch) {
   static const bool off = std::getenv("ACNQP_NO_WAVE") != nullptr;   // diagnostic / A-B: the register-resident tiled kernel instead
+  static const bool off2 = std::getenv("ACNQP_NO_WAVE2") != nullptr; // ... for horizons 13 ... 24 only
   static const int min_batch = std::getenv("ACNQP_WAVE_MIN_BATCH") ? std::atoi(std::getenv("ACNQP_WAVE_MIN_BATCH")) : 1;
-  return !off && N <= 64 && t_max <= kWaveTS && k_sessions == 1 && MR == 16 && !has_prox && batch >= min_batch;
+  if (off || N > 64 || t_max > 2 * kWaveTS || k_sessions != 1 || MR != 16 || has_prox || batch < min_batch) return 0;
+  if (t_max <= kWaveTS) return 1;
+  return off2 ? 0 : 2;   // two waves per problem, twelve periods each
 }
 
-hipError_t launch_wave(const TiledArgs& a_in, hipStream_t st) {
+template <int NPW>
+static hipError_t launch_wave_npw(const TiledArgs& a_in, hipStream_t st) {
   TiledArgs a = a_in;
   a.accel_mem = std::min(a.accel_mem, kWaveAM);
-  const WaveLds L(a.accel_mem);
+  const WaveLds L(a.accel_mem, NPW);
   const size_t lds = (size_t)L.total * 8;
-  auto kern = &admm_wave_kernel<kWaveAM>;
+  auto kern = &admm_wave_kernel<kWaveAM, NPW>;
   if (lds > 64 * 1024) {
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
   }
-  // one queue position per WAVE: a workgroup serves kWaveNW positions at a time
-  const int groups = (a.B + kWaveNW - 1) / kWaveNW;
+  // one queue position per WAVE (pair of waves): a workgroup serves kWaveNW / NPW positions at a time
+  constexpr int per_wg = kWaveNW / NPW;
+  const int groups = (a.B + per_wg - 1) / per_wg;
   int grid = groups;
   if (a.queue) {
     const int per_cu = resident_per_cu(reinterpret_cast<const void*>(kern), kWaveNW * 64, lds), cus = device_cus();
@@ -45,6 +51,10 @@ hipError_t launch_wave(const TiledArgs& a_in, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaveNW * 64), lds, st, a);
   return hipGetLastError();
+}
+
+hipError_t launch_wave(const TiledArgs& a, hipStream_t st) {
+  return a.Tm <= kWaveTS ? launch_wave_npw<1>(a, st) : launch_wave_npw<2>(a, st);
 }
 
 }  // namespace acnqp

@@ -14,7 +14,15 @@
 //       corr (periods x EVSEs) = e^' Ghat            16                       (A operand = the e^ accumulator tile)
 //     with the A / B fragments of Ghat and Q read from LDS (20 KB per workgroup, loaded once per launch).
 //
-// Shapes: N <= 64 EVSEs, horizon <= 12, one session slot per EVSE, <= 16 site rows (one row tile), box / disc / peak
+// Horizons 13 ... 24 (NPW = 2): TWO waves per problem, wave h holding periods 12 h ... 12 h + 11 of every EVSE.  The
+// products and the site rows are per period, so they stay wave-local (each wave its own transposes, MFMA chains and
+// site-row tile); what couples the halves are sums over a session's window (the water-filling: two per-lane values per
+// pass), the Anderson event's seven dot products and the residual check's maxima -- exchanged through a 2 KB LDS mailbox
+// per wave with a sequence flag (pair_xchg: the partner's in-order LDS writes, then its flag; no workgroup barrier,
+// the other pair of the workgroup is never involved).  Both waves take the same branches: every decision is made on
+// exchanged, identical values.
+//
+// Shapes: N <= 64 EVSEs, horizon <= 12 (one wave) or <= 24 (two), one session slot per EVSE, <= 16 site rows (one row tile), box / disc / peak
 // rows (no prox row).  Everything else stays with acn_qp_tiled.hpp (acn_qp_api.hip routes; ACNQP_NO_WAVE=1 keeps the
 // tiled kernel for these shapes too: the A/B switch of the parity tests).
 #pragma once
@@ -33,7 +41,8 @@ constexpr int kWaveAM = 5;    // Anderson columns compiled in
 struct WaveLds {
   int fragp, fragx, fragq, rowc, wave0, wstride;   // offsets in doubles
   int xt, rowd, aah, snap, hist, total;            // per-wave offsets (relative to the wave's region), total in doubles
-  __host__ __device__ WaveLds(int accel_mem) {
+  int xch;                                         // NPW == 2: the wave's mailbox (two buffers of [2][64] doubles) + its flag
+  __host__ __device__ WaveLds(int accel_mem, int npw = 1) {
     int o = 0;
     fragp = o; o += 16 * 64;          // Ghat as A operand of P = Ghat r0: [k-step][lane]
     fragx = o; o += 4 * 4 * 64;       // Ghat as B operand of corr = e^' Ghat: [EVSE tile][k-step][lane]
@@ -45,7 +54,10 @@ struct WaveLds {
     rowd = w; w += 16;                // rho / (a + rho lam)
     aah = w;  w += kWaveAM * kWaveAM + kWaveAM + 1;
     w = (w + 1) & ~1;
-    snap = w; w += 64 * 16 / 2;       // floats: [chunk of 4][lane][4]
+    snap = w; xch = w;
+    w += npw == 2 ? 2 * 2 * 64 + 2 : 64 * 16 / 2;   // one wave per problem: the certificate snapshot, floats [chunk of 4][lane][4];
+                                                    // two: the mailbox (the snapshot lives in registers there)
+    w = (w + 1) & ~1;
     hist = w; w += accel_mem * 64 * 16 / 2;
     wstride = (w + 1) & ~1;
     total = wave0 + kWaveNW * wstride;
@@ -70,8 +82,9 @@ __device__ inline void wave_lds_sync() {   // this wave's LDS writes are visible
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int AM>
+template <int AM, int NPW>
 __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledArgs A_kernarg) {
+  static_assert(NPW == 1 || NPW == 2, "one or two waves per problem");
   using M = Mfma<double>;
   using vec4 = typename M::vec4;
   typedef double real;
@@ -82,10 +95,14 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   const int tid0 = threadIdx.x;
   const int lane = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int g = lane >> 4, tc = lane & 15;   // MFMA operand coordinates of the lane
+  const int half = NPW == 2 ? (wave & 1) : 0;   // which half of the horizon this wave holds (scalar)
+  const int tb = 12 * half;                     // its first period
+  int xseq = 0;                                 // mailbox sequence number (the partner counts the same exchanges)
+  bool xbroken = false;                         // a wait ran into its bound (never expected): no further waits
 
   // ---- once per workgroup: the site's fragments and row constants -> LDS ------------------------------------------------
   {
-    const WaveLds L0(0);
+    const WaveLds L0(0, NPW);
     const int NP = A_kernarg.NP;
     const real* Gh = static_cast<const real*>(A_kernarg.Ghat);
     const real* FQg = static_cast<const real*>(A_kernarg.fragQ);
@@ -102,13 +119,91 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       const int g_ = tid0 >> 2, r_ = tid0 & 3;
       reinterpret_cast<int*>(sm + L0.rowc + 32)[tid0] = A_kernarg.rowtype[M::rowof(g_, r_)];
     }
-    real* XT0 = sm + L0.wave0 + (size_t)wave * WaveLds(min(A_kernarg.accel_mem, AM)).wstride;
+    const WaveLds L1(min(A_kernarg.accel_mem, AM), NPW);
+    real* XT0 = sm + L1.wave0 + (size_t)wave * L1.wstride;
     for (int k = lane; k < 64 * XS; k += 64) XT0[k] = 0;   // the pad columns (periods 12 ... 15) stay zero for good
+    if (NPW == 2 && lane < 2) reinterpret_cast<int*>(XT0 + L1.xch + 2 * 2 * 64)[lane] = 0;   // the mailbox flag
   }
   __syncthreads();   // the only workgroup barrier of the kernel
 
-  for (int q_round = 0;; ++q_round) {   // work queue: this WAVE's next problem
-  const int q_pos = wave_queue_next(A_kernarg.queue, queue_length(A_kernarg), q_round, wave, lane);
+  // ---- the pair's mailbox (NPW == 2): my two per-lane values out, the partner's in ----------------------------------------
+  // Protocol: write the values into buffer (seq & 1) of MY mailbox, then my flag = seq (LDS operations of a wave complete
+  // in order); wait for the partner's flag >= seq; read ITS buffer.  Double buffering is enough: the partner raises its
+  // flag to seq + 1 only after it has read my buffer of seq, and I write that buffer again at seq + 2.  Every wait is
+  // bounded (a wave that never arrives would otherwise hang the queue for good).
+  real* Xm = nullptr;
+  const real* Xp = nullptr;
+  if constexpr (NPW == 2) {
+    const WaveLds Lx(min(A_kernarg.accel_mem, AM), NPW);
+    Xm = sm + Lx.wave0 + (size_t)wave * Lx.wstride + Lx.xch;
+    Xp = sm + Lx.wave0 + (size_t)(wave ^ 1) * Lx.wstride + Lx.xch;
+  }
+  auto pair_xchg = [&](real va, real vb, real& pa, real& pb) __attribute__((always_inline)) {
+    if constexpr (NPW == 2) {
+      ++xseq;
+      const int o = (xseq & 1) * 128;
+      Xm[o + lane] = va;
+      Xm[o + 64 + lane] = vb;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) *reinterpret_cast<volatile int*>(Xm + 256) = xseq;
+      if (!xbroken) {
+        int spins = 0;
+        while (*reinterpret_cast<const volatile int*>(Xp + 256) - xseq < 0) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 22)) { xbroken = true; break; }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      pa = Xp[o + lane];
+      pb = Xp[o + 64 + lane];
+    } else {
+      pa = va; pb = vb;   // (never used)
+    }
+  };
+  // per-lane sum / max / min over the problem's two waves (identity with one wave)
+  auto pl_sum2 = [&](real& va, real& vb) __attribute__((always_inline)) {
+    if constexpr (NPW == 2) { real pa, pb; pair_xchg(va, vb, pa, pb); va += pa; vb += pb; }
+  };
+  // up to 8 wave-uniform values at once: value j rides in lane j
+  auto pu_sum = [&](real* d, int n) __attribute__((always_inline)) {
+    if constexpr (NPW == 2) {
+      real v = 0, pa, pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (j < n) v = lane == j ? d[j] : v;
+      pair_xchg(v, 0.0, pa, pb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (j < n) d[j] += lane_value(pa, j);
+    }
+  };
+  auto pu_max = [&](real* d, int n) __attribute__((always_inline)) {
+    if constexpr (NPW == 2) {
+      real v = 0, pa, pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (j < n) v = lane == j ? d[j] : v;
+      pair_xchg(v, 0.0, pa, pb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (j < n) d[j] = fmax(d[j], lane_value(pa, j));
+    }
+  };
+
+  for (int q_round = 0;; ++q_round) {   // work queue: this WAVE's (pair's) next problem
+  int q_pos;
+  if constexpr (NPW == 2) {   // the first wave of the pair fetches; the position travels through the mailbox
+    int mine = 0;
+    if (half == 0) {
+      if (A_kernarg.queue == nullptr) {
+        const int pos = (int)blockIdx.x * (kWaveNW / 2) + (wave >> 1);
+        mine = q_round == 0 && pos < queue_length(A_kernarg) ? pos : -1;
+      } else {
+        mine = wave_queue_next(A_kernarg.queue, queue_length(A_kernarg), q_round, wave, lane);
+      }
+    }
+    real pa, pb;
+    pair_xchg((real)mine, 0.0, pa, pb);
+    q_pos = half == 0 ? mine : __builtin_amdgcn_readfirstlane((int)pa);
+  } else {
+    q_pos = wave_queue_next(A_kernarg.queue, queue_length(A_kernarg), q_round, wave, lane);
+  }
   if (q_pos < 0) break;
   int it_total = 0, best_status = 0;
   for (int pass = 0;; ++pass) {
@@ -127,7 +222,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   const int adapt_p = pass == 0 ? A.adapt_every : 0;
   const int N = A.N, Tm = A.Tm;
   const int aa_m = min(A.accel_mem, AM);
-  const WaveLds L(aa_m);
+  const WaveLds L(aa_m, NPW);
   const real* FragP = sm + L.fragp;
   const real* FragX = sm + L.fragx;
   const real* FQs = sm + L.fragq;
@@ -197,8 +292,8 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   real x[TS], z1[TS], y1[TS], qv[TS], lbv[TS], ubv[TS];
 #pragma unroll
   for (int t = 0; t < TS; ++t) {
-    const bool ok = act && t < Tm;
-    const size_t idx = ((size_t)b * N + (ok ? lane : 0)) * Tm + (ok ? t : 0);
+    const bool ok = act && tb + t < Tm;
+    const size_t idx = ((size_t)b * N + (ok ? lane : 0)) * Tm + (ok ? tb + t : 0);
     lbv[t] = ok ? A.lb[idx] : 0.0;
     ubv[t] = ok ? A.ub[idx] : 0.0;
     qv[t] = ok ? A.q[idx] : 0.0;
@@ -218,7 +313,8 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
     real sl = 0, su = 0;
 #pragma unroll
     for (int t = 0; t < TS; ++t)
-      if (t >= off && t < off + len && t < Tm) { swm |= 1u << t; sl += lbv[t]; su += ubv[t]; }
+      if (tb + t >= off && tb + t < off + len && tb + t < Tm) { swm |= 1u << t; sl += lbv[t]; su += ubv[t]; }
+    pl_sum2(sl, su);   // (the window may span both halves)
     scap = act ? A.s_cap[sidx] : 0.0;
     if (len > 0) {
       smode = 0;
@@ -231,8 +327,8 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   }
   // the peak limit of the lane's period column (C layout), scaled like its row
   real pk_lane = BIGC;
-  if (A.peak && tc < Tm) {
-    const double pv = A.peak[(size_t)b * Tm + tc];
+  if (A.peak && tc < TS && tb + tc < Tm) {
+    const double pv = A.peak[(size_t)b * Tm + tb + tc];
     pk_lane = pv < 1e300 ? pv * A.peak_scale : BIGC;
   }
 
@@ -254,16 +350,17 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       if (!((swm >> t) & 1u)) f3 = fmax(f3, fmax(fabs(lbv[t]), fabs(ubv[t])));
     }
     f1 = wave_max<real>(f1); f2 = wave_max<real>(f2); f3 = wave_max<real>(f3);
+    { real f[3] = {f1, f2, f3}; pu_max(f, 3); f1 = f[0]; f2 = f[1]; f3 = f[2]; }
     plain_windows = uniform_scalar(f3) == 0.0;
     qnorm = uniform_scalar(f1);
     pd = uniform_scalar(effective_pdiag<real>(pd_user, A.reg_rel, qnorm, uniform_scalar(f2), A.horizon[b], false));
     if (__any(empty_set)) {   // a session cannot meet its energy row inside its own bounds (wave-uniform)
 #pragma unroll
       for (int t = 0; t < TS; ++t)
-        if (act && t < Tm) A.x[((size_t)b * N + lane) * Tm + t] = 0;
-      if (A.y_out && !A.y_for_polish_only)
+        if (act && tb + t < Tm) A.x[((size_t)b * N + lane) * Tm + tb + t] = 0;
+      if (A.y_out && !A.y_for_polish_only && half == 0)
         for (int k = lane; k < A.Mg * Tm; k += 64) A.y_out[(size_t)b * A.Mg * Tm + k] = 0;
-      if (lane == 0) {
+      if (lane == 0 && half == 0) {
         A.status[b] = 4; A.iters[b] = 0;
         A.pri[b] = 1e300; A.dua[b] = 1e300; A.obj[b] = 0;
       }
@@ -289,6 +386,11 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   real best_score = BIGC;
   real pri = BIGC, dua = BIGC;
   bool done = false, have_prev = false;
+  float sn1[TS], sn2[4];   // NPW == 2: the certificate's dual snapshot (one wave per problem keeps it in LDS: Snap)
+#pragma unroll
+  for (int t = 0; t < TS; ++t) sn1[t] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sn2[r] = 0.f;
 
   // ---- Anderson acceleration state (wave-uniform scalars; vectors: EVSE layout [0, TS) then the site tile [TS, TS + 4)) ----
   constexpr int DV = TS + 4;
@@ -336,7 +438,8 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       real sp = 0;
 #pragma unroll
       for (int t = 0; t < TS; ++t) sp += ((imask >> t) & 1u) ? zin[t] : z1[t];
-      const int ni = __builtin_popcount(imask);
+      int ni = __builtin_popcount(imask);
+      if constexpr (NPW == 2) { real nr = (real)ni; pl_sum2(sp, nr); ni = (int)nr; }
       real mp = (sp - cap) * rcp_small((float)(ni > 0 ? ni : 1));
       mp = (!eq & (mp < 0.0)) ? 0.0 : mp;
       m = (need & (ni > 0)) ? mp : m;
@@ -376,7 +479,8 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
         }
       }
       imask = im;
-      const float nl = (float)__builtin_popcount(im);
+      float nl = (float)__builtin_popcount(im);
+      if constexpr (NPW == 2) { real nr = (real)nl; pl_sum2(gl, nr); nl = (float)nr; }
       const real d = gl - cap;
       const real big_ = BIGC;
       const bool fin = (fabs(d) <= tol) | (!eq & (m <= 0.0) & (d <= 0.0)) | (guard > ACNQP_GUARD_MAX);
@@ -394,6 +498,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
           lo_l = inw ? fmin(lo_l, zin[t] - ubv[t]) : lo_l;
           hi_l = inw ? fmax(hi_l, zin[t] - lbv[t]) : hi_l;
         }
+        if constexpr (NPW == 2) { real pa, pb; pair_xchg(lo_l, hi_l, pa, pb); lo_l = fmin(lo_l, pa); hi_l = fmax(hi_l, pb); }
         lo = open ? fmax(lo, lo_l) : lo;
         hi = open ? fmin(hi, hi_l) : hi;
       }
@@ -426,8 +531,8 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
     for (int t = 0; t < TS; ++t) {
       zs[t] = -scalar_const(kStartGain) * qv[t];
       if (warm) {
-        const bool ok = act && t < Tm;
-        zs[t] = ok ? A.warm_x[((size_t)b * N + (ok ? lane : 0)) * Tm + (ok ? t : 0)] : 0.0;
+        const bool ok = act && tb + t < Tm;
+        zs[t] = ok ? A.warm_x[((size_t)b * N + (ok ? lane : 0)) * Tm + (ok ? tb + t : 0)] : 0.0;
       }
     }
     project_B(zs, []() {});
@@ -442,8 +547,8 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       for (int r = 0; r < 4; ++r) {
         const int j = M::rowof(g, r);
         const int ja = A.rowabi[j];
-        const bool ok = ja >= 0 && tc < Tm;
-        y2[r] = ok ? A.warm_y[((size_t)b * A.Mg + (ok ? ja : 0)) * Tm + (ok ? tc : 0)] / RS[j] : 0.0;
+        const bool ok = ja >= 0 && tc < TS && tb + tc < Tm;
+        y2[r] = ok ? A.warm_y[((size_t)b * A.Mg + (ok ? ja : 0)) * Tm + (ok ? tb + tc : 0)] / RS[j] : 0.0;
         yv[r] = y2[r];
       }
       rows_to_evse(yv, frag_g, gty);
@@ -583,6 +688,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
         for (int k = 0; k < DV; ++k) fp[k] = (float)f[k];
 #pragma unroll
         for (int j = 0; j < AM + 2; ++j) d[j] = wave_sum<real>(d[j]);
+        pu_sum(d, AM + 2);   // (two waves per problem: the partner's share)
         STAMP(13);   // event: dot products, wave sums
         const real fn = sqrt(d[AM + 1]);
         bool keep = col;
@@ -715,10 +821,12 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
           v2 = fmax(v2, fmax(fabs(gx[r]), fabs(z2[r])));
         }
       }
-      pri = uniform_scalar(wave_max<real>(v0));
-      dua = uniform_scalar(wave_max<real>(v1));
-      const real npri = uniform_scalar(wave_max<real>(v2));
-      const real ndua = fmax(uniform_scalar(wave_max<real>(fmax(v4, v5))), qnorm);
+      real vm[4] = {wave_max<real>(v0), wave_max<real>(v1), wave_max<real>(v2), wave_max<real>(fmax(v4, v5))};
+      pu_max(vm, 4);
+      pri = uniform_scalar(vm[0]);
+      dua = uniform_scalar(vm[1]);
+      const real npri = uniform_scalar(vm[2]);
+      const real ndua = fmax(uniform_scalar(vm[3]), qnorm);
       const real eps_p = A.eps_abs + A.eps_rel * npri;
       const real eps_d = A.eps_abs + A.eps_rel * ndua;
       if (pri <= eps_p && dua <= eps_d) { status = 1; done = true; }
@@ -728,17 +836,27 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
         real dv1[TS], dv2[4];
         {
           vec4 dy;
-          const float4 s2 = *reinterpret_cast<const float4*>(Snap + 3 * 256 + lane * 4);
-          dv2[0] = y2[0] - (real)s2.x; dv2[1] = y2[1] - (real)s2.y; dv2[2] = y2[2] - (real)s2.z; dv2[3] = y2[3] - (real)s2.w;
+          if constexpr (NPW == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dv2[r] = y2[r] - (real)sn2[r];
+          } else {
+            const float4 s2 = *reinterpret_cast<const float4*>(Snap + 3 * 256 + lane * 4);
+            dv2[0] = y2[0] - (real)s2.x; dv2[1] = y2[1] - (real)s2.y; dv2[2] = y2[2] - (real)s2.z; dv2[3] = y2[3] - (real)s2.w;
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) { dy[r] = dv2[r]; w0 = fmax(w0, fabs(dv2[r])); }
           real gtv[TS];
           rows_to_evse(dy, frag_g, gtv);
+          if constexpr (NPW == 2) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            const float4 s1 = *reinterpret_cast<const float4*>(Snap + c * 256 + lane * 4);
-            dv1[4 * c] = y1[4 * c] - (real)s1.x; dv1[4 * c + 1] = y1[4 * c + 1] - (real)s1.y;
-            dv1[4 * c + 2] = y1[4 * c + 2] - (real)s1.z; dv1[4 * c + 3] = y1[4 * c + 3] - (real)s1.w;
+            for (int t = 0; t < TS; ++t) dv1[t] = y1[t] - (real)sn1[t];
+          } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const float4 s1 = *reinterpret_cast<const float4*>(Snap + c * 256 + lane * 4);
+              dv1[4 * c] = y1[4 * c] - (real)s1.x; dv1[4 * c + 1] = y1[4 * c + 1] - (real)s1.y;
+              dv1[4 * c + 2] = y1[4 * c + 2] - (real)s1.z; dv1[4 * c + 3] = y1[4 * c + 3] - (real)s1.w;
+            }
           }
 #pragma unroll
           for (int t = 0; t < TS; ++t) {
@@ -746,8 +864,10 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
             w1 = fmax(w1, fabs(dv1[t] + gtv[t]));
           }
         }
-        const real vn = uniform_scalar(wave_max<real>(w0));
-        const real atv = uniform_scalar(wave_max<real>(w1));
+        real wm[2] = {wave_max<real>(w0), wave_max<real>(w1)};
+        pu_max(wm, 2);
+        const real vn = uniform_scalar(wm[0]);
+        const real atv = uniform_scalar(wm[1]);
         const real vtol = scalar_const(1e-4) * vn;
         if (vn > scalar_const(1e-12) * fmax(1.0, qnorm) && atv <= vtol) {
           real bad = 0, ssum = 0;
@@ -774,36 +894,49 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
 #pragma unroll
             for (int t = 0; t < TS; ++t)
               if ((swm >> t) & 1u) { lmin = fmin(lmin, dv1[t]); lmax = fmax(lmax, dv1[t]); }
+            if constexpr (NPW == 2) { real pa, pb; pair_xchg(lmin, lmax, pa, pb); lmin = fmin(lmin, pa); lmax = fmax(lmax, pb); }
             real lam3[3] = {lmin, lmax, 0.0};
-            real best = BIGC;
+            real ph3[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
               real l_ = lam3[j];
               if (!eq) l_ = fmax(l_, 0.0);
-              real ph = l_ * scap;
+              real ph = half == 0 ? l_ * scap : 0.0;   // (the cap term once per session)
 #pragma unroll
               for (int t = 0; t < TS; ++t)
                 if ((swm >> t) & 1u) {
                   const real dv = dv1[t] - l_;
                   ph += ubv[t] * fmax(dv, 0.0) + lbv[t] * fmin(dv, 0.0);
                 }
-              best = fmin(best, ph);
+              ph3[j] = ph;
             }
-            if (smode != 4) ssum += best;
+            if constexpr (NPW == 2) { real z_ = 0; pl_sum2(ph3[0], ph3[1]); pl_sum2(ph3[2], z_); }
+            const real best = fmin(fmin(ph3[0], ph3[1]), ph3[2]);
+            if (smode != 4 && half == 0) ssum += best;
 #pragma unroll
             for (int t = 0; t < TS; ++t)
               if (!((swm >> t) & 1u)) ssum += lbv[t] * dv1[t];   // periods outside the window are pinned to lb (= ub)
           }
-          const real stot = uniform_scalar(wave_sum<real>(ssum));
-          const real bmax = uniform_scalar(wave_max<real>(bad));
+          real st1[1] = {wave_sum<real>(ssum)}, bm1[1] = {wave_max<real>(bad)};
+          pu_sum(st1, 1);
+          pu_max(bm1, 1);
+          const real stot = uniform_scalar(st1[0]);
+          const real bmax = uniform_scalar(bm1[0]);
           if (bmax == 0.0 && stot < -vtol) { status = 3; done = true; }
         }
       }
       if (!done) {   // snapshot for the next certificate test (single precision, as the twin rounds it)
+        if constexpr (NPW == 2) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
-          *reinterpret_cast<float4*>(Snap + c * 256 + lane * 4) = make_float4((float)y1[4 * c], (float)y1[4 * c + 1], (float)y1[4 * c + 2], (float)y1[4 * c + 3]);
-        *reinterpret_cast<float4*>(Snap + 3 * 256 + lane * 4) = make_float4((float)y2[0], (float)y2[1], (float)y2[2], (float)y2[3]);
+          for (int t = 0; t < TS; ++t) sn1[t] = (float)y1[t];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sn2[r] = (float)y2[r];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            *reinterpret_cast<float4*>(Snap + c * 256 + lane * 4) = make_float4((float)y1[4 * c], (float)y1[4 * c + 1], (float)y1[4 * c + 2], (float)y1[4 * c + 3]);
+          *reinterpret_cast<float4*>(Snap + 3 * 256 + lane * 4) = make_float4((float)y2[0], (float)y2[1], (float)y2[2], (float)y2[3]);
+        }
         have_prev = true;
       }
       const real tiny_ = scalar_const(1e-300);
@@ -823,10 +956,12 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
           const real yr = y2[r], yi = y2[(r + 1) & 3];
           const bool disc = rty[r] == kRowSocRe;
           const real mag = disc ? sqrt(yr * yr + yi * yi) : yr;
-          const bool counts = (disc | (rty[r] == kRowBox) | (rty[r] == kRowPeak)) & (tc < Tm) & (mag > ytol);
+          const bool counts = (disc | (rty[r] == kRowBox) | (rty[r] == kRowPeak)) & (tc < TS) & (tb + tc < Tm) & (mag > ytol);
           cnt += counts ? (disc ? 2.0 : 1.0) : 0.0;
         }
-        cnt = uniform_scalar(wave_sum<real>(cnt));
+        real c1[1] = {wave_sum<real>(cnt)};
+        pu_sum(c1, 1);
+        cnt = uniform_scalar(c1[0]);
         hand_over = cnt + 8.0 <= (real)A.pol_rows;
       }
       if (done) {
@@ -873,8 +1008,8 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
     asm volatile("" : "+v"(lane_o));
 #pragma unroll
     for (int t = 0; t < TS; ++t)
-      if (lane_o < N && t < Tm) {
-        A.x[((size_t)b * N + lane_o) * Tm + t] = z1[t];
+      if (lane_o < N && tb + t < Tm) {
+        A.x[((size_t)b * N + lane_o) * Tm + tb + t] = z1[t];
         ol += (0.5 * pd_user * z1[t] + qv[t]) * z1[t];
       }
     if (A.y_out && (!A.y_for_polish_only || status == kStatusPolish)) {   // site-row multipliers, caller's row order and units
@@ -884,11 +1019,12 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       for (int r = 0; r < 4; ++r) {
         const int j = M::rowof(g_o, r);
         const int ja = A.rowabi[j];
-        if (ja >= 0 && t_o < Tm) A.y_out[((size_t)b * A.Mg + ja) * Tm + t_o] = y2[r] * RS[j];
+        if (ja >= 0 && t_o < TS && tb + t_o < Tm) A.y_out[((size_t)b * A.Mg + ja) * Tm + tb + t_o] = y2[r] * RS[j];
       }
     }
     ol = wave_sum<real>(ol);
-    if (lane == 0) {
+    { real o1[1] = {ol}; pu_sum(o1, 1); ol = o1[0]; }
+    if (lane == 0 && half == 0) {
       A.status[b] = status;
       A.pri[b] = pri;
       A.dua[b] = dua;
@@ -896,7 +1032,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       if (status == kStatusPolish) A.pol_list[atomicAdd(A.pol_count, 1)] = b;
     }
   }
-  if (lane == 0) A.iters[b] = it_total;
+  if (lane == 0 && half == 0) A.iters[b] = it_total;
 #ifdef ACNQP_STAMPS
   {
     unsigned long long st_rt1, st_t1;

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-CASES = ("soc", "linear", "equality", "short", "site30", "peak", "infeasible", "empty_set", "warm", "general_windows", "stalled")
+CASES = ("soc", "linear", "equality", "short", "site30", "peak", "infeasible", "empty_set", "warm", "general_windows", "stalled",
+         "h24", "h18_linear", "h24_equality", "h20_windows", "h24_infeasible", "h24_warm")
 
 
 def build(name):
@@ -63,6 +64,29 @@ def build(name):
     if name == "general_windows":   # delayed arrivals and minimum rates over a prefix: lb != 0, windows that do not start at 0
         snaps = [sites.random_sessions_general(infra, 12, rng, False, min_rates=True) for _ in range(96)]
         return build_batch(snaps, infra, iface, obj, "SOC"), {}, {}
+    # ---- horizons 13 ... 24: two waves per problem, twelve periods each
+    if name == "h24":
+        return build_batch(sites.snapshot_batch(infra, 24, 192, seed=921), infra, iface, obj, "SOC"), {}, {}
+    if name == "h18_linear":   # the second wave holds six live periods
+        return build_batch(sites.snapshot_batch(infra, 18, 128, seed=922, min_rate_fraction=0.3), infra, iface, obj, "LINEAR"), {}, {}
+    if name == "h24_equality":
+        snaps = sites.snapshot_batch(infra, 24, 96, seed=923, demand_range=(0.1, 0.5))
+        return build_batch(snaps, infra, iface, obj, "SOC", True), {}, {}
+    if name == "h20_windows":   # windows that start late / end early, minimum rates over a prefix: sums that cross the halves
+        snaps = [sites.random_sessions_general(infra, 20, rng, False, min_rates=True) for _ in range(96)]
+        return build_batch(snaps, infra, iface, obj, "SOC"), {}, {}
+    if name == "h24_infeasible":
+        from adacharge_amd.sites import SessionInfo
+
+        snaps = []
+        for b in range(96):
+            evses = rng.choice(infra.num_stations, size=int(rng.integers(6, 55)), replace=False)
+            snaps.append([SessionInfo(infra.station_ids[int(e)], f"s{k}", float(rng.uniform(6.0, 12.0)), 0.0, 0, 24, current_time=0,
+                                      min_rates=np.zeros(24), max_rates=32.0) for k, e in enumerate(evses)])
+        return build_batch(snaps, infra, iface, obj, "LINEAR", True), dict(max_iter=30000), {}
+    if name == "h24_warm":
+        b = build_batch(sites.snapshot_batch(infra, 24, 64, seed=924), infra, iface, obj, "SOC")
+        return b, {}, dict(warm="self", want_y=True)
     if name == "stalled":    # the congested fixtures the polish exists for (hand-over at polish_iters, resume behind it)
         from tests import helpers as H
 
