@@ -10,24 +10,26 @@ namespace acnqp {
 // here (4.3 us per iteration) and four waves' in the tiled kernel (3.1 us alone on a CU), so a launch of at most one
 // problem per CU ends later than it did (256 problems: 2.9 against 2.3 ms; one problem: 0.85 against 0.6 ms) -- from two
 // problems per CU on, four problems in flight per CU win (16,384: 26.5 -> 15.5 ms).  ACNQP_WAVE_MIN_BATCH=n (diagnostic)
-// sends launches of fewer than n problems to the tiled kernel.  Returns the waves per problem (0: not this kernel; 1:
-// horizon <= 12; 2: horizon 13 ... 24).
+// sends launches of fewer than n problems to the tiled kernel.  Returns the variant (0: not this kernel; 1: horizon
+// <= 12, one wave per problem; 2: horizon 13 ... 24, two waves; 3: two row tiles at horizon <= 12, two waves of six periods).
 int wave_shape(int N, int t_max, int k_sessions, int MR, bool has_prox, int batch) {
   static const bool off = std::getenv("ACNQP_NO_WAVE") != nullptr;   // diagnostic / A-B: the register-resident tiled kernel instead
-  static const bool off2 = std::getenv("ACNQP_NO_WAVE2") != nullptr; // ... for horizons 13 ... 24 only
+  static const bool off2 = std::getenv("ACNQP_NO_WAVE2") != nullptr; // ... for the two-waves-per-problem variants only
   static const int min_batch = std::getenv("ACNQP_WAVE_MIN_BATCH") ? std::atoi(std::getenv("ACNQP_WAVE_MIN_BATCH")) : 1;
-  if (off || N > 64 || t_max > 2 * kWaveTS || k_sessions != 1 || MR != 16 || has_prox || batch < min_batch) return 0;
-  if (t_max <= kWaveTS) return 1;
-  return off2 ? 0 : 2;   // two waves per problem, twelve periods each
+  if (off || N > 64 || k_sessions != 1 || has_prox || batch < min_batch) return 0;
+  if (MR == 16 && t_max <= kWaveTS) return 1;                   // one wave per problem
+  if (MR == 16 && t_max <= 2 * kWaveTS) return off2 ? 0 : 2;    // two waves, twelve periods each
+  if (MR == 32 && t_max <= kWaveTS) return off2 ? 0 : 3;        // two row tiles: two waves, six periods each
+  return 0;
 }
 
-template <int NPW>
+template <int NPW, int TSV, int MT>
 static hipError_t launch_wave_npw(const TiledArgs& a_in, hipStream_t st) {
   TiledArgs a = a_in;
   a.accel_mem = std::min(a.accel_mem, kWaveAM);
-  const WaveLds L(a.accel_mem, NPW);
+  const WaveLds L(a.accel_mem, NPW, MT, TSV);
   const size_t lds = (size_t)L.total * 8;
-  auto kern = &admm_wave_kernel<kWaveAM, NPW>;
+  auto kern = &admm_wave_kernel<kWaveAM, NPW, TSV, MT>;
   if (lds > 64 * 1024) {
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
@@ -54,7 +56,8 @@ static hipError_t launch_wave_npw(const TiledArgs& a_in, hipStream_t st) {
 }
 
 hipError_t launch_wave(const TiledArgs& a, hipStream_t st) {
-  return a.Tm <= kWaveTS ? launch_wave_npw<1>(a, st) : launch_wave_npw<2>(a, st);
+  if (a.MR == 32) return launch_wave_npw<2, 6, 2>(a, st);
+  return a.Tm <= kWaveTS ? launch_wave_npw<1, 12, 1>(a, st) : launch_wave_npw<2, 12, 1>(a, st);
 }
 
 }  // namespace acnqp

@@ -42,16 +42,18 @@ struct WaveLds {
   int fragp, fragx, fragq, rowc, wave0, wstride;   // offsets in doubles
   int xt, rowd, aah, snap, hist, total;            // per-wave offsets (relative to the wave's region), total in doubles
   int xch;                                         // NPW == 2: the wave's mailbox (two buffers of [2][64] doubles) + its flag
-  __host__ __device__ WaveLds(int accel_mem, int npw = 1) {
+  int xs;                                          // row stride of the transpose scratch (doubles)
+  __host__ __device__ WaveLds(int accel_mem, int npw = 1, int mt = 1, int tsv = kWaveTS) {
     int o = 0;
-    fragp = o; o += 16 * 64;          // Ghat as A operand of P = Ghat r0: [k-step][lane]
-    fragx = o; o += 4 * 4 * 64;       // Ghat as B operand of corr = e^' Ghat: [EVSE tile][k-step][lane]
-    fragq = o; o += 2 * 4 * 64;       // Q' and Q as A operands (the tiled kernel's fragQ)
-    rowc = o;  o += 16 + 16 + 8;      // eigenvalues, limits, row types (ints, lane order)
+    fragp = o; o += mt * 16 * 64;         // Ghat as A operand of P = Ghat r0: [row tile][k-step][lane]
+    fragx = o; o += 4 * 4 * mt * 64;      // Ghat as B operand of corr = e^' Ghat: [EVSE tile][k-step (4 per row tile)][lane]
+    fragq = o; o += mt * mt * 2 * 4 * 64; // Q' and Q as A operands (the tiled kernel's fragQ: [mo][mi][2][4][64])
+    rowc = o;  o += mt * (16 + 16 + 8);   // eigenvalues, limits, row types (ints, lane order)
     wave0 = o;
     int w = 0;
-    xt = w;   w += 64 * kWaveXS;
-    rowd = w; w += 16;                // rho / (a + rho lam)
+    xs = tsv > 8 ? kWaveXS : 9;           // 64 EVSE rows x 16 (8) period columns, odd stride
+    xt = w;   w += 64 * xs;
+    rowd = w; w += 16 * mt;               // rho / (a + rho lam)
     aah = w;  w += kWaveAM * kWaveAM + kWaveAM + 1;
     w = (w + 1) & ~1;
     snap = w; xch = w;
@@ -82,13 +84,15 @@ __device__ inline void wave_lds_sync() {   // this wave's LDS writes are visible
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int AM, int NPW>
+template <int AM, int NPW, int TSV, int MT>
 __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledArgs A_kernarg) {
   static_assert(NPW == 1 || NPW == 2, "one or two waves per problem");
+  static_assert((TSV == 12 && MT == 1) || (TSV == 6 && MT == 2 && NPW == 2), "instantiated: 12 periods x one row tile, 6 periods x two row tiles");
   using M = Mfma<double>;
   using vec4 = typename M::vec4;
   typedef double real;
-  constexpr int TS = kWaveTS, XS = kWaveXS;
+  constexpr int TS = TSV, XS = TSV > 8 ? kWaveXS : 9, XC = TSV > 8 ? 16 : 8;   // period slots, scratch stride, its live columns
+  constexpr int SR = 4 * MT, KS = 4 * MT;                                         // site-row registers per lane, k-steps of corr
 #define BIGC (scalar_const(1e300))
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   real* sm = reinterpret_cast<real*>(smem_raw);
@@ -96,30 +100,33 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   const int lane = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int g = lane >> 4, tc = lane & 15;   // MFMA operand coordinates of the lane
   const int half = NPW == 2 ? (wave & 1) : 0;   // which half of the horizon this wave holds (scalar)
-  const int tb = 12 * half;                     // its first period
+  const int tb = TSV * half;                    // its first period
   int xseq = 0;                                 // mailbox sequence number (the partner counts the same exchanges)
   bool xbroken = false;                         // a wait ran into its bound (never expected): no further waits
 
   // ---- once per workgroup: the site's fragments and row constants -> LDS ------------------------------------------------
   {
-    const WaveLds L0(0, NPW);
+    const WaveLds L0(0, NPW, MT, TSV);
     const int NP = A_kernarg.NP;
     const real* Gh = static_cast<const real*>(A_kernarg.Ghat);
     const real* FQg = static_cast<const real*>(A_kernarg.fragQ);
-    for (int k = tid0; k < 16 * 64; k += kWaveNW * 64) {
-      const int s = k >> 6, l = k & 63, gg = l >> 4, tt = l & 15;
-      sm[L0.fragp + k] = Gh[(size_t)tt * NP + 4 * s + gg];                               // A[i = row tt][k = EVSE 4 s + gg]
-      const int w = s >> 2, s2 = s & 3;
-      sm[L0.fragx + k] = Gh[(size_t)(4 * s2 + gg) * NP + 16 * w + tt];                   // B[k = row 4 s2 + gg][j = EVSE 16 w + tt]
+    for (int k = tid0; k < MT * 16 * 64; k += kWaveNW * 64) {
+      const int m = k >> 10, s = (k >> 6) & 15, l = k & 63, gg = l >> 4, tt = l & 15;
+      sm[L0.fragp + k] = Gh[(size_t)(16 * m + tt) * NP + 4 * s + gg];                    // A[i = row 16 m + tt][k = EVSE 4 s + gg]
     }
-    for (int k = tid0; k < 2 * 4 * 64; k += kWaveNW * 64) sm[L0.fragq + k] = FQg[k];
-    if (tid0 < 16) {
+    for (int k = tid0; k < 4 * KS * 64; k += kWaveNW * 64) {
+      const int ws = k >> 6, l = k & 63, gg = l >> 4, tt = l & 15;
+      const int w = ws / KS, s = ws % KS;
+      sm[L0.fragx + k] = Gh[(size_t)(16 * (s >> 2) + 4 * (s & 3) + gg) * NP + 16 * w + tt];   // B[k = row of k-step s][j = EVSE 16 w + tt]
+    }
+    for (int k = tid0; k < MT * MT * 2 * 4 * 64; k += kWaveNW * 64) sm[L0.fragq + k] = FQg[k];
+    if (tid0 < 16 * MT) {
       sm[L0.rowc + tid0] = static_cast<const real*>(A_kernarg.lam)[tid0];
-      sm[L0.rowc + 16 + tid0] = static_cast<const real*>(A_kernarg.rowlim)[tid0];
-      const int g_ = tid0 >> 2, r_ = tid0 & 3;
-      reinterpret_cast<int*>(sm + L0.rowc + 32)[tid0] = A_kernarg.rowtype[M::rowof(g_, r_)];
+      sm[L0.rowc + 16 * MT + tid0] = static_cast<const real*>(A_kernarg.rowlim)[tid0];
+      const int m_ = tid0 >> 4, g_ = (tid0 >> 2) & 3, r_ = tid0 & 3;
+      reinterpret_cast<int*>(sm + L0.rowc + 32 * MT)[tid0] = A_kernarg.rowtype[16 * m_ + M::rowof(g_, r_)];
     }
-    const WaveLds L1(min(A_kernarg.accel_mem, AM), NPW);
+    const WaveLds L1(min(A_kernarg.accel_mem, AM), NPW, MT, TSV);
     real* XT0 = sm + L1.wave0 + (size_t)wave * L1.wstride;
     for (int k = lane; k < 64 * XS; k += 64) XT0[k] = 0;   // the pad columns (periods 12 ... 15) stay zero for good
     if (NPW == 2 && lane < 2) reinterpret_cast<int*>(XT0 + L1.xch + 2 * 2 * 64)[lane] = 0;   // the mailbox flag
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   real* Xm = nullptr;
   const real* Xp = nullptr;
   if constexpr (NPW == 2) {
-    const WaveLds Lx(min(A_kernarg.accel_mem, AM), NPW);
+    const WaveLds Lx(min(A_kernarg.accel_mem, AM), NPW, MT, TSV);
     Xm = sm + Lx.wave0 + (size_t)wave * Lx.wstride + Lx.xch;
     Xp = sm + Lx.wave0 + (size_t)(wave ^ 1) * Lx.wstride + Lx.xch;
   }
@@ -144,16 +151,18 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       const int o = (xseq & 1) * 128;
       Xm[o + lane] = va;
       Xm[o + 64 + lane] = vb;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      // (LDS is one memory per CU and a wave's LDS operations complete in order: the compiler must keep the order -- the
+      //  wavefront-scope fences -- and the hardware needs no wait between the values and the flag)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       if (lane == 0) *reinterpret_cast<volatile int*>(Xm + 256) = xseq;
       if (!xbroken) {
         int spins = 0;
         while (*reinterpret_cast<const volatile int*>(Xp + 256) - xseq < 0) {
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > (1 << 22)) { xbroken = true; break; }
+          if (++spins > 64) __builtin_amdgcn_s_sleep(1);   // the partner is usually a few hundred cycles away: poll first
+          if (spins > (1 << 22)) { xbroken = true; break; }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       pa = Xp[o + lane];
       pb = Xp[o + 64 + lane];
     } else {
@@ -222,13 +231,13 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   const int adapt_p = pass == 0 ? A.adapt_every : 0;
   const int N = A.N, Tm = A.Tm;
   const int aa_m = min(A.accel_mem, AM);
-  const WaveLds L(aa_m, NPW);
+  const WaveLds L(aa_m, NPW, MT, TSV);
   const real* FragP = sm + L.fragp;
   const real* FragX = sm + L.fragx;
   const real* FQs = sm + L.fragq;
   const real* RowLam = sm + L.rowc;
-  const real* RowLim = RowLam + 16;
-  const int* RowTy = reinterpret_cast<const int*>(RowLam + 32);
+  const real* RowLim = RowLam + 16 * MT;
+  const int* RowTy = reinterpret_cast<const int*>(RowLam + 32 * MT);
   real* Wv = sm + L.wave0 + (size_t)wave * L.wstride;
   real* XT = Wv + L.xt;
   real* RowDj = Wv + L.rowd;
@@ -236,56 +245,68 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   float* Snap = reinterpret_cast<float*>(Wv + L.snap);   // [chunk][lane][4]: chunks 0..2 = y1 of the lane's EVSE, chunk 3 = y2 (C layout)
   float* HistF = reinterpret_cast<float*>(Wv + L.hist);  // dF ring: [slot][chunk][lane][4]
   const real* Gm = static_cast<const real*>(A.G);
-  auto row_types = [&](int (&ty)[4]) __attribute__((always_inline)) {
-    const int4 v = *reinterpret_cast<const int4*>(RowTy + g * 4);
+  auto row_types = [&](int m, int (&ty)[4]) __attribute__((always_inline)) {
+    const int4 v = *reinterpret_cast<const int4*>(RowTy + (m * 4 + g) * 4);
     ty[0] = v.x; ty[1] = v.y; ty[2] = v.z; ty[3] = v.w;
   };
 
   // ---- layout changes through the wave's scratch -----------------------------------------------------------------------
   // EVSE layout (lane = EVSE, register = period) -> C-layout tile (rows x periods) of Amat v, Amat given as A fragments
-  auto evse_to_rows = [&](const real (&v)[TS], const real* frag) __attribute__((always_inline)) -> vec4 {
+  auto evse_to_rows = [&](const real (&v)[TS], const real* frag, vec4 (&out)[MT]) __attribute__((always_inline)) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int t = 0; t < TS; ++t) XT[lane * XS + t] = v[t];
     wave_lds_sync();
     // every operand requested before the first MFMA (no branch in the chain: EVSEs beyond N hold zeros); two
-    // accumulators, so that a product does not wait for the previous one's result
-    real bop[16], aop[16];
+    // accumulators per row tile, so that a product does not wait for the previous one's result
+    real bop[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) { bop[s] = XT[(4 * s + g) * XS + tc]; aop[s] = frag[s * 64 + lane]; }
-    vec4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-#pragma unroll
-    for (int s = 0; s < 16; s += 2) {
-      acc0 = M::mma(aop[s], bop[s], acc0);
-      acc1 = M::mma(aop[s + 1], bop[s + 1], acc1);
+    for (int s = 0; s < 16; ++s) {
+      if constexpr (XC == 16) bop[s] = XT[(4 * s + g) * XS + tc];
+      else bop[s] = tc < XC ? XT[(4 * s + g) * XS + (tc < XC ? tc : 0)] : 0.0;   // (the scratch holds 8 period columns)
     }
-    return acc0 + acc1;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      real aop[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) aop[s] = frag[(m * 16 + s) * 64 + lane];
+      vec4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < 16; s += 2) {
+        acc0 = M::mma(aop[s], bop[s], acc0);
+        acc1 = M::mma(aop[s + 1], bop[s + 1], acc1);
+      }
+      out[m] = acc0 + acc1;
+    }
   };
-  // C-layout tile c4 (rows x periods) -> EVSE layout of Bmat' c4, Bmat (rows x EVSEs) given by bfrag(tile, k-step)
-  auto rows_to_evse = [&](const vec4& c4, auto&& bfrag, real (&out)[TS]) __attribute__((always_inline)) {
-    real bf[4][4];
+  // C-layout tiles c4 (rows x periods) -> EVSE layout of Bmat' c4, Bmat (rows x EVSEs) given by bfrag(tile, k-step)
+  auto rows_to_evse = [&](const vec4 (&c4)[MT], auto&& bfrag, real (&out)[TS]) __attribute__((always_inline)) {
+    real bf[4][KS];
 #pragma unroll
     for (int w = 0; w < 4; ++w)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) bf[w][s] = bfrag(w, s);
+      for (int s = 0; s < KS; ++s) bf[w][s] = bfrag(w, s);
     vec4 acc[4];
 #pragma unroll
     for (int w = 0; w < 4; ++w) acc[w] = vec4{0, 0, 0, 0};
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
-      for (int w = 0; w < 4; ++w) acc[w] = M::mma(c4[s], bf[w][s], acc[w]);   // (four independent chains, interleaved)
+      for (int w = 0; w < 4; ++w) acc[w] = M::mma(c4[s >> 2][s & 3], bf[w][s], acc[w]);   // (four independent chains, interleaved)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int w = 0; w < 4; ++w)
 #pragma unroll
-      for (int r = 0; r < 3; ++r) XT[(16 * w + tc) * XS + g + 4 * r] = acc[w][r];   // (period g + 4 r of EVSE 16 w + tc)
+      for (int r = 0; r < 3; ++r) {   // (period g + 4 r of EVSE 16 w + tc)
+        if constexpr (TS >= 12) XT[(16 * w + tc) * XS + g + 4 * r] = acc[w][r];
+        else if (4 * r < TS) { if (g + 4 * r < TS) XT[(16 * w + tc) * XS + g + 4 * r] = acc[w][r]; }
+      }
     wave_lds_sync();
 #pragma unroll
     for (int t = 0; t < TS; ++t) out[t] = XT[lane * XS + t];
   };
-  auto frag_ghat = [&](int w, int s) __attribute__((always_inline)) -> real { return FragX[(w * 4 + s) * 64 + lane]; };
-  auto frag_g = [&](int w, int s) __attribute__((always_inline)) -> real { return Gm[(size_t)(4 * s + g) * A.NP + 16 * w + tc]; };
+  auto frag_ghat = [&](int w, int s) __attribute__((always_inline)) -> real { return FragX[(w * KS + s) * 64 + lane]; };
+  auto frag_g = [&](int w, int s) __attribute__((always_inline)) -> real { return Gm[(size_t)(16 * (s >> 2) + 4 * (s & 3) + g) * A.NP + 16 * w + tc]; };
 
   // ---- problem data -> registers (EVSE layout) ------------------------------------------------------------------------
   const bool act = lane < N;
@@ -369,14 +390,14 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   }
 
   // site-row state (C layout: lane (g, tc), register r <-> row g + 4 r, period tc)
-  real z2[4], y2[4], gx[4];
+  real z2[SR], y2[SR], gx[SR];   // (register 4 m + r <-> row 16 m + g + 4 r)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { z2[r] = 0; y2[r] = 0; gx[r] = 0; }
+  for (int r = 0; r < SR; ++r) { z2[r] = 0; y2[r] = 0; gx[r] = 0; }
 
   rho = uniform_scalar(rho);
   real a = sigma + pd + rho, inv_a = uniform_scalar(1.0 / a), inv_rho = uniform_scalar(1.0 / rho);
   __builtin_amdgcn_wave_barrier();
-  if (lane < 16) RowDj[lane] = rho / (a + rho * RowLam[lane]);
+  if (lane < 16 * MT) RowDj[lane] = rho / (a + rho * RowLam[lane]);
   wave_lds_sync();
 
   int status = 2, it = 0, n_adapt = 0, best_it = 0;
@@ -386,14 +407,15 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   real best_score = BIGC;
   real pri = BIGC, dua = BIGC;
   bool done = false, have_prev = false;
-  float sn1[TS], sn2[4];   // NPW == 2: the certificate's dual snapshot (one wave per problem keeps it in LDS: Snap)
+  float sn1[TS], sn2[SR];   // NPW == 2: the certificate's dual snapshot (one wave per problem keeps it in LDS: Snap)
 #pragma unroll
   for (int t = 0; t < TS; ++t) sn1[t] = 0.f;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) sn2[r] = 0.f;
+  for (int r = 0; r < SR; ++r) sn2[r] = 0.f;
 
   // ---- Anderson acceleration state (wave-uniform scalars; vectors: EVSE layout [0, TS) then the site tile [TS, TS + 4)) ----
-  constexpr int DV = TS + 4;
+  constexpr int DV = TS + SR, DVP = 16;   // the Anderson state per lane; its ring row padded to four float4 chunks
+  static_assert(DV <= DVP, "ring row");
   real up[DV];
   float fp[DV], cp[DV];
   float hg[AM][DV];   // dG ring (registers)
@@ -542,14 +564,14 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
     for (int t = 0; t < TS; ++t) gty[t] = 0;
     if (warm) {
       const real* RS = static_cast<const real*>(A.rowscale);
-      vec4 yv;
+      vec4 yv[MT];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = M::rowof(g, r);
+      for (int r = 0; r < SR; ++r) {
+        const int j = 16 * (r >> 2) + M::rowof(g, r & 3);
         const int ja = A.rowabi[j];
         const bool ok = ja >= 0 && tc < TS && tb + tc < Tm;
         y2[r] = ok ? A.warm_y[((size_t)b * A.Mg + (ok ? ja : 0)) * Tm + (ok ? tb + tc : 0)] / RS[j] : 0.0;
-        yv[r] = y2[r];
+        yv[r >> 2][r & 3] = y2[r];
       }
       rows_to_evse(yv, frag_g, gty);
     }
@@ -560,16 +582,23 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       up[t] = z1[t] + y1[t] * inv_rho;
       cp[t] = 0.f;
     }
-    const vec4 g0 = evse_to_rows(z1, FragP);
-    vec4 zt = {0, 0, 0, 0};
+    vec4 g0[MT];
+    evse_to_rows(z1, FragP, g0);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) zt = M::mma(FQs[(1 * 4 + s) * 64 + lane], g0[s], zt);
+    for (int mo = 0; mo < MT; ++mo) {
+      vec4 zt = {0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      z2[r] = zt[r]; gx[r] = zt[r];
-      if (!warm) y2[r] = 0;
-      up[TS + r] = zt[r] + y2[r] * inv_rho;
-      cp[TS + r] = 0.f;
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) zt = M::mma(FQs[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane], g0[mi][s], zt);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 4 * mo + r;
+        z2[k] = zt[r]; gx[k] = zt[r];
+        if (!warm) y2[k] = 0;
+        up[TS + k] = zt[r] + y2[k] * inv_rho;
+        cp[TS + k] = 0.f;
+      }
     }
   }
 
@@ -588,31 +617,47 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
     real r0[TS];
 #pragma unroll
     for (int t = 0; t < TS; ++t) r0[t] = sigma * x[t] - qv[t] + rho * z1[t] - y1[t];
-    vec4 wh = {0, 0, 0, 0};
+    vec4 wh[MT];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wh = M::mma(FQs[(0 * 4 + s) * 64 + lane], rho * z2[s] - y2[s], wh);
+    for (int mo = 0; mo < MT; ++mo) {
+      vec4 acc = {0, 0, 0, 0};
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = M::mma(FQs[(((mo * MT + mi) * 2 + 0) * 4 + s) * 64 + lane], rho * z2[4 * mi + s] - y2[4 * mi + s], acc);
+      wh[mo] = acc;
+    }
     STAMP(0);   // r0, w^ (4 MFMA)
-    const vec4 g0 = evse_to_rows(r0, FragP);
+    vec4 g0[MT];
+    evse_to_rows(r0, FragP, g0);
     STAMP(1);   // EVSE -> rows: 12 writes, 32 reads, 16 MFMA
     // ---- e^ = w^ - D (g0 + Lam w^);  h^ = (g0 + Lam e^)/a -----------------------------------------------------------------
-    vec4 eh, hh;
+    vec4 eh[MT], hh[MT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const real w_ = wh[r];
-      const real lam_ = RowLam[M::rowof(g, r)];
-      const real e_ = w_ - RowDj[M::rowof(g, r)] * (g0[r] + lam_ * w_);
-      eh[r] = e_;
-      hh[r] = (g0[r] + lam_ * e_) * inv_a;
-    }
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const real w_ = wh[m][r];
+        const real lam_ = RowLam[16 * m + M::rowof(g, r)];
+        const real e_ = w_ - RowDj[16 * m + M::rowof(g, r)] * (g0[m][r] + lam_ * w_);
+        eh[m][r] = e_;
+        hh[m][r] = (g0[m][r] + lam_ * e_) * inv_a;
+      }
     // ---- G x~ = Q h^ and the pre-projection point of the site rows (issued first: its VALU work overlaps the x~ MFMAs) ----
-    vec4 zt = {0, 0, 0, 0};
+    real zhr[SR];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) zt = M::mma(FQs[(1 * 4 + s) * 64 + lane], hh[s], zt);
-    real zhr[4];
+    for (int mo = 0; mo < MT; ++mo) {
+      vec4 zt = {0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      gx[r] = alpha * zt[r] + (1.0 - alpha) * gx[r];
-      zhr[r] = alpha * zt[r] + (1.0 - alpha) * z2[r] + y2[r] * inv_rho;
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) zt = M::mma(FQs[(((mo * MT + mi) * 2 + 1) * 4 + s) * 64 + lane], hh[mi][s], zt);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 4 * mo + r;
+        gx[k] = alpha * zt[r] + (1.0 - alpha) * gx[k];
+        zhr[k] = alpha * zt[r] + (1.0 - alpha) * z2[k] + y2[k] * inv_rho;
+      }
     }
     STAMP(2);   // e^, h^, Q h^ (4 MFMA), zhr
     // ---- x~ = (r0 + Ghat' e^)/a, relaxation -------------------------------------------------------------------------------
@@ -640,7 +685,9 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
         const bool col = aa_have_prev;
         const int slot = aa_head;
         real f[DV];
-        float cq[DV];
+        float cq[DVP];
+#pragma unroll
+        for (int k = DV; k < DVP; ++k) cq[k] = 0.f;
         real d[AM + 2];
         {
           real fa = 0;
@@ -767,31 +814,34 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
     STAMP(4);   // Anderson event (amortised)
     project_B(zh, [&]() __attribute__((always_inline)) {
       // ---- site rows: projection of zhr onto C, y2 (branch-free over the row types, as acn_qp_tiled.hpp) ----------------
-      int rty[4];
-      row_types(rty);
-      real scl[2], lim4[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { lim4[r] = RowLim[M::rowof(g, r)]; asm volatile("" : "+v"(lim4[r])); }
+      for (int m = 0; m < MT; ++m) {
+        int rty[4];
+        row_types(m, rty);
+        real scl[2], lim4[4];
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const real re = zhr[2 * pr], im = zhr[2 * pr + 1], lim = lim4[2 * pr];
-        const real n2 = re * re + im * im;
-        const bool clip = rty[2 * pr] == kRowSocRe && n2 > lim * lim;
-        const real n2s = clip ? n2 : 1.0;
-        const real f = lim * rsqrt_nr(n2s);
-        scl[pr] = clip ? f : 1.0;
-      }
-      const real big_s = BIGC;
+        for (int r = 0; r < 4; ++r) { lim4[r] = RowLim[16 * m + M::rowof(g, r)]; asm volatile("" : "+v"(lim4[r])); }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const real zh_ = zhr[r];
-        const int ty = rty[r];
-        const real fac = ((ty == kRowSocRe) | (ty == kRowSocIm)) ? scl[r >> 1] : 1.0;
-        real cap_ = ty == kRowBox ? lim4[r] : big_s;
-        cap_ = ty == kRowPeak ? pk_lane : cap_;
-        const real zn = fmin(zh_ * fac, cap_);
-        y2[r] = rho * (zh_ - zn);
-        z2[r] = zn;
+        for (int pr = 0; pr < 2; ++pr) {
+          const real re = zhr[4 * m + 2 * pr], im = zhr[4 * m + 2 * pr + 1], lim = lim4[2 * pr];
+          const real n2 = re * re + im * im;
+          const bool clip = rty[2 * pr] == kRowSocRe && n2 > lim * lim;
+          const real n2s = clip ? n2 : 1.0;
+          const real f = lim * rsqrt_nr(n2s);
+          scl[pr] = clip ? f : 1.0;
+        }
+        const real big_s = BIGC;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const real zh_ = zhr[4 * m + r];
+          const int ty = rty[r];
+          const real fac = ((ty == kRowSocRe) | (ty == kRowSocIm)) ? scl[r >> 1] : 1.0;
+          real cap_ = ty == kRowBox ? lim4[r] : big_s;
+          cap_ = ty == kRowPeak ? pk_lane : cap_;
+          const real zn = fmin(zh_ * fac, cap_);
+          y2[4 * m + r] = rho * (zh_ - zn);
+          z2[4 * m + r] = zn;
+        }
       }
     });
 #pragma unroll
@@ -803,9 +853,9 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       real v0 = 0, v1 = 0, v2 = 0, v4 = 0, v5 = 0;
       {
         real gty[TS];
-        vec4 yv;
+        vec4 yv[MT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) yv[r] = y2[r];
+        for (int r = 0; r < SR; ++r) yv[r >> 2][r & 3] = y2[r];
         rows_to_evse(yv, frag_g, gty);
 #pragma unroll
         for (int t = 0; t < TS; ++t) {
@@ -816,7 +866,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
           v5 = fmax(v5, fabs(y1[t] + gty[t]));
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < SR; ++r) {
           v0 = fmax(v0, fabs(gx[r] - z2[r]));
           v2 = fmax(v2, fmax(fabs(gx[r]), fabs(z2[r])));
         }
@@ -833,18 +883,18 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       if (!done && have_prev) {
         // ---- primal infeasibility certificate (acn_qp_tiled.hpp / oracle/admm_port.c) ----------------------------------
         real w0 = 0, w1 = 0;
-        real dv1[TS], dv2[4];
+        real dv1[TS], dv2[SR];
         {
-          vec4 dy;
+          vec4 dy[MT];
           if constexpr (NPW == 2) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dv2[r] = y2[r] - (real)sn2[r];
+            for (int r = 0; r < SR; ++r) dv2[r] = y2[r] - (real)sn2[r];
           } else {
             const float4 s2 = *reinterpret_cast<const float4*>(Snap + 3 * 256 + lane * 4);
             dv2[0] = y2[0] - (real)s2.x; dv2[1] = y2[1] - (real)s2.y; dv2[2] = y2[2] - (real)s2.z; dv2[3] = y2[3] - (real)s2.w;
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { dy[r] = dv2[r]; w0 = fmax(w0, fabs(dv2[r])); }
+          for (int r = 0; r < SR; ++r) { dy[r >> 2][r & 3] = dv2[r]; w0 = fmax(w0, fabs(dv2[r])); }
           real gtv[TS];
           rows_to_evse(dy, frag_g, gtv);
           if constexpr (NPW == 2) {
@@ -871,20 +921,21 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
         const real vtol = scalar_const(1e-4) * vn;
         if (vn > scalar_const(1e-12) * fmax(1.0, qnorm) && atv <= vtol) {
           real bad = 0, ssum = 0;
-          {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
             int rty[4];
-            row_types(rty);
+            row_types(m, rty);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const real v2_ = dv2[r];
+              const real v2_ = dv2[4 * m + r];
               const int ty = rty[r];
-              if (ty == kRowBox) { ssum += RowLim[M::rowof(g, r)] * fmax(v2_, 0.0); if (v2_ < -vtol) bad = 1; }
+              if (ty == kRowBox) { ssum += RowLim[16 * m + M::rowof(g, r)] * fmax(v2_, 0.0); if (v2_ < -vtol) bad = 1; }
               else if (ty == kRowPeak) {
                 if (pk_lane < BIGC) ssum += pk_lane * fmax(v2_, 0.0); else if (v2_ > vtol) bad = 1;
                 if (v2_ < -vtol) bad = 1;
               } else if (ty == kRowSocRe) {
-                const real vi = dv2[(r + 1) & 3];
-                ssum += RowLim[M::rowof(g, r)] * sqrt(v2_ * v2_ + vi * vi);
+                const real vi = dv2[4 * m + ((r + 1) & 3)];
+                ssum += RowLim[16 * m + M::rowof(g, r)] * sqrt(v2_ * v2_ + vi * vi);
               } else if (ty == kRowSocIm) {
               } else if (fabs(v2_) > vtol) bad = 1;   // free rows admit no ray
             }
@@ -930,7 +981,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
 #pragma unroll
           for (int t = 0; t < TS; ++t) sn1[t] = (float)y1[t];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sn2[r] = (float)y2[r];
+          for (int r = 0; r < SR; ++r) sn2[r] = (float)y2[r];
         } else {
 #pragma unroll
           for (int c = 0; c < 3; ++c)
@@ -949,15 +1000,18 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
         // rows the polish's Schur system would have: one per tight box / peak row, two per tight disc
         real cnt = 0;
         const real ytol = scalar_const(1e-9) * fmax(1.0, qnorm);
-        int rty[4];
-        row_types(rty);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const real yr = y2[r], yi = y2[(r + 1) & 3];
-          const bool disc = rty[r] == kRowSocRe;
-          const real mag = disc ? sqrt(yr * yr + yi * yi) : yr;
-          const bool counts = (disc | (rty[r] == kRowBox) | (rty[r] == kRowPeak)) & (tc < TS) & (tb + tc < Tm) & (mag > ytol);
-          cnt += counts ? (disc ? 2.0 : 1.0) : 0.0;
+        for (int m = 0; m < MT; ++m) {
+          int rty[4];
+          row_types(m, rty);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const real yr = y2[4 * m + r], yi = y2[4 * m + ((r + 1) & 3)];
+            const bool disc = rty[r] == kRowSocRe;
+            const real mag = disc ? sqrt(yr * yr + yi * yi) : yr;
+            const bool counts = (disc | (rty[r] == kRowBox) | (rty[r] == kRowPeak)) & (tc < TS) & (tb + tc < Tm) & (mag > ytol);
+            cnt += counts ? (disc ? 2.0 : 1.0) : 0.0;
+          }
         }
         real c1[1] = {wave_sum<real>(cnt)};
         pu_sum(c1, 1);
@@ -984,14 +1038,14 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
           inv_a = uniform_scalar(1.0 / a);
           inv_rho = uniform_scalar(1.0 / rho);
           __builtin_amdgcn_wave_barrier();
-          if (lane < 16) RowDj[lane] = rho / (a + rho * RowLam[lane]);
+          if (lane < 16 * MT) RowDj[lane] = rho / (a + rho * RowLam[lane]);
           if (aa_m > 0) {   // the fixed-point map changed: restart the ring from the current (z, y)
             aa_cnt = 0; aa_head = 0; aa_valid = 0; aa_have_prev = false; aa_was = false;
             for (int k = lane; k < AM * AM + AM; k += 64) AaH[k] = 0;
 #pragma unroll
             for (int t = 0; t < TS; ++t) { up[t] = z1[t] + y1[t] / rho; cp[t] = 0.f; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { up[TS + r] = z2[r] + y2[r] / rho; cp[TS + r] = 0.f; }
+            for (int r = 0; r < SR; ++r) { up[TS + r] = z2[r] + y2[r] / rho; cp[TS + r] = 0.f; }
           }
           wave_lds_sync();
         }
@@ -1016,8 +1070,8 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       const real* RS = static_cast<const real*>(A.rowscale);
       const int g_o = lane_o >> 4, t_o = lane_o & 15;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = M::rowof(g_o, r);
+      for (int r = 0; r < SR; ++r) {
+        const int j = 16 * (r >> 2) + M::rowof(g_o, r & 3);
         const int ja = A.rowabi[j];
         if (ja >= 0 && t_o < TS && tb + t_o < Tm) A.y_out[((size_t)b * A.Mg + ja) * Tm + tb + t_o] = y2[r] * RS[j];
       }

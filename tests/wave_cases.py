@@ -13,7 +13,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CASES = ("soc", "linear", "equality", "short", "site30", "peak", "infeasible", "empty_set", "warm", "general_windows", "stalled",
-         "h24", "h18_linear", "h24_equality", "h20_windows", "h24_infeasible", "h24_warm")
+         "h24", "h18_linear", "h24_equality", "h20_windows", "h24_infeasible", "h24_warm",
+         "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_warm", "mt2_infeasible")
 
 
 def build(name):
@@ -87,6 +88,29 @@ def build(name):
     if name == "h24_warm":
         b = build_batch(sites.snapshot_batch(infra, 24, 64, seed=924), infra, iface, obj, "SOC")
         return b, {}, dict(warm="self", want_y=True)
+    # ---- two row tiles (17 ... 32 site rows) at horizon <= 12: two waves per problem, six periods each
+    if name.startswith("mt2_"):
+        k = 7 if name == "mt2_site64" else 3          # eight_sites: 36 EVSEs / 18 rows, 64 EVSEs / 20 rows
+        infra2 = sites.eight_sites()[k]
+        iface2 = Interface({"infrastructure_info": infra2, "period": 5})
+        if name in ("mt2_site36", "mt2_site64"):
+            return build_batch(sites.snapshot_batch(infra2, 12, 128, seed=931 + k), infra2, iface2, obj, "SOC"), {}, {}
+        if name == "mt2_short":      # horizon 7: the second wave holds one live period; minimum rates
+            return build_batch(sites.snapshot_batch(infra2, 7, 96, seed=933, min_rate_fraction=0.1), infra2, iface2, obj, "SOC"), {}, {}
+        if name == "mt2_equality":
+            snaps = sites.snapshot_batch(infra2, 12, 96, seed=934, demand_range=(0.05, 0.25))
+            return build_batch(snaps, infra2, iface2, obj, "SOC", True), {}, {}
+        if name == "mt2_warm":
+            return build_batch(sites.snapshot_batch(infra2, 12, 64, seed=935), infra2, iface2, obj, "SOC"), {}, dict(warm="self", want_y=True)
+        if name == "mt2_infeasible":
+            from adacharge_amd.sites import SessionInfo
+
+            snaps = []
+            for b in range(96):
+                evses = rng.choice(infra2.num_stations, size=int(rng.integers(2, 24)), replace=False)
+                snaps.append([SessionInfo(infra2.station_ids[int(e)], f"s{j}", float(rng.uniform(3.0, 6.0)), 0.0, 0, 12, current_time=0,
+                                          min_rates=np.zeros(12), max_rates=32.0) for j, e in enumerate(evses)])
+            return build_batch(snaps, infra2, iface2, obj, "SOC", True), dict(max_iter=30000), {}
     if name == "stalled":    # the congested fixtures the polish exists for (hand-over at polish_iters, resume behind it)
         from tests import helpers as H
 

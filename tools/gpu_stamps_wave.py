@@ -11,8 +11,14 @@ from tests import helpers as H
 infra, iface = H.caltech_interface()
 obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
 names = ["r0 + w^ (4 mfma)", "EVSE->rows 16 mfma", "e^ h^ Qh^ (4 mfma)", "rows->EVSE 16 mfma", "anderson event", "site projection", "water-filling + y1", "check", "(passes x1000)"]
+SITE = os.environ.get("STAMP_SITE")   # e.g. 3: eight_sites()[3] (two row tiles: the two-waves-per-problem variant)
+T = int(os.environ.get("STAMP_T", "12"))
+if SITE is not None:
+    from adacharge_amd.acn import Interface
+    infra = sites.eight_sites()[int(SITE)]
+    iface = Interface({"infrastructure_info": infra, "period": 5})
 for NB in [int(a) for a in sys.argv[1:]] or [256]:
-    snaps = sites.snapshot_batch(infra, 12, NB, seed=20240)
+    snaps = sites.snapshot_batch(infra, T, NB, seed=20240)
     batch = build_batch(snaps, infra, iface, obj, "SOC")
     h = SiteHandle(batch.site, 0)
     res = h.solve(batch, default_options(polish_iters=0))
