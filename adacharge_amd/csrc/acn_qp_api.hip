@@ -612,7 +612,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     for (auto& sl : h->slot) own = own || sl.st == st;
     a.grid_oversub = own ? 4 : 1;
   }
-  a.polish_iters = 0; a.resume = 0; a.y_for_polish_only = 0; a.pol_rows = 0; a.pol_list = nullptr; a.pol_count = nullptr; a.count_dev = nullptr;
+  a.polish_iters = 0; a.polish_stall = 0; a.resume = 0; a.y_for_polish_only = 0; a.pol_rows = 0; a.pol_list = nullptr; a.pol_count = nullptr; a.count_dev = nullptr;
   (void)hipGetLastError();   // drop any stale error so the checks below report this launch only
   // a problem whose workgroup never ran must not look solved (or carry the previous call's status)
   HIP_TRY(hipMemsetAsync(r->status, 0, (size_t)p->batch * sizeof(int32_t), st));
@@ -749,6 +749,10 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     a1.polish_iters = o->polish_iters - o->polish_iters % std::max(1, o->check_every);   // the exit is taken at a residual check
     if (a1.polish_iters < o->check_every) a1.polish_iters = o->check_every;
     a1.pol_list = list; a1.pol_count = ctr + 2; a1.y_out = ybuf; a1.pol_rows = pol_max;
+    // (measured, wave kernel: the early hand-over takes 5 % off the headline launch and 23 % off configs[3] site 0, and hands
+    //  ten times as many problems to the polish -- one 256-batch per call 81 -> 62 k QP/s, the table path 654 -> 580 k: off)
+    static const bool early = std::getenv("ACNQP_EARLY_HANDOVER") != nullptr;   // diagnostic
+    a1.polish_stall = early ? std::max(o->check_every, a1.polish_iters / 4) : 0;
     a1.y_for_polish_only = r->y ? 0 : 1;
     e = launch_solver(a1);
     if (e == hipSuccess) {

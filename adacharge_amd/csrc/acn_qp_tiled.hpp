@@ -100,6 +100,8 @@ struct TiledArgs {
   //    `resume` = 1 is the launch that follows the polish kernel: it runs over pol_list (order = pol_list, count_dev = its
   //    length, on the device), skips what the polish solved and solves the rest from scratch as if there were no polish
   int polish_iters, resume;
+  int polish_stall;           // > 0: from polish_iters / 2 on, a problem whose residual score has not improved by 10 % for this many
+                              // iterations is handed over early (acn_qp_wave.hpp; acn_qp_api.hip sets polish_iters / 4)
   int y_for_polish_only;      // 1: y_out is the polish's internal buffer -- only a problem that is handed over writes it (the
                               // multipliers of every problem were 5.4 KB of HBM writes per problem for 1.5 KB of payload)
   int pol_rows;               // rows of the polish kernel's Schur system for this shape: a problem whose iterate has more tight site

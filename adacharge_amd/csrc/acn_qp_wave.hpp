@@ -996,7 +996,10 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       const bool inacc = inaccurate_ok<real>(pri, dua, npri, ndua, A.eps_abs, A.eps_rel, A.inacc_floor);
       const bool stalled = A.stall_iters > 0 && it - best_it >= A.stall_iters && score <= scalar_const(kStallNear) * best_score;
       bool hand_over = false;
-      if (!done && pass == 0 && A.polish_iters > 0 && it >= A.polish_iters) {
+      // hand-over to the polish: after polish_iters iterations -- or (polish_stall > 0: ACNQP_EARLY_HANDOVER=1, off by default)
+      // from half of them on once the residual score has not improved by 10 % for polish_stall iterations
+      const bool pol_due = A.polish_iters > 0 && (it >= A.polish_iters || (A.polish_stall > 0 && 2 * it >= A.polish_iters && it - best_it >= A.polish_stall));
+      if (!done && pass == 0 && pol_due) {
         // rows the polish's Schur system would have: one per tight box / peak row, two per tight disc
         real cnt = 0;
         const real ytol = scalar_const(1e-9) * fmax(1.0, qnorm);
