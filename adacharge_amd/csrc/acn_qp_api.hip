@@ -629,7 +629,9 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   // across the whole chip: a slot that ends early leaves its bandwidth to the others, and the static schedule measured
   // the same or better (configs[4] leg 432 vs 434-438 ms, 54 x 144 x 2,048 237-243 vs 247-248 ms; gpurun_out/r4c):
   // they keep one workgroup per problem.
-  const bool on_chip = tiled_shape(h, p->t_max, p->k_sessions) || (long_shape(h, p->t_max, p->k_sessions) && lds_long_shape(h, p->t_max));
+  // the wave-per-problem kernel's variant for this shape (0: another kernel family; acn_qp_wave.hip)
+  const int wv = acnqp::wave_shape(h->N, p->t_max, p->k_sessions, d->MR, h->has_flat || h->has_max, p->batch);
+  const bool on_chip = wv > 0 || tiled_shape(h, p->t_max, p->k_sessions) || (long_shape(h, p->t_max, p->k_sessions) && lds_long_shape(h, p->t_max));
   const bool no_queue = no_queue_env || !(on_chip || queue_all);
   // (the order by sessions only for separable objectives: with a load-flattening or demand-charge row the coupling, not
   //  the number of sessions, sets the iteration count -- on the configs[4] leg it was 10 % SLOWER than the natural one)
@@ -658,9 +660,9 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   static const bool ws_per_problem = std::getenv("ACNQP_WS_PER_PROBLEM") != nullptr;   // diagnostic
   a.ws_by_slot = a.queue && !ws_per_problem ? 1 : 0;
   a.grid_cap = a.ws_by_slot ? std::min(p->batch, 2 * h->cus) : p->batch;
-  const bool tiled = tiled_shape(h, p->t_max, p->k_sessions);
+  const bool tiled = wv > 0 || tiled_shape(h, p->t_max, p->k_sessions);   // (no workspace: state on chip)
   const bool stream = !tiled && stream_shape(h, p->t_max);
-  const bool lng = long_shape(h, p->t_max, p->k_sessions);
+  const bool lng = !tiled && long_shape(h, p->t_max, p->k_sessions);
   acnqp::GeneralArgs ga;
   acnqp::StreamArgs sa;
   if (stream) {
@@ -697,7 +699,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     ga.t = a;
   }
   auto launch_solver = [&](const acnqp::TiledArgs& aa) -> hipError_t {
-    if (tiled && acnqp::wave_shape(h->N, p->t_max, p->k_sessions, d->MR, h->has_flat || h->has_max, p->batch) > 0) return acnqp::launch_wave(aa, st);
+    if (wv > 0) return acnqp::launch_wave(aa, st);
     if (tiled) return p->t_max <= 16 ? acnqp::launch_tiled_ct1(aa, st) : acnqp::launch_tiled_ct2(aa, st);
     if (stream) { sa.t = aa; return acnqp::launch_stream(sa, st); }
     if (lng) { sa.t = aa; return acnqp::launch_long(sa, st, lds_long_shape(h, p->t_max)); }
@@ -947,7 +949,7 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
         cur_T = (int)Tm; cur_K = (int)K; cur_opt = opt; fill = 0;
         // (the kernels' workspaces belong to the resident workgroup slots since the work queue: no per-problem term)
         cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K),
-                             tiled_shape(h, (int)Tm, (int)K) && acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(call_total, 1 << 30)) > 0);
+                             acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(call_total, 1 << 30)) > 0);
         // ramp: the first kernel cannot start before its chunk's H2D has landed, and nothing overlaps that copy -- a
         // quarter-size first chunk (then a half-size one) shortens the exposed head of the pipeline
         static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
@@ -1171,7 +1173,7 @@ int run_table_pipeline(acnqp_handle* h, const acnqp_table* T, const acnqp_option
   const long long B = T->batch;
   const size_t nv = N * Tm, nsl = K * N;
   long long cap0 = chunk_problems(4 * nv * 8 + nsl * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K),
-                                  tiled_shape(h, (int)Tm, (int)K) && acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(B, 1 << 30)) > 0);
+                                  acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(B, 1 << 30)) > 0);
   static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
   long long lo = 0;
   for (size_t c = 0; lo < B; ++c) {

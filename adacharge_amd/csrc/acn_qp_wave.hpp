@@ -57,7 +57,7 @@ struct WaveLds {
     aah = w;  w += kWaveAM * kWaveAM + kWaveAM + 1;
     w = (w + 1) & ~1;
     snap = w; xch = w;
-    w += npw == 2 ? 2 * 2 * 64 + 2 : 64 * 16 / 2;   // one wave per problem: the certificate snapshot, floats [chunk of 4][lane][4];
+    w += npw >= 2 ? 2 * 2 * 64 + 2 : 64 * 16 / 2;   // one wave per problem: the certificate snapshot, floats [chunk of 4][lane][4];
                                                     // two: the mailbox (the snapshot lives in registers there)
     w = (w + 1) & ~1;
     hist = w; w += accel_mem * 64 * 16 / 2;
@@ -86,8 +86,8 @@ __device__ inline void wave_lds_sync() {   // this wave's LDS writes are visible
 
 template <int AM, int NPW, int TSV, int MT>
 __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledArgs A_kernarg) {
-  static_assert(NPW == 1 || NPW == 2, "one or two waves per problem");
-  static_assert((TSV == 12 && MT == 1) || (TSV == 6 && MT == 2 && NPW == 2), "instantiated: 12 periods x one row tile, 6 periods x two row tiles");
+  static_assert(NPW == 1 || NPW == 2 || NPW == 4, "one, two or four waves per problem");
+  static_assert((TSV == 12 && MT == 1 && NPW <= 2) || (TSV == 6 && MT == 2 && NPW >= 2), "instantiated: 12 periods x one row tile, 6 periods x two row tiles");
   using M = Mfma<double>;
   using vec4 = typename M::vec4;
   typedef double real;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   const int tid0 = threadIdx.x;
   const int lane = tid0 & 63, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int g = lane >> 4, tc = lane & 15;   // MFMA operand coordinates of the lane
-  const int half = NPW == 2 ? (wave & 1) : 0;   // which half of the horizon this wave holds (scalar)
+  const int half = wave & (NPW - 1);            // which part of the horizon this wave holds (scalar; 0 with one wave per problem)
   const int tb = TSV * half;                    // its first period
   int xseq = 0;                                 // mailbox sequence number (the partner counts the same exchanges)
   bool xbroken = false;                         // a wait ran into its bound (never expected): no further waits
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
     const WaveLds L1(min(A_kernarg.accel_mem, AM), NPW, MT, TSV);
     real* XT0 = sm + L1.wave0 + (size_t)wave * L1.wstride;
     for (int k = lane; k < 64 * XS; k += 64) XT0[k] = 0;   // the pad columns (periods 12 ... 15) stay zero for good
-    if (NPW == 2 && lane < 2) reinterpret_cast<int*>(XT0 + L1.xch + 2 * 2 * 64)[lane] = 0;   // the mailbox flag
+    if (NPW >= 2 && lane < 2) reinterpret_cast<int*>(XT0 + L1.xch + 2 * 2 * 64)[lane] = 0;   // the mailbox flag
   }
   __syncthreads();   // the only workgroup barrier of the kernel
 
@@ -139,14 +139,18 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   // flag to seq + 1 only after it has read my buffer of seq, and I write that buffer again at seq + 2.  Every wait is
   // bounded (a wave that never arrives would otherwise hang the queue for good).
   real* Xm = nullptr;
-  const real* Xp = nullptr;
-  if constexpr (NPW == 2) {
+  const real* Xg = nullptr;   // mailbox of the group's first wave; wave k's is Xg + k * xstride
+  int xstride = 0;
+  if constexpr (NPW >= 2) {
     const WaveLds Lx(min(A_kernarg.accel_mem, AM), NPW, MT, TSV);
     Xm = sm + Lx.wave0 + (size_t)wave * Lx.wstride + Lx.xch;
-    Xp = sm + Lx.wave0 + (size_t)(wave ^ 1) * Lx.wstride + Lx.xch;
+    Xg = sm + Lx.wave0 + (size_t)(wave & ~(NPW - 1)) * Lx.wstride + Lx.xch;
+    xstride = Lx.wstride;
   }
-  auto pair_xchg = [&](real va, real vb, real& pa, real& pb) __attribute__((always_inline)) {
-    if constexpr (NPW == 2) {
+  // every part's two per-lane values, in part order (index `half` = my own): the same arrays in every wave of the group,
+  // so that sums formed from them in index order are the same bits everywhere
+  auto grp_xchg = [&](real va, real vb, real (&pa)[NPW], real (&pb)[NPW]) __attribute__((always_inline)) {
+    if constexpr (NPW >= 2) {
       ++xseq;
       const int o = (xseq & 1) * 128;
       Xm[o + lane] = va;
@@ -155,61 +159,89 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       //  wavefront-scope fences -- and the hardware needs no wait between the values and the flag)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       if (lane == 0) *reinterpret_cast<volatile int*>(Xm + 256) = xseq;
-      if (!xbroken) {
-        int spins = 0;
-        while (*reinterpret_cast<const volatile int*>(Xp + 256) - xseq < 0) {
-          if (++spins > 64) __builtin_amdgcn_s_sleep(1);   // the partner is usually a few hundred cycles away: poll first
-          if (spins > (1 << 22)) { xbroken = true; break; }
+#pragma unroll
+      for (int k = 0; k < NPW; ++k) {   // every part's mailbox in part order, my own included (its flag is up already): no branch on `half`
+        const real* Xk = Xg + (size_t)k * xstride;
+        if (!xbroken) {
+          int spins = 0;
+          while (*reinterpret_cast<const volatile int*>(Xk + 256) - xseq < 0) {
+            if (++spins > 64) __builtin_amdgcn_s_sleep(1);   // the partner is usually a few hundred cycles away: poll first
+            if (spins > (1 << 22)) { xbroken = true; break; }
+          }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        pa[k] = Xk[o + lane];
+        pb[k] = Xk[o + 64 + lane];
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      pa = Xp[o + lane];
-      pb = Xp[o + 64 + lane];
     } else {
-      pa = va; pb = vb;   // (never used)
+      pa[0] = va; pb[0] = vb;
     }
   };
-  // per-lane sum / max / min over the problem's two waves (identity with one wave)
+  // per-lane sum / min-max over the problem's waves (identity with one wave)
   auto pl_sum2 = [&](real& va, real& vb) __attribute__((always_inline)) {
-    if constexpr (NPW == 2) { real pa, pb; pair_xchg(va, vb, pa, pb); va += pa; vb += pb; }
+    if constexpr (NPW >= 2) {
+      real pa[NPW], pb[NPW];
+      grp_xchg(va, vb, pa, pb);
+      va = pa[0]; vb = pb[0];
+#pragma unroll
+      for (int k = 1; k < NPW; ++k) { va += pa[k]; vb += pb[k]; }
+    }
+  };
+  auto pl_minmax = [&](real& lo_, real& hi_) __attribute__((always_inline)) {
+    if constexpr (NPW >= 2) {
+      real pa[NPW], pb[NPW];
+      grp_xchg(lo_, hi_, pa, pb);
+#pragma unroll
+      for (int k = 0; k < NPW; ++k) { lo_ = fmin(lo_, pa[k]); hi_ = fmax(hi_, pb[k]); }
+    }
   };
   // up to 8 wave-uniform values at once: value j rides in lane j
   auto pu_sum = [&](real* d, int n) __attribute__((always_inline)) {
-    if constexpr (NPW == 2) {
-      real v = 0, pa, pb;
+    if constexpr (NPW >= 2) {
+      real v = 0, pa[NPW], pb[NPW];
 #pragma unroll
       for (int j = 0; j < 8; ++j) if (j < n) v = lane == j ? d[j] : v;
-      pair_xchg(v, 0.0, pa, pb);
+      grp_xchg(v, 0.0, pa, pb);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) if (j < n) d[j] += lane_value(pa, j);
+      for (int j = 0; j < 8; ++j)
+        if (j < n) {
+          real t_ = lane_value(pa[0], j);
+#pragma unroll
+          for (int k = 1; k < NPW; ++k) t_ += lane_value(pa[k], j);
+          d[j] = t_;
+        }
     }
   };
   auto pu_max = [&](real* d, int n) __attribute__((always_inline)) {
-    if constexpr (NPW == 2) {
-      real v = 0, pa, pb;
+    if constexpr (NPW >= 2) {
+      real v = 0, pa[NPW], pb[NPW];
 #pragma unroll
       for (int j = 0; j < 8; ++j) if (j < n) v = lane == j ? d[j] : v;
-      pair_xchg(v, 0.0, pa, pb);
+      grp_xchg(v, 0.0, pa, pb);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) if (j < n) d[j] = fmax(d[j], lane_value(pa, j));
+      for (int j = 0; j < 8; ++j)
+        if (j < n) {
+#pragma unroll
+          for (int k = 0; k < NPW; ++k) d[j] = fmax(d[j], lane_value(pa[k], j));
+        }
     }
   };
 
   for (int q_round = 0;; ++q_round) {   // work queue: this WAVE's (pair's) next problem
   int q_pos;
-  if constexpr (NPW == 2) {   // the first wave of the pair fetches; the position travels through the mailbox
+  if constexpr (NPW >= 2) {   // the group's first wave fetches; the position travels through the mailbox
     int mine = 0;
     if (half == 0) {
       if (A_kernarg.queue == nullptr) {
-        const int pos = (int)blockIdx.x * (kWaveNW / 2) + (wave >> 1);
+        const int pos = (int)blockIdx.x * (kWaveNW / NPW) + wave / NPW;
         mine = q_round == 0 && pos < queue_length(A_kernarg) ? pos : -1;
       } else {
         mine = wave_queue_next(A_kernarg.queue, queue_length(A_kernarg), q_round, wave, lane);
       }
     }
-    real pa, pb;
-    pair_xchg((real)mine, 0.0, pa, pb);
-    q_pos = half == 0 ? mine : __builtin_amdgcn_readfirstlane((int)pa);
+    real pa[NPW], pb[NPW];
+    grp_xchg((real)mine, 0.0, pa, pb);
+    q_pos = __builtin_amdgcn_readfirstlane((int)pa[0]);
   } else {
     q_pos = wave_queue_next(A_kernarg.queue, queue_length(A_kernarg), q_round, wave, lane);
   }
@@ -461,7 +493,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
 #pragma unroll
       for (int t = 0; t < TS; ++t) sp += ((imask >> t) & 1u) ? zin[t] : z1[t];
       int ni = __builtin_popcount(imask);
-      if constexpr (NPW == 2) { real nr = (real)ni; pl_sum2(sp, nr); ni = (int)nr; }
+      if constexpr (NPW >= 2) { real nr = (real)ni; pl_sum2(sp, nr); ni = (int)nr; }
       real mp = (sp - cap) * rcp_small((float)(ni > 0 ? ni : 1));
       mp = (!eq & (mp < 0.0)) ? 0.0 : mp;
       m = (need & (ni > 0)) ? mp : m;
@@ -502,7 +534,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
       }
       imask = im;
       float nl = (float)__builtin_popcount(im);
-      if constexpr (NPW == 2) { real nr = (real)nl; pl_sum2(gl, nr); nl = (float)nr; }
+      if constexpr (NPW >= 2) { real nr = (real)nl; pl_sum2(gl, nr); nl = (float)nr; }
       const real d = gl - cap;
       const real big_ = BIGC;
       const bool fin = (fabs(d) <= tol) | (!eq & (m <= 0.0) & (d <= 0.0)) | (guard > ACNQP_GUARD_MAX);
@@ -520,7 +552,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
           lo_l = inw ? fmin(lo_l, zin[t] - ubv[t]) : lo_l;
           hi_l = inw ? fmax(hi_l, zin[t] - lbv[t]) : hi_l;
         }
-        if constexpr (NPW == 2) { real pa, pb; pair_xchg(lo_l, hi_l, pa, pb); lo_l = fmin(lo_l, pa); hi_l = fmax(hi_l, pb); }
+        pl_minmax(lo_l, hi_l);
         lo = open ? fmax(lo, lo_l) : lo;
         hi = open ? fmin(hi, hi_l) : hi;
       }
@@ -886,7 +918,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
         real dv1[TS], dv2[SR];
         {
           vec4 dy[MT];
-          if constexpr (NPW == 2) {
+          if constexpr (NPW >= 2) {
 #pragma unroll
             for (int r = 0; r < SR; ++r) dv2[r] = y2[r] - (real)sn2[r];
           } else {
@@ -897,7 +929,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
           for (int r = 0; r < SR; ++r) { dy[r >> 2][r & 3] = dv2[r]; w0 = fmax(w0, fabs(dv2[r])); }
           real gtv[TS];
           rows_to_evse(dy, frag_g, gtv);
-          if constexpr (NPW == 2) {
+          if constexpr (NPW >= 2) {
 #pragma unroll
             for (int t = 0; t < TS; ++t) dv1[t] = y1[t] - (real)sn1[t];
           } else {
@@ -945,7 +977,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
 #pragma unroll
             for (int t = 0; t < TS; ++t)
               if ((swm >> t) & 1u) { lmin = fmin(lmin, dv1[t]); lmax = fmax(lmax, dv1[t]); }
-            if constexpr (NPW == 2) { real pa, pb; pair_xchg(lmin, lmax, pa, pb); lmin = fmin(lmin, pa); lmax = fmax(lmax, pb); }
+            pl_minmax(lmin, lmax);
             real lam3[3] = {lmin, lmax, 0.0};
             real ph3[3];
 #pragma unroll
@@ -961,7 +993,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
                 }
               ph3[j] = ph;
             }
-            if constexpr (NPW == 2) { real z_ = 0; pl_sum2(ph3[0], ph3[1]); pl_sum2(ph3[2], z_); }
+            if constexpr (NPW >= 2) { real z_ = 0; pl_sum2(ph3[0], ph3[1]); pl_sum2(ph3[2], z_); }
             const real best = fmin(fmin(ph3[0], ph3[1]), ph3[2]);
             if (smode != 4 && half == 0) ssum += best;
 #pragma unroll
@@ -977,7 +1009,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
         }
       }
       if (!done) {   // snapshot for the next certificate test (single precision, as the twin rounds it)
-        if constexpr (NPW == 2) {
+        if constexpr (NPW >= 2) {
 #pragma unroll
           for (int t = 0; t < TS; ++t) sn1[t] = (float)y1[t];
 #pragma unroll

@@ -14,7 +14,7 @@ if ROOT not in sys.path:
 
 CASES = ("soc", "linear", "equality", "short", "site30", "peak", "infeasible", "empty_set", "warm", "general_windows", "stalled",
          "h24", "h18_linear", "h24_equality", "h20_windows", "h24_infeasible", "h24_warm",
-         "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_warm", "mt2_infeasible")
+         "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_warm", "mt2_infeasible", "mt2_h24", "mt2_h17")
 
 
 def build(name):
@@ -95,6 +95,10 @@ def build(name):
         iface2 = Interface({"infrastructure_info": infra2, "period": 5})
         if name in ("mt2_site36", "mt2_site64"):
             return build_batch(sites.snapshot_batch(infra2, 12, 128, seed=931 + k), infra2, iface2, obj, "SOC"), {}, {}
+        if name == "mt2_h24":        # two row tiles AND horizon 13 ... 24: four waves per problem, six periods each
+            return build_batch(sites.snapshot_batch(infra2, 24, 96, seed=936), infra2, iface2, obj, "SOC"), {}, {}
+        if name == "mt2_h17":        # ... the fourth wave idle (periods 18 ... 23 do not exist), the third with five live periods
+            return build_batch(sites.snapshot_batch(infra2, 17, 96, seed=937, min_rate_fraction=0.1), infra2, iface2, obj, "SOC"), {}, {}
         if name == "mt2_short":      # horizon 7: the second wave holds one live period; minimum rates
             return build_batch(sites.snapshot_batch(infra2, 7, 96, seed=933, min_rate_fraction=0.1), infra2, iface2, obj, "SOC"), {}, {}
         if name == "mt2_equality":
