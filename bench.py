@@ -616,7 +616,7 @@ def main():
                 "achieved": tf_sparse, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
                 "frac": tf_sparse / FP64_VALU_PEAK_TF,
                 "traffic": None if traffic is None else traffic / launch_b * per_step,
-                "kernel": "acnqp::admm_wave_kernel<5>",
+                "kernel": "acnqp::admm_wave_kernel<5, 1, 12, 1>",
                 "launch_ms": lone_ms, "problems_per_launch": per_step,
                 "flops_per_iteration_sparse": fl_sparse, "flops_per_iteration_dense": fl_dense,
                 "achieved_dense_count": tf_dense, "frac_dense_count": tf_dense / FP64_VALU_PEAK_TF,

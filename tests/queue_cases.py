@@ -15,7 +15,8 @@ if ROOT not in sys.path:
 CASES = {
     "wave":     ("caltech54", 12, 1024, 1e-12, {}),    # the headline shape: one wave per problem (acn_qp_wave.hpp)
     "tiled":    ("caltech54", 16, 1024, 1e-12, {}),    # horizon 13 ... 16 stays with the register-resident tiled kernel
-    "long-lds": ("jpl52", 24, 800, 1e-3, {}),
+    "wave4":    ("jpl52", 24, 800, 1e-3, {}),          # two row tiles x horizon 24: four waves per problem (acn_qp_wave.hpp)
+    "long-lds": ("jpl52", 28, 800, 1e-3, {}),          # horizon 25 ... 32 stays with the LDS-resident long-horizon kernel
     "long-96":  ("caltech54", 96, 800, 1e-12, dict(demand_range=(5.0, 60.0))),
     "stream":   ("wide128", 12, 800, 1e-3, dict(min_sessions=40)),
     "general":  ("caltech54", 300, 768, 1e-12, dict(demand_range=(5.0, 60.0))),

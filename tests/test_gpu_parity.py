@@ -1003,10 +1003,10 @@ def test_certified_infeasible_problems_are_infeasible_for_highs():
     h.close()
 
 
-@pytest.mark.parametrize("family", ["wave", "tiled", "long-lds", "long-96", "stream", "general"])
+@pytest.mark.parametrize("family", ["wave", "wave4", "tiled", "long-lds", "long-96", "stream", "general"])
 def test_work_queue_and_launch_order_do_not_change_results(tmp_path, family):
     """a launch hands its problems to the resident workgroups through a work queue, in the order
-    `longest expected first` for launches of >= 768 problems.  ONE launch of >= 768 problems per kernel family (six since round 4: the wave-per-problem kernel)
+    `longest expected first` for launches of >= 768 problems.  ONE launch of >= 768 problems per kernel family (seven since round 4: the wave-per-problem kernel with one and with four waves per problem)
     (acnqp_solve_batch_device: the pipelined host entry would cut it into chunks below the ordering threshold -- ADVICE
     r3), the order asserted to have engaged, against child processes that run the NATURAL queue order (ACNQP_NO_ORDER=1)
     the STATIC schedule, one workgroup per problem (ACNQP_NO_QUEUE=1) and the queue in every family (ACNQP_QUEUE_ALL=1):
