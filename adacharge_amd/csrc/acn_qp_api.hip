@@ -753,8 +753,8 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     a1.pol_list = list; a1.pol_count = ctr + 2; a1.y_out = ybuf; a1.pol_rows = pol_max;
     // (measured, wave kernel: the early hand-over takes 5 % off the headline launch and 23 % off configs[3] site 0, and hands
     //  ten times as many problems to the polish -- one 256-batch per call 81 -> 62 k QP/s, the table path 654 -> 580 k: off)
-    static const bool early = std::getenv("ACNQP_EARLY_HANDOVER") != nullptr;   // diagnostic
-    a1.polish_stall = early ? std::max(o->check_every, a1.polish_iters / 4) : 0;
+    static const int early = std::getenv("ACNQP_EARLY_HANDOVER") ? std::atoi(std::getenv("ACNQP_EARLY_HANDOVER")) : 0;   // diagnostic: the window (1: polish_iters / 4)
+    a1.polish_stall = early > 1 ? early : (early == 1 ? std::max(o->check_every, a1.polish_iters / 4) : 0);
     a1.y_for_polish_only = r->y ? 0 : 1;
     e = launch_solver(a1);
     if (e == hipSuccess) {

@@ -14,17 +14,23 @@
 //       corr (periods x EVSEs) = e^' Ghat            16                       (A operand = the e^ accumulator tile)
 //     with the A / B fragments of Ghat and Q read from LDS (20 KB per workgroup, loaded once per launch).
 //
-// Horizons 13 ... 24 (NPW = 2): TWO waves per problem, wave h holding periods 12 h ... 12 h + 11 of every EVSE.  The
-// products and the site rows are per period, so they stay wave-local (each wave its own transposes, MFMA chains and
-// site-row tile); what couples the halves are sums over a session's window (the water-filling: two per-lane values per
-// pass), the Anderson event's seven dot products and the residual check's maxima -- exchanged through a 2 KB LDS mailbox
-// per wave with a sequence flag (pair_xchg: the partner's in-order LDS writes, then its flag; no workgroup barrier,
-// the other pair of the workgroup is never involved).  Both waves take the same branches: every decision is made on
-// exchanged, identical values.
+// Several waves per problem (NPW = 2 or 4): wave h of the group holds periods TSV h ... TSV h + TSV - 1 of every EVSE.
+// The products and the site rows are per period, so they stay wave-local (each wave its own transposes, MFMA chains and
+// site-row tile); what couples the parts are sums over a session's window (the water-filling: two per-lane values per
+// pass), the Anderson event's seven dot products, the residual check's maxima and the queue position -- exchanged through
+// a 2 KB LDS mailbox per wave with a sequence flag (grp_xchg: a wave's in-order LDS writes, then its flag; no workgroup
+// barrier: another group of the workgroup is never involved).  Every wave reads all the group's mailboxes in part order,
+// so sums are the same bits everywhere and every wave takes the same branches.
 //
-// Shapes: N <= 64 EVSEs, horizon <= 12 (one wave) or <= 24 (two), one session slot per EVSE, <= 16 site rows (one row tile), box / disc / peak
-// rows (no prox row).  Everything else stays with acn_qp_tiled.hpp (acn_qp_api.hip routes; ACNQP_NO_WAVE=1 keeps the
-// tiled kernel for these shapes too: the A/B switch of the parity tests).
+// Instantiations <AM, NPW, TSV, MT> (acn_qp_wave.hip routes by shape; N <= 64 EVSEs, one session slot per EVSE, box /
+// disc / peak rows, no prox row):
+//   <5, 1, 12, 1>  horizon <= 12, <= 16 site rows            one wave per problem, four problems per workgroup (the headline)
+//   <5, 2, 12, 1>  horizon 13 ... 24, <= 16 site rows        two waves of twelve periods
+//   <5, 2,  6, 2>  horizon <= 12, 17 ... 32 site rows        two waves of six periods, two row tiles (a lane's state halves:
+//                                                            room for the second site-row tile without a spill)
+//   <5, 4,  6, 2>  horizon 13 ... 24, 17 ... 32 site rows    four waves of six periods: one problem per workgroup
+// Everything else stays with acn_qp_tiled.hpp / acn_qp_long.hpp (ACNQP_NO_WAVE=1, ACNQP_NO_WAVE2=1: the A/B switches of
+// tests/test_wave_kernel.py).
 #pragma once
 #include "acn_qp_tiled.hpp"
 
@@ -41,7 +47,7 @@ constexpr int kWaveAM = 5;    // Anderson columns compiled in
 struct WaveLds {
   int fragp, fragx, fragq, rowc, wave0, wstride;   // offsets in doubles
   int xt, rowd, aah, snap, hist, total;            // per-wave offsets (relative to the wave's region), total in doubles
-  int xch;                                         // NPW == 2: the wave's mailbox (two buffers of [2][64] doubles) + its flag
+  int xch;                                         // NPW >= 2: the wave's mailbox (two buffers of [2][64] doubles) + its flag
   int xs;                                          // row stride of the transpose scratch (doubles)
   __host__ __device__ WaveLds(int accel_mem, int npw = 1, int mt = 1, int tsv = kWaveTS) {
     int o = 0;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   }
   __syncthreads();   // the only workgroup barrier of the kernel
 
-  // ---- the pair's mailbox (NPW == 2): my two per-lane values out, the partner's in ----------------------------------------
+  // ---- the group's mailboxes (NPW >= 2): my two per-lane values out, every part's in -------------------------------------
   // Protocol: write the values into buffer (seq & 1) of MY mailbox, then my flag = seq (LDS operations of a wave complete
   // in order); wait for the partner's flag >= seq; read ITS buffer.  Double buffering is enough: the partner raises its
   // flag to seq + 1 only after it has read my buffer of seq, and I write that buffer again at seq + 2.  Every wait is
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   real best_score = BIGC;
   real pri = BIGC, dua = BIGC;
   bool done = false, have_prev = false;
-  float sn1[TS], sn2[SR];   // NPW == 2: the certificate's dual snapshot (one wave per problem keeps it in LDS: Snap)
+  float sn1[TS], sn2[SR];   // NPW >= 2: the certificate's dual snapshot (one wave per problem keeps it in LDS: Snap)
 #pragma unroll
   for (int t = 0; t < TS; ++t) sn1[t] = 0.f;
 #pragma unroll
