@@ -966,7 +966,7 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
   // pinned mirrors of the chunks' small arrays (device ranges [pd, wx) and [st, y) of ChunkLayout), whole call; beyond
   // kSmallCap the per-batch copies of old (a call that large is not bound by their latency)
   const size_t Mg0 = (size_t)h->Mg;
-  constexpr size_t kSmallCap = (size_t)1 << 30;
+  constexpr size_t kSmallCap = (size_t)256 << 20;
   std::vector<size_t> in_off(chunks.size()), out_off(chunks.size());
   size_t in_sum = 0, out_sum = 0;
   for (size_t c = 0; c < chunks.size(); ++c) {
