@@ -1120,7 +1120,9 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
     ol = wave_sum<real>(ol);
     { real o1[1] = {ol}; pu_sum(o1, 1); ol = o1[0]; }
     if (lane == 0 && half == 0) {
-      A.status[b] = status;
+      // (a mailbox wait that ran into its bound -- never expected -- leaves the problem UNSET: the host entry then fails the
+      //  call loudly instead of returning a schedule built on a partner's stale values)
+      A.status[b] = xbroken ? 0 : status;
       A.pri[b] = pri;
       A.dua[b] = dua;
       A.obj[b] = ol;
