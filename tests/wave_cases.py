@@ -14,7 +14,7 @@ if ROOT not in sys.path:
 
 CASES = ("soc", "linear", "equality", "short", "site30", "peak", "infeasible", "empty_set", "warm", "general_windows", "stalled",
          "h24", "h18_linear", "h24_equality", "h20_windows", "h24_infeasible", "h24_warm",
-         "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_warm", "mt2_infeasible", "mt2_h24", "mt2_h17")
+         "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_warm", "mt2_infeasible", "mt2_h24", "mt2_h17", "mt2_t4", "h13")
 
 
 def build(name):
@@ -66,6 +66,8 @@ def build(name):
         snaps = [sites.random_sessions_general(infra, 12, rng, False, min_rates=True) for _ in range(96)]
         return build_batch(snaps, infra, iface, obj, "SOC"), {}, {}
     # ---- horizons 13 ... 24: two waves per problem, twelve periods each
+    if name == "h13":          # one live period in the second wave
+        return build_batch(sites.snapshot_batch(infra, 13, 96, seed=925), infra, iface, obj, "SOC"), {}, {}
     if name == "h24":
         return build_batch(sites.snapshot_batch(infra, 24, 192, seed=921), infra, iface, obj, "SOC"), {}, {}
     if name == "h18_linear":   # the second wave holds six live periods
@@ -99,6 +101,8 @@ def build(name):
             return build_batch(sites.snapshot_batch(infra2, 24, 96, seed=936), infra2, iface2, obj, "SOC"), {}, {}
         if name == "mt2_h17":        # ... the fourth wave idle (periods 18 ... 23 do not exist), the third with five live periods
             return build_batch(sites.snapshot_batch(infra2, 17, 96, seed=937, min_rate_fraction=0.1), infra2, iface2, obj, "SOC"), {}, {}
+        if name == "mt2_t4":         # horizon 4: the second wave of the pair holds no live period at all
+            return build_batch(sites.snapshot_batch(infra2, 4, 64, seed=938, demand_range=(0.2, 2.0)), infra2, iface2, obj, "SOC"), {}, {}
         if name == "mt2_short":      # horizon 7: the second wave holds one live period; minimum rates
             return build_batch(sites.snapshot_batch(infra2, 7, 96, seed=933, min_rate_fraction=0.1), infra2, iface2, obj, "SOC"), {}, {}
         if name == "mt2_equality":
