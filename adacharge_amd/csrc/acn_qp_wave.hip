@@ -12,7 +12,8 @@ namespace acnqp {
 // problems per CU on, four problems in flight per CU win (16,384: 26.5 -> 15.5 ms).  ACNQP_WAVE_MIN_BATCH=n (diagnostic)
 // sends launches of fewer than n problems to the tiled kernel.  Returns the variant (0: not this kernel; 1: horizon
 // <= 12, one wave per problem; 2: horizon 13 ... 24, two waves; 3: two row tiles at horizon <= 12, two waves of six periods;
-// 4: two row tiles at horizon 13 ... 24, four waves of six periods -- one problem per workgroup).
+// 4: two row tiles at horizon 13 ... 24, four waves of six periods -- one problem per workgroup; 5: one row tile at
+// horizon 33 ... 48, four waves of twelve periods).
 int wave_shape(int N, int t_max, int k_sessions, int MR, bool has_prox, int batch) {
   static const bool off = std::getenv("ACNQP_NO_WAVE") != nullptr;   // diagnostic / A-B: the register-resident tiled kernel instead
   static const bool off2 = std::getenv("ACNQP_NO_WAVE2") != nullptr; // ... for the two-waves-per-problem variants only
@@ -20,6 +21,9 @@ int wave_shape(int N, int t_max, int k_sessions, int MR, bool has_prox, int batc
   if (off || N > 64 || k_sessions != 1 || has_prox || batch < min_batch) return 0;
   if (MR == 16 && t_max <= kWaveTS) return 1;                   // one wave per problem
   if (MR == 16 && t_max <= 2 * kWaveTS) return off2 ? 0 : 2;    // two waves, twelve periods each
+  // (horizons 25 ... 32 stay with the tiled kernel's two column tiles: the same four waves per problem there, 19.8 against
+  //  21.3 ms at 2,048 problems; from 33 on the alternative streams its state: 57.0 against 22.3 ms at horizon 48)
+  if (MR == 16 && t_max > 32 && t_max <= 4 * kWaveTS) return off2 ? 0 : 5;   // horizon 33 ... 48: four waves, twelve periods each
   if (MR == 32 && t_max <= kWaveTS) return off2 ? 0 : 3;        // two row tiles: two waves, six periods each
   if (MR == 32 && t_max <= 2 * kWaveTS) return off2 ? 0 : 4;    // two row tiles, horizon 13 ... 24: four waves, six periods each
   return 0;
@@ -59,6 +63,7 @@ static hipError_t launch_wave_npw(const TiledArgs& a_in, hipStream_t st) {
 
 hipError_t launch_wave(const TiledArgs& a, hipStream_t st) {
   if (a.MR == 32) return a.Tm <= kWaveTS ? launch_wave_npw<2, 6, 2>(a, st) : launch_wave_npw<4, 6, 2>(a, st);
+  if (a.Tm > 2 * kWaveTS) return launch_wave_npw<4, 12, 1>(a, st);
   return a.Tm <= kWaveTS ? launch_wave_npw<1, 12, 1>(a, st) : launch_wave_npw<2, 12, 1>(a, st);
 }
 

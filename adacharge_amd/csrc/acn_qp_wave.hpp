@@ -29,6 +29,7 @@
 //   <5, 2,  6, 2>  horizon <= 12, 17 ... 32 site rows        two waves of six periods, two row tiles (a lane's state halves:
 //                                                            room for the second site-row tile without a spill)
 //   <5, 4,  6, 2>  horizon 13 ... 24, 17 ... 32 site rows    four waves of six periods: one problem per workgroup
+//   <5, 4, 12, 1>  horizon 33 ... 48, <= 16 site rows        four waves of twelve periods: one problem per workgroup
 // Everything else stays with acn_qp_tiled.hpp / acn_qp_long.hpp (ACNQP_NO_WAVE=1, ACNQP_NO_WAVE2=1: the A/B switches of
 // tests/test_wave_kernel.py).
 #pragma once
@@ -93,7 +94,7 @@ __device__ inline void wave_lds_sync() {   // this wave's LDS writes are visible
 template <int AM, int NPW, int TSV, int MT>
 __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledArgs A_kernarg) {
   static_assert(NPW == 1 || NPW == 2 || NPW == 4, "one, two or four waves per problem");
-  static_assert((TSV == 12 && MT == 1 && NPW <= 2) || (TSV == 6 && MT == 2 && NPW >= 2), "instantiated: 12 periods x one row tile, 6 periods x two row tiles");
+  static_assert((TSV == 12 && MT == 1) || (TSV == 6 && MT == 2 && NPW >= 2), "instantiated: 12 periods x one row tile, 6 periods x two row tiles");
   using M = Mfma<double>;
   using vec4 = typename M::vec4;
   typedef double real;

@@ -30,7 +30,8 @@ def _both(tmp_path, name):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["soc", "linear", "equality", "short", "site30", "peak", "general_windows",
                                   "h24", "h18_linear", "h24_equality", "h20_windows",
-                                  "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_h24", "mt2_h17", "mt2_t4", "h13"])
+                                  "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_h24", "mt2_h17", "mt2_t4", "h13",
+                                  "h48", "h36_linear", "h40_equality"])
 def test_wave_kernel_agrees_with_the_tiled_kernel(tmp_path, name):
     """Same statuses, schedules within the rate tolerance, iteration counts that differ only where rounding moved a
     residual check (the two kernels sum in different orders): feasible shapes the wave kernel routes -- SOC and LINEAR

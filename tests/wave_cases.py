@@ -14,7 +14,7 @@ if ROOT not in sys.path:
 
 CASES = ("soc", "linear", "equality", "short", "site30", "peak", "infeasible", "empty_set", "warm", "general_windows", "stalled",
          "h24", "h18_linear", "h24_equality", "h20_windows", "h24_infeasible", "h24_warm",
-         "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_warm", "mt2_infeasible", "mt2_h24", "mt2_h17", "mt2_t4", "h13")
+         "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_warm", "mt2_infeasible", "mt2_h24", "mt2_h17", "mt2_t4", "h13", "h48", "h36_linear", "h40_equality")
 
 
 def build(name):
@@ -66,6 +66,14 @@ def build(name):
         snaps = [sites.random_sessions_general(infra, 12, rng, False, min_rates=True) for _ in range(96)]
         return build_batch(snaps, infra, iface, obj, "SOC"), {}, {}
     # ---- horizons 13 ... 24: two waves per problem, twelve periods each
+    # ---- horizons 33 ... 48 on one row tile: four waves per problem, twelve periods each
+    if name == "h48":
+        return build_batch(sites.snapshot_batch(infra, 48, 96, seed=941), infra, iface, obj, "SOC"), {}, {}
+    if name == "h36_linear":   # the fourth wave holds no live period
+        return build_batch(sites.snapshot_batch(infra, 36, 96, seed=942, min_rate_fraction=0.2), infra, iface, obj, "LINEAR"), {}, {}
+    if name == "h40_equality":
+        snaps = sites.snapshot_batch(infra, 40, 64, seed=943, demand_range=(0.1, 0.5))
+        return build_batch(snaps, infra, iface, obj, "SOC", True), {}, {}
     if name == "h13":          # one live period in the second wave
         return build_batch(sites.snapshot_batch(infra, 13, 96, seed=925), infra, iface, obj, "SOC"), {}, {}
     if name == "h24":
