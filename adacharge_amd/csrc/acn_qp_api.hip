@@ -917,8 +917,10 @@ long long chunk_problems(size_t per_problem_bytes, bool on_chip, bool wave = fal
   // streams in flight the shorter pipeline head and tail outweigh the per-launch tails (bench: 441 -> 455 k QP/s)
   long long want = on_chip ? 1024 : 2048;
   // the wave-per-problem kernel's launches are persistent (four problems in flight per CU, one wave each): a launch ends
-  // with its slowest problem whatever its size, so few large chunks (sweep: 3,072 / 4,096 / 6,144 -> 21.7 / 20.5 / 20.0 ms)
-  if (wave) want = 6144;
+  // with its slowest problem whatever its size, so few large chunks (sweep at 16,384 problems per call: 4,096 / 6,144 /
+  // 7,168 / 8,192 / 9,216 -> 18.9 / 19.0 / 18.3 / 18.0 / 19.4 ms: what matters beside the size is that the LAST chunk is
+  // a small one -- plan_chunks below)
+  if (wave) want = 8192;
   if (const char* e = std::getenv("ACNQP_CHUNK")) { const long long v = std::atoll(e); if (v > 0) want = v; }
   const long long by_mem = (long long)((size_t)1024 * 1024 * 1024 / std::max<size_t>(per_problem_bytes, 1));
   long long n = std::max<long long>(1, std::min(want, by_mem));
@@ -929,11 +931,34 @@ long long chunk_problems(size_t per_problem_bytes, bool on_chip, bool wave = fal
 // what the caller's small result arrays still need after the streams have drained: a copy out of the pinned mirror
 struct Scatter { int g; size_t lo, n, pos; const char* host; size_t st, it, pr, du, ob; };
 
+// Chunk sizes of a call of `total` problems of ONE shape served by the wave kernel: a quarter-size and a half-size chunk
+// in front (the first kernel waits for its inputs, and nothing overlaps that copy), full chunks, and a quarter-size one
+// at the END (what follows the last solver launch -- its polish, its result copies -- is exposed too):
+// c/4 + c/2 + k c + c/4 = total with the smallest k for which c <= cap.
+void plan_chunks(long long total, long long cap, std::vector<long long>* out) {
+  std::vector<long long>& plan = *out;
+  plan.clear();
+  if (total < 2048 || cap < 2048) { plan.push_back(total); return; }
+  const long long k = (total + cap - 1) / cap - 1;
+  long long c = total / (k + 1);
+  c = std::max<long long>(2048, std::min(cap, c - c % 512));
+  plan.push_back(c / 4);
+  plan.push_back(c / 2);
+  for (long long i = 0; i < k; ++i) plan.push_back(c);
+  plan.push_back(total);   // (the rest: the loop below ends a chunk when the call's problems are gone)
+}
+
 int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_options* o, acnqp_results* R, std::vector<Scatter>* scatter) {
   const size_t N = h->N;
   const bool peak = h->has_peak, flat = h->has_flat, mx = h->has_max;
   long long call_total = 0;
-  for (int g = 0; g < nb; ++g) call_total += P[g].batch;
+  bool uniform_call = true;   // one shape, one set of optional arrays: the call's chunks can be planned as a whole
+  std::vector<long long> plan;
+  for (int g = 0; g < nb; ++g) {
+    call_total += P[g].batch;
+    uniform_call = uniform_call && P[g].t_max == P[0].t_max && P[g].k_sessions == P[0].k_sessions &&
+                   (P[g].warm_x != nullptr) == (P[0].warm_x != nullptr) && (R[g].y != nullptr) == (R[0].y != nullptr);
+  }
   // chunks: consecutive batches of one shape (t_max, k_sessions) share launches of up to chunk_problems() problems
   std::vector<std::vector<Piece>> chunks;
   long long fill = 0, cap = 0;
@@ -953,7 +978,11 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
         // ramp: the first kernel cannot start before its chunk's H2D has landed, and nothing overlaps that copy -- a
         // quarter-size first chunk (then a half-size one) shortens the exposed head of the pipeline
         static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
-        if (ramp && cap >= 1024) {
+        const bool is_wave = acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(call_total, 1 << 30)) > 0;
+        if (ramp && is_wave && uniform_call) {
+          if (plan.empty()) plan_chunks(call_total, cap, &plan);
+          cap = chunks.size() <= plan.size() ? plan[chunks.size() - 1] : cap;
+        } else if (ramp && cap >= 1024) {
           if (chunks.size() == 1) cap /= 4;
           else if (chunks.size() == 2) cap /= 2;
         }
@@ -1175,10 +1204,14 @@ int run_table_pipeline(acnqp_handle* h, const acnqp_table* T, const acnqp_option
   long long cap0 = chunk_problems(4 * nv * 8 + nsl * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K),
                                   acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(B, 1 << 30)) > 0);
   static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
+  const bool is_wave = acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(B, 1 << 30)) > 0;
+  std::vector<long long> plan;
+  if (ramp && is_wave) plan_chunks(B, cap0, &plan);
   long long lo = 0;
   for (size_t c = 0; lo < B; ++c) {
     long long cap = cap0;
-    if (ramp && cap0 >= 1024) cap = c == 0 ? cap0 / 4 : (c == 1 ? cap0 / 2 : cap0);
+    if (!plan.empty()) cap = c < plan.size() ? plan[c] : cap0;
+    else if (ramp && cap0 >= 1024) cap = c == 0 ? cap0 / 4 : (c == 1 ? cap0 / 2 : cap0);
     const long long cn = std::min(B - lo, cap);
     acnqp_handle::Slot& S = h->slot[c % acnqp_handle::kSlots];
     const ChunkLayout L((size_t)cn, N, Tm, K, Mg, peak, flat, mx, false, want_y);
