@@ -938,6 +938,11 @@ struct Scatter { int g; size_t lo, n, pos; const char* host; size_t st, it, pr, 
 void plan_chunks(long long total, long long cap, std::vector<long long>* out) {
   std::vector<long long>& plan = *out;
   plan.clear();
+  if (const char* e = std::getenv("ACNQP_PLAN")) {   // diagnostic: explicit chunk sizes "a,b,c" (the rest goes into a last chunk)
+    for (const char* q = e; *q;) { plan.push_back(std::atoll(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+    plan.push_back(total);
+    return;
+  }
   if (total < 2048 || cap < 2048) { plan.push_back(total); return; }
   const long long k = (total + cap - 1) / cap - 1;
   long long c = total / (k + 1);
