@@ -12,8 +12,8 @@ One "step" = ONE call of the product entry point `acnqp_solve_batches` over `--b
 batches per GPU, i.e. 16,384 problems per GPU per step, from pinned HOST buffers to pinned HOST buffers:
 H2D of every problem array + kernels + D2H of schedules, statuses, iterations, residuals and objectives,
 all inside the timed region (the metric SURVEY.md section 8d defines; `acnqp_create` -- the one-time site
-upload -- is outside).  The library pipelines the call internally (chunks of up to 6,144 problems on this shape --
-1,536 and 3,072 for the first two, which shortens the exposed head of the pipeline -- rotate over four streams with
+upload -- is outside).  The library pipelines the call internally (chunks of 2,048 / 4,096 / 8,192 / 2,048 problems
+on this shape -- small ones first and last, which shortens the exposed head and tail of the pipeline -- rotate over four streams with
 their own device staging; the small per-problem arrays travel through pinned mirrors, one copy per chunk and
 direction), so there is nothing for the bench to overlap by hand and
 `value` is what any caller of the API gets.  Weak scaling: every rank owns its own 64 x 256 snapshots.
