@@ -630,7 +630,7 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
   // the same or better (configs[4] leg 432 vs 434-438 ms, 54 x 144 x 2,048 237-243 vs 247-248 ms; gpurun_out/r4c):
   // they keep one workgroup per problem.
   // the wave-per-problem kernel's variant for this shape (0: another kernel family; acn_qp_wave.hip)
-  const int wv = acnqp::wave_shape(h->N, p->t_max, p->k_sessions, d->MR, h->has_flat || h->has_max, p->batch);
+  const int wv = acnqp::wave_shape(h->N, p->t_max, p->k_sessions, d->MR, h->has_max, p->batch);
   const bool on_chip = wv > 0 || tiled_shape(h, p->t_max, p->k_sessions) || (long_shape(h, p->t_max, p->k_sessions) && lds_long_shape(h, p->t_max));
   const bool no_queue = no_queue_env || !(on_chip || queue_all);
   // (the order by sessions only for separable objectives: with a load-flattening or demand-charge row the coupling, not
@@ -979,11 +979,11 @@ int run_pipeline(acnqp_handle* h, int nb, const acnqp_problems* P, const acnqp_o
         cur_T = (int)Tm; cur_K = (int)K; cur_opt = opt; fill = 0;
         // (the kernels' workspaces belong to the resident workgroup slots since the work queue: no per-problem term)
         cap = chunk_problems(4 * N * Tm * 8 + K * N * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K),
-                             acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(call_total, 1 << 30)) > 0);
+                             acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_max, (int)std::min<long long>(call_total, 1 << 30)) > 0);
         // ramp: the first kernel cannot start before its chunk's H2D has landed, and nothing overlaps that copy -- a
         // quarter-size first chunk (then a half-size one) shortens the exposed head of the pipeline
         static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
-        const bool is_wave = acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(call_total, 1 << 30)) > 0;
+        const bool is_wave = acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_max, (int)std::min<long long>(call_total, 1 << 30)) > 0;
         if (ramp && is_wave && uniform_call) {
           if (plan.empty()) plan_chunks(call_total, cap, &plan);
           cap = chunks.size() <= plan.size() ? plan[chunks.size() - 1] : cap;
@@ -1207,9 +1207,9 @@ int run_table_pipeline(acnqp_handle* h, const acnqp_table* T, const acnqp_option
   const long long B = T->batch;
   const size_t nv = N * Tm, nsl = K * N;
   long long cap0 = chunk_problems(4 * nv * 8 + nsl * 16 + Tm * 8 + 96, tiled_shape(h, (int)Tm, (int)K),
-                                  acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(B, 1 << 30)) > 0);
+                                  acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_max, (int)std::min<long long>(B, 1 << 30)) > 0);
   static const bool ramp = std::getenv("ACNQP_NO_RAMP") == nullptr;
-  const bool is_wave = acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_flat || h->has_max, (int)std::min<long long>(B, 1 << 30)) > 0;
+  const bool is_wave = acnqp::wave_shape(h->N, (int)Tm, (int)K, h->dev64.MR, h->has_max, (int)std::min<long long>(B, 1 << 30)) > 0;
   std::vector<long long> plan;
   if (ramp && is_wave) plan_chunks(B, cap0, &plan);
   long long lo = 0;

@@ -97,7 +97,7 @@ hipError_t launch_tiled_ct2(const TiledArgs& a, hipStream_t st);
 // wave-per-problem kernel (acn_qp_wave.hpp): the shapes of launch_tiled_ct1 with horizon <= 12, one session slot, one row
 // tile and no prox row (the headline shape); wave_shape says whether a launch is routed to it (by shape; `batch` only
 // for the diagnostic ACNQP_WAVE_MIN_BATCH)
-int wave_shape(int N, int t_max, int k_sessions, int MR, bool has_prox, int batch);   // waves per problem; 0: not routed
+int wave_shape(int N, int t_max, int k_sessions, int MR, bool has_max, int batch);   // waves per problem; 0: not routed
 hipError_t launch_wave(const TiledArgs& a, hipStream_t st);
 // large-site kernel (acn_qp_stream.hpp)
 hipError_t launch_stream(const StreamArgs& sa, hipStream_t st);

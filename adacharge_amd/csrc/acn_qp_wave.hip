@@ -5,7 +5,7 @@
 namespace acnqp {
 
 // shapes the wave-per-problem kernel takes: a lane per EVSE, twelve period registers, one session slot, one row tile,
-// box / disc / peak rows.  A function of the SHAPE only, never of the batch size: a problem's result does not depend on
+// box / disc / peak rows and the load-flattening row.  A function of the SHAPE only, never of the batch size: a problem's result does not depend on
 // what it is batched with (tests/test_gpu_parity.py asserts the bits).  The price: a problem is ONE wave's dependent chain
 // here (4.3 us per iteration) and four waves' in the tiled kernel (3.1 us alone on a CU), so a launch of at most one
 // problem per CU ends later than it did (256 problems: 2.9 against 2.3 ms; one problem: 0.85 against 0.6 ms) -- from two
@@ -14,11 +14,11 @@ namespace acnqp {
 // <= 12, one wave per problem; 2: horizon 13 ... 24, two waves; 3: two row tiles at horizon <= 12, two waves of six periods;
 // 4: two row tiles at horizon 13 ... 24, four waves of six periods -- one problem per workgroup; 5: one row tile at
 // horizon 33 ... 48, four waves of twelve periods).
-int wave_shape(int N, int t_max, int k_sessions, int MR, bool has_prox, int batch) {
+int wave_shape(int N, int t_max, int k_sessions, int MR, bool has_max, int batch) {
   static const bool off = std::getenv("ACNQP_NO_WAVE") != nullptr;   // diagnostic / A-B: the register-resident tiled kernel instead
   static const bool off2 = std::getenv("ACNQP_NO_WAVE2") != nullptr; // ... for the two-waves-per-problem variants only
   static const int min_batch = std::getenv("ACNQP_WAVE_MIN_BATCH") ? std::atoi(std::getenv("ACNQP_WAVE_MIN_BATCH")) : 1;
-  if (off || N > 64 || k_sessions != 1 || has_prox || batch < min_batch) return 0;
+  if (off || N > 64 || k_sessions != 1 || has_max || batch < min_batch) return 0;   // (the demand-charge row couples all periods)
   if (MR == 16 && t_max <= kWaveTS) return 1;                   // one wave per problem
   if (MR == 16 && t_max <= 2 * kWaveTS) return off2 ? 0 : 2;    // two waves, twelve periods each
   // (horizons 25 ... 32 stay with the tiled kernel's two column tiles: the same four waves per problem there, 19.8 against

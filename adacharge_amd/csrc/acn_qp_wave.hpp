@@ -23,7 +23,7 @@
 // so sums are the same bits everywhere and every wave takes the same branches.
 //
 // Instantiations <AM, NPW, TSV, MT> (acn_qp_wave.hip routes by shape; N <= 64 EVSEs, one session slot per EVSE, box /
-// disc / peak rows, no prox row):
+// disc / peak rows and the load-flattening row; no demand-charge row):
 //   <5, 1, 12, 1>  horizon <= 12, <= 16 site rows            one wave per problem, four problems per workgroup (the headline)
 //   <5, 2, 12, 1>  horizon 13 ... 24, <= 16 site rows        two waves of twelve periods
 //   <5, 2,  6, 2>  horizon <= 12, 17 ... 32 site rows        two waves of six periods, two row tiles (a lane's state halves:
@@ -393,6 +393,8 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
   }
 
   const real pd_user = uniform_scalar(A.pdiag[b]);
+  // load flattening's aggregate-power row lives in equilibrated units z' = s z: 1/2 lf z^2 = 1/2 (lf / s^2) z'^2
+  const real lfb = uniform_scalar(A.lf ? A.lf[b] / (A.flat_scale * A.flat_scale) : 0.0);
   const real sigma = A.sigma, alpha = A.alpha;
   real rho = A.rho0;
   if (pass > 0) {
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
     { real f[3] = {f1, f2, f3}; pu_max(f, 3); f1 = f[0]; f2 = f[1]; f3 = f[2]; }
     plain_windows = uniform_scalar(f3) == 0.0;
     qnorm = uniform_scalar(f1);
-    pd = uniform_scalar(effective_pdiag<real>(pd_user, A.reg_rel, qnorm, uniform_scalar(f2), A.horizon[b], false));
+    pd = uniform_scalar(effective_pdiag<real>(pd_user, A.reg_rel, qnorm, uniform_scalar(f2), A.horizon[b], lfb > 0.0));
     if (__any(empty_set)) {   // a session cannot meet its energy row inside its own bounds (wave-uniform)
 #pragma unroll
       for (int t = 0; t < TS; ++t)
@@ -870,11 +872,13 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
           scl[pr] = clip ? f : 1.0;
         }
         const real big_s = BIGC;
+        const real quadf = rho / (rho + lfb);   // prox of 1/2 lf z^2 (the load-flattening row): z = zh rho / (rho + lf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const real zh_ = zhr[4 * m + r];
           const int ty = rty[r];
-          const real fac = ((ty == kRowSocRe) | (ty == kRowSocIm)) ? scl[r >> 1] : 1.0;
+          real fac = ((ty == kRowSocRe) | (ty == kRowSocIm)) ? scl[r >> 1] : 1.0;
+          fac = ty == kRowQuad ? quadf : fac;
           real cap_ = ty == kRowBox ? lim4[r] : big_s;
           cap_ = ty == kRowPeak ? pk_lane : cap_;
           const real zn = fmin(zh_ * fac, cap_);

@@ -14,7 +14,7 @@ if ROOT not in sys.path:
 
 CASES = ("soc", "linear", "equality", "short", "site30", "peak", "infeasible", "empty_set", "warm", "general_windows", "stalled",
          "h24", "h18_linear", "h24_equality", "h20_windows", "h24_infeasible", "h24_warm",
-         "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_warm", "mt2_infeasible", "mt2_h24", "mt2_h17", "mt2_t4", "h13", "h48", "h36_linear", "h40_equality")
+         "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_warm", "mt2_infeasible", "mt2_h24", "mt2_h17", "mt2_t4", "h13", "h48", "h36_linear", "h40_equality", "flat_linear", "flat_soc", "flat_h24")
 
 
 def build(name):
@@ -27,6 +27,15 @@ def build(name):
     iface = Interface({"infrastructure_info": infra, "period": 5})
     obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
     rng = np.random.default_rng(9100)
+    if name.startswith("flat_"):   # load_flattening: the prox row of the aggregate power (one more site row; SOC: two row tiles)
+        from adacharge_amd import load_flattening, total_energy
+
+        T = 24 if name == "flat_h24" else 12
+        ext = 40.0 + 30.0 * np.cos(np.arange(T) / T * 2 * np.pi)
+        fobj = [ObjectiveComponent(load_flattening, 1.0, {"external_signal": ext}), ObjectiveComponent(total_energy, 1500.0),
+                ObjectiveComponent(equal_share, 1e-3)]
+        ct = "SOC" if name == "flat_soc" else "LINEAR"
+        return build_batch(sites.snapshot_batch(infra, T, 96, seed=951 + T), infra, iface, fobj, ct), {}, {}
     if name == "soc":
         return build_batch(sites.snapshot_batch(infra, 12, 192, seed=911), infra, iface, obj, "SOC"), {}, {}
     if name == "linear":
