@@ -5,7 +5,7 @@
 namespace acnqp {
 
 // shapes the wave-per-problem kernel takes: a lane per EVSE, twelve period registers, one session slot, one row tile,
-// box / disc / peak rows and the load-flattening row.  A function of the SHAPE only, never of the batch size: a problem's result does not depend on
+// box / disc / peak rows and the two prox rows.  A function of the SHAPE only, never of the batch size: a problem's result does not depend on
 // what it is batched with (tests/test_gpu_parity.py asserts the bits).  The price: a problem is ONE wave's dependent chain
 // here (4.3 us per iteration) and four waves' in the tiled kernel (3.1 us alone on a CU), so a launch of at most one
 // problem per CU ends later than it did (256 problems: 2.9 against 2.3 ms; one problem: 0.85 against 0.6 ms) -- from two
@@ -18,7 +18,8 @@ int wave_shape(int N, int t_max, int k_sessions, int MR, bool has_max, int batch
   static const bool off = std::getenv("ACNQP_NO_WAVE") != nullptr;   // diagnostic / A-B: the register-resident tiled kernel instead
   static const bool off2 = std::getenv("ACNQP_NO_WAVE2") != nullptr; // ... for the two-waves-per-problem variants only
   static const int min_batch = std::getenv("ACNQP_WAVE_MIN_BATCH") ? std::atoi(std::getenv("ACNQP_WAVE_MIN_BATCH")) : 1;
-  if (off || N > 64 || k_sessions != 1 || has_max || batch < min_batch) return 0;   // (the demand-charge row couples all periods)
+  (void)has_max;   // (the demand-charge row's prox couples all periods: its sums cross the group's mailbox)
+  if (off || N > 64 || k_sessions != 1 || batch < min_batch) return 0;
   if (MR == 16 && t_max <= kWaveTS) return 1;                   // one wave per problem
   if (MR == 16 && t_max <= 2 * kWaveTS) return off2 ? 0 : 2;    // two waves, twelve periods each
   // (horizons 25 ... 32 stay with the tiled kernel's two column tiles: the same four waves per problem there, 19.8 against
@@ -29,13 +30,13 @@ int wave_shape(int N, int t_max, int k_sessions, int MR, bool has_max, int batch
   return 0;
 }
 
-template <int NPW, int TSV, int MT>
-static hipError_t launch_wave_npw(const TiledArgs& a_in, hipStream_t st) {
+template <int NPW, int TSV, int MT, bool PROX>
+static hipError_t launch_wave_prox(const TiledArgs& a_in, hipStream_t st) {
   TiledArgs a = a_in;
   a.accel_mem = std::min(a.accel_mem, kWaveAM);
   const WaveLds L(a.accel_mem, NPW, MT, TSV);
   const size_t lds = (size_t)L.total * 8;
-  auto kern = &admm_wave_kernel<kWaveAM, NPW, TSV, MT>;
+  auto kern = &admm_wave_kernel<kWaveAM, NPW, TSV, MT, PROX>;
   if (lds > 64 * 1024) {
     hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return e;
@@ -59,6 +60,12 @@ static hipError_t launch_wave_npw(const TiledArgs& a_in, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kWaveNW * 64), lds, st, a);
   return hipGetLastError();
+}
+
+// (sites without a prox row run the instantiation that carries no prox code)
+template <int NPW, int TSV, int MT>
+static hipError_t launch_wave_npw(const TiledArgs& a, hipStream_t st) {
+  return a.lf != nullptr || a.dc != nullptr ? launch_wave_prox<NPW, TSV, MT, true>(a, st) : launch_wave_prox<NPW, TSV, MT, false>(a, st);
 }
 
 hipError_t launch_wave(const TiledArgs& a, hipStream_t st) {

@@ -23,7 +23,7 @@
 // so sums are the same bits everywhere and every wave takes the same branches.
 //
 // Instantiations <AM, NPW, TSV, MT> (acn_qp_wave.hip routes by shape; N <= 64 EVSEs, one session slot per EVSE, box /
-// disc / peak rows and the load-flattening row; no demand-charge row):
+// disc / peak rows, the load-flattening and the demand-charge row):
 //   <5, 1, 12, 1>  horizon <= 12, <= 16 site rows            one wave per problem, four problems per workgroup (the headline)
 //   <5, 2, 12, 1>  horizon 13 ... 24, <= 16 site rows        two waves of twelve periods
 //   <5, 2,  6, 2>  horizon <= 12, 17 ... 32 site rows        two waves of six periods, two row tiles (a lane's state halves:
@@ -91,7 +91,7 @@ __device__ inline void wave_lds_sync() {   // this wave's LDS writes are visible
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int AM, int NPW, int TSV, int MT>
+template <int AM, int NPW, int TSV, int MT, bool PROX>
 __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledArgs A_kernarg) {
   static_assert(NPW == 1 || NPW == 2 || NPW == 4, "one, two or four waves per problem");
   static_assert((TSV == 12 && MT == 1) || (TSV == 6 && MT == 2 && NPW >= 2), "instantiated: 12 periods x one row tile, 6 periods x two row tiles");
@@ -394,7 +394,12 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
 
   const real pd_user = uniform_scalar(A.pdiag[b]);
   // load flattening's aggregate-power row lives in equilibrated units z' = s z: 1/2 lf z^2 = 1/2 (lf / s^2) z'^2
-  const real lfb = uniform_scalar(A.lf ? A.lf[b] / (A.flat_scale * A.flat_scale) : 0.0);
+  // (PROX = false: sites without a prox row -- the headline -- carry none of this code: its mere presence cost 4 %)
+  const real lfb = PROX ? uniform_scalar(A.lf ? A.lf[b] / (A.flat_scale * A.flat_scale) : 0.0) : 0.0;
+  // ... the demand-charge row's too: dc max(z) = (dc / s) max(z')
+  const real dcb = PROX ? uniform_scalar(A.dc ? A.dc[b] / A.max_scale : 0.0) : 0.0;
+  const real dfl = PROX ? uniform_scalar(A.dfloor ? A.dfloor[b] * A.max_scale : 0.0) : 0.0;
+  real tau_max = 0;   // warm start of the demand-charge level
   const real sigma = A.sigma, alpha = A.alpha;
   real rho = A.rho0;
   if (pass > 0) {
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
     { real f[3] = {f1, f2, f3}; pu_max(f, 3); f1 = f[0]; f2 = f[1]; f3 = f[2]; }
     plain_windows = uniform_scalar(f3) == 0.0;
     qnorm = uniform_scalar(f1);
-    pd = uniform_scalar(effective_pdiag<real>(pd_user, A.reg_rel, qnorm, uniform_scalar(f2), A.horizon[b], lfb > 0.0));
+    pd = uniform_scalar(effective_pdiag<real>(pd_user, A.reg_rel, qnorm, uniform_scalar(f2), A.horizon[b], PROX && ((lfb > 0.0) | (dcb > 0.0))));
     if (__any(empty_set)) {   // a session cannot meet its energy row inside its own bounds (wave-uniform)
 #pragma unroll
       for (int t = 0; t < TS; ++t)
@@ -878,12 +883,63 @@ __global__ __launch_bounds__(kWaveNW * 64, 1) void admm_wave_kernel(const TiledA
           const real zh_ = zhr[4 * m + r];
           const int ty = rty[r];
           real fac = ((ty == kRowSocRe) | (ty == kRowSocIm)) ? scl[r >> 1] : 1.0;
-          fac = ty == kRowQuad ? quadf : fac;
+          if constexpr (PROX) fac = ty == kRowQuad ? quadf : fac;
           real cap_ = ty == kRowBox ? lim4[r] : big_s;
           cap_ = ty == kRowPeak ? pk_lane : cap_;
           const real zn = fmin(zh_ * fac, cap_);
           y2[4 * m + r] = rho * (zh_ - zn);
           z2[4 * m + r] = zn;
+        }
+      }
+      // ---- demand charge: prox of dc * max(max_t z_t, floor) over the whole horizon of the "max" row: z_t = min(zh_t, tau),
+      // tau = max(floor, root of sum_t (zh_t - tau)+ = dc / rho) (Newton on a convex piecewise-linear function).  The row's
+      // periods are the 16 lanes of a DPP row -- times the waves of the group: its sums cross the mailbox like a session's.
+      if (PROX && A.dc != nullptr && dcb > 0.0) {   // wave-uniform
+        real zv = 0;
+        bool mine = false;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          int rty[4];
+          row_types(m, rty);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (rty[r] == kRowMax) { mine = true; zv = z2[4 * m + r]; }   // = zh of that row (left unprojected above)
+        }
+        const bool live = (tc < TS) & (tb + tc < Tm);
+        const real cw = dcb * inv_rho;
+        real vmax = row_max<real>((mine & live) ? zv : -BIGC), vdummy = 0;
+        pl_minmax(vdummy, vmax);
+        real tau = tau_max;
+        bool need = mine;
+        int guard = 0;
+        while (__any(need)) {
+          ++guard;
+          const real dd = zv - tau;
+          const bool on = live & (dd > 0.0);
+          real S = row_sum<real>(on ? dd : 0.0);
+          real nr = (real)row_sum<float>(on ? 1.f : 0.f);
+          pl_sum2(S, nr);
+          const float nn = (float)nr;
+          const real f = S - cw;
+          const real tn = nn > 0.f ? tau + f * rcp_small(nn) : vmax - cw;
+          const bool fin = (fabs(f) <= M::proj_tol * fmax(1.0, cw) * 16.0) | (tn == tau) | (guard > 60);
+          tau = (need & !fin) ? tn : tau;
+          need = need & !fin;
+        }
+        tau_max = tau;
+        const real lev = fmax(tau, dfl);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          int rty[4];
+          row_types(m, rty);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (rty[r] == kRowMax) {
+              const real zh_ = z2[4 * m + r];
+              const real zn = live ? fmin(zh_, lev) : zh_;
+              y2[4 * m + r] = rho * (zh_ - zn);
+              z2[4 * m + r] = zn;
+            }
         }
       }
     });

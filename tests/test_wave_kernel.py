@@ -31,13 +31,14 @@ def _both(tmp_path, name):
 @pytest.mark.parametrize("name", ["soc", "linear", "equality", "short", "site30", "peak", "general_windows",
                                   "h24", "h18_linear", "h24_equality", "h20_windows",
                                   "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_h24", "mt2_h17", "mt2_t4", "h13",
-                                  "h48", "h36_linear", "h40_equality", "flat_linear", "flat_soc", "flat_h24"])
+                                  "h48", "h36_linear", "h40_equality", "flat_linear", "flat_soc", "flat_h24",
+                                  "dc_linear", "dc_soc", "dc_h24"])
 def test_wave_kernel_agrees_with_the_tiled_kernel(tmp_path, name):
     """Same statuses, schedules within the rate tolerance, iteration counts that differ only where rounding moved a
     residual check (the two kernels sum in different orders): feasible shapes the wave kernel routes -- SOC and LINEAR
     rows, energy equalities, a short horizon with minimum rates, a 30-EVSE site, a peak row, windows that start late;
     and horizons 13 ... 24, where TWO waves share a problem (twelve periods each) and exchange the sums that cross the
-    halves through an LDS mailbox; and sites of 17 ... 32 rows (two row tiles), where the two waves hold six periods each; and load_flattening's prox row."""
+    halves through an LDS mailbox; and sites of 17 ... 32 rows (two row tiles), where the two waves hold six periods each; and the prox rows of load_flattening and demand_charge."""
     w, t = _both(tmp_path, name)
     assert np.array_equal(w["status"], t["status"]), (w["status"], t["status"])
     assert (w["status"] == 1).all()

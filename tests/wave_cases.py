@@ -14,7 +14,7 @@ if ROOT not in sys.path:
 
 CASES = ("soc", "linear", "equality", "short", "site30", "peak", "infeasible", "empty_set", "warm", "general_windows", "stalled",
          "h24", "h18_linear", "h24_equality", "h20_windows", "h24_infeasible", "h24_warm",
-         "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_warm", "mt2_infeasible", "mt2_h24", "mt2_h17", "mt2_t4", "h13", "h48", "h36_linear", "h40_equality", "flat_linear", "flat_soc", "flat_h24")
+         "mt2_site36", "mt2_site64", "mt2_short", "mt2_equality", "mt2_warm", "mt2_infeasible", "mt2_h24", "mt2_h17", "mt2_t4", "h13", "h48", "h36_linear", "h40_equality", "flat_linear", "flat_soc", "flat_h24", "dc_linear", "dc_soc", "dc_h24")
 
 
 def build(name):
@@ -27,6 +27,14 @@ def build(name):
     iface = Interface({"infrastructure_info": infra, "period": 5})
     obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
     rng = np.random.default_rng(9100)
+    if name.startswith("dc_"):     # demand_charge: the horizon-wide prox of the "max" row (its sums cross the waves of a group)
+        from adacharge_amd import demand_charge, total_energy
+
+        T = 24 if name == "dc_h24" else 12
+        diface = Interface({"infrastructure_info": infra, "period": 5, "demand_charge": 15.0, "prev_peak": 50.0})
+        dobj = [ObjectiveComponent(total_energy, 20.0), ObjectiveComponent(demand_charge), ObjectiveComponent(equal_share, 1e-3)]
+        ct = "LINEAR" if name == "dc_linear" else "SOC"
+        return build_batch(sites.snapshot_batch(infra, T, 96, seed=961 + T), infra, diface, dobj, ct), {}, {}
     if name.startswith("flat_"):   # load_flattening: the prox row of the aggregate power (one more site row; SOC: two row tiles)
         from adacharge_amd import load_flattening, total_energy
 
