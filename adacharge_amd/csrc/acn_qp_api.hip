@@ -807,6 +807,7 @@ static long long workspace_doubles(const acnqp_handle* h, int t_max, int k_sessi
 int32_t acnqp_accel_columns(acnqp_handle* h, int32_t t_max, int32_t k_sessions, int32_t precision, int32_t requested) {
   if (!h || t_max < 1 || k_sessions < 1 || requested <= 0) return 0;
   if (precision != 64) return 0;
+  if (acnqp::wave_shape(h->N, t_max, k_sessions, h->dev64.MR, h->has_max, 1 << 30) > 0) return std::min(requested, acnqp::wave_accel_columns());
   if (!tiled_shape(h, t_max, k_sessions)) {
     if (stream_shape(h, t_max)) return std::min(requested, acnqp::kStreamAccelMax);   // ring in its workspace
     if (long_shape(h, t_max, k_sessions)) return std::min(requested, acnqp::kLongAccelMax);   // ring in its workspace

@@ -94,11 +94,12 @@ inline int launch_grid(Kern kern, int threads, size_t lds, const TiledArgs& a) {
 // register-resident kernel (acn_qp_tiled.hpp): N <= 64, one / two column tiles; a.accel_mem = columns requested
 hipError_t launch_tiled_ct1(const TiledArgs& a, hipStream_t st);
 hipError_t launch_tiled_ct2(const TiledArgs& a, hipStream_t st);
-// wave-per-problem kernel (acn_qp_wave.hpp): the shapes of launch_tiled_ct1 with horizon <= 12, one session slot, one row
-// tile and no prox row (the headline shape); wave_shape says whether a launch is routed to it (by shape; `batch` only
-// for the diagnostic ACNQP_WAVE_MIN_BATCH)
-int wave_shape(int N, int t_max, int k_sessions, int MR, bool has_max, int batch);   // waves per problem; 0: not routed
+// wave-per-problem kernel (acn_qp_wave.hpp): N <= 64, one session slot, horizon <= 24 with one or two row tiles or 33 ... 48
+// with one; wave_shape says which variant a launch is routed to (0: none; by shape -- `batch` only for the diagnostic
+// ACNQP_WAVE_MIN_BATCH)
+int wave_shape(int N, int t_max, int k_sessions, int MR, bool has_max, int batch);
 hipError_t launch_wave(const TiledArgs& a, hipStream_t st);
+int wave_accel_columns();   // Anderson columns compiled into it
 // large-site kernel (acn_qp_stream.hpp)
 hipError_t launch_stream(const StreamArgs& sa, hipStream_t st);
 // long-horizon kernel (acn_qp_long.hpp); lds_resident: its LDS-resident variant for two column tiles x two row tiles

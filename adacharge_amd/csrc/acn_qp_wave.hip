@@ -68,6 +68,8 @@ static hipError_t launch_wave_npw(const TiledArgs& a, hipStream_t st) {
   return a.lf != nullptr || a.dc != nullptr ? launch_wave_prox<NPW, TSV, MT, true>(a, st) : launch_wave_prox<NPW, TSV, MT, false>(a, st);
 }
 
+int wave_accel_columns() { return kWaveAM; }
+
 hipError_t launch_wave(const TiledArgs& a, hipStream_t st) {
   if (a.MR == 32) return a.Tm <= kWaveTS ? launch_wave_npw<2, 6, 2>(a, st) : launch_wave_npw<4, 6, 2>(a, st);
   if (a.Tm > 2 * kWaveTS) return launch_wave_npw<4, 12, 1>(a, st);
