@@ -1316,13 +1316,23 @@ int run_table_pipeline(acnqp_handle* h, const acnqp_table* T, const acnqp_option
 }  // namespace
 
 int acnqp_solve_table(acnqp_handle* h, const acnqp_table* t, const acnqp_options* o, acnqp_results* r) {
+  const auto tcheck0 = std::chrono::steady_clock::now();
   const int rc0 = check_table(h, t, o, r);
   if (rc0 != ACNQP_OK) return rc0;
   if (t->batch == 0) return ACNQP_OK;
   HIP_TRY(hipSetDevice(h->device));
+  static const bool trace = std::getenv("ACNQP_TRACE") != nullptr;   // diagnostic: check / enqueue / whole call, on stderr
+  const auto tc0 = std::chrono::steady_clock::now();
   const int rc = run_table_pipeline(h, t, o, r);
+  const auto tc1 = std::chrono::steady_clock::now();
   hipError_t e = hipSuccess;   // drain every slot before returning, also on failure: nothing may touch the caller's buffers afterwards
   for (auto& sl : h->slot) { const hipError_t e1 = hipStreamSynchronize(sl.st); if (e == hipSuccess) e = e1; }
+  if (trace) {
+    const auto tc2 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[acnqp] solve_table: check %.3f ms, enqueue %.3f ms, drained after %.3f ms\n",
+                 std::chrono::duration<double, std::milli>(tc0 - tcheck0).count(), std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
+                 std::chrono::duration<double, std::milli>(tc2 - tc0).count());
+  }
   if (rc != ACNQP_OK) return rc;
   if (e != hipSuccess) return fail(ACNQP_ERR_HIP, std::string("acnqp_solve_table: ") + hipGetErrorString(e));
   for (int b = 0; b < t->batch; ++b)
