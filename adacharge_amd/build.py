@@ -107,7 +107,8 @@ def build_hip_library(force: bool = False, verbose: bool = True, extra_flags=(),
             store_hazard.write_stamp(out, "skipped")
             return out
         try:
-            stores, found = store_hazard.scan_library(out)
+            spills = []
+            stores, found = store_hazard.scan_library(out, spills)
         except store_hazard.ScannerUnavailable as e:
             os.replace(out, out + ".rejected")
             raise RuntimeError(f"store-data hazard scan cannot run ({e}); the scan is the only protection against the gfx950 "
@@ -121,6 +122,13 @@ def build_hip_library(force: bool = False, verbose: bool = True, extra_flags=(),
             raise RuntimeError(f"{len(found)} buffer stores of more than 64 bits are followed by a VALU write of their data "
                                f"registers (gfx950 store-data hazard, DESIGN.md section 3.6); library kept as {out}.rejected\n"
                                + store_hazard.describe(found))
+        if verbose:
+            print(f"[build] spill scan: {len(spills)} register spills / reloads ahead of an exec restore", flush=True)
+        if spills:
+            os.replace(out, out + ".rejected")
+            raise RuntimeError(f"{len(spills)} register spills / reloads sit before the exec restore of a join block (stored or "
+                               f"loaded with the lanes of the finished region only: store_hazard.scan_exec_spills); library "
+                               f"kept as {out}.rejected\n" + "\n".join(f"  {k[:100]}\n    {l}" for k, l in spills[:8]))
     return out
 
 

@@ -57,17 +57,32 @@ struct WsRef32 {
   __device__ inline void operator=(float v) const { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, vo, so, 0); }
 };
 
+// lane-offset flag of a workspace access that must not happen: beyond num_records of any problem's descriptor (a few
+// MB), so the buffer unit answers a load with zeros and drops a store without touching memory
+#ifndef ACNQP_LONG_PAD_SKIP
+#define ACNQP_LONG_PAD_SKIP 1
+#endif
+constexpr unsigned kWsKill = ACNQP_LONG_PAD_SKIP ? 0x80000000u : 0u;
+#ifndef ACNQP_LONG_FLAT_BOUNDS
+#define ACNQP_LONG_FLAT_BOUNDS 1
+#endif
 constexpr int kLongAccelMax = 5;
 #ifndef ACNQP_LONG_PAIR_ROWS
 #define ACNQP_LONG_PAIR_ROWS 9
 #endif
 constexpr int kLongPairRows = ACNQP_LONG_PAIR_ROWS;   // longest row (column tiles) whose two paired rows fit the registers   // Anderson columns (the ring lives in the workspace: any shape takes all five)
 
+// Compressed bounds of a row item (two register rows x 64 lanes): per row and lane one (l, u) pair of doubles, and per
+// lane the two rows' period masks -- 40 bytes per lane instead of 2 x 2 x CTL x 8 (see `flat items` in the kernel)
+constexpr int kLongFlatRows = 256;   // rows (of 4 EVSEs) whose flags fit the LDS table: sites of up to 1,024 EVSEs
+__host__ __device__ inline long long long_flat_doubles(int NP) { return (long long)(NP / 16) * 640; }
+
 // doubles of workspace one problem needs (accel = Anderson columns in use)
 __host__ __device__ inline long long long_workspace(int NP, int CTL, int K, int MT, int accel) {
   const long long NT = (long long)(NP / 16) * CTL * 256, MS = (long long)MT * CTL * 256;
   long long w = 7 * NT + (long long)K * NP + 3 * MS + (NT + MS + 1) / 2 + 64;   // + the certificate's dual snapshot (floats)
   if (accel > 0) w += MS + 3 * (NT + MS) + (2LL * accel * (NT + MS) * 4 + 7) / 8;   // zhr; u, f, g; the float rings
+  w += long_flat_doubles(NP);   // the compressed bounds of the row items (at the END of the workspace)
   return w;
 }
 
@@ -89,6 +104,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   __shared__ real AaHS[NWV * (AMX * AMX + AMX)];
   __shared__ real RowLam[16 * MT], RowLim[16 * MT], RowDj[16 * MT];   // per padded site row: eigenvalue, limit, rho / (a + rho lam)
   __shared__ int RowTy[16 * MT];
+  __shared__ unsigned char RowFlat[kLongFlatRows];   // per register row (4 EVSEs x the horizon): its bounds compress
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   real* EH = reinterpret_cast<real*>(smem_raw);   // e^ [MT][CTL][4][64]
   real* HH = EH + MT * CTL * 256;                 // h^ (start: Ghat z1)
@@ -174,6 +190,15 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   const WsArr64 UP{ZHR.off + MS8}, FP{UP.off + DU * 8u}, GP{FP.off + DU * 8u};
   const WsArr32 HF{GP.off + DU * 8u};
   const WsArr32 HG{HF.off + (unsigned)aa_m * DU * 4u};
+  // Flat items.  The rate bounds of a session are two constants inside its window and zero outside (aco.py:45-73: min /
+  // max rates of the session, clipped to the EVSE's), so per lane the CTL (l, u) pairs of a row nearly always take ONE
+  // non-zero value: the init phase checks exactly that, lane by lane, and keeps (l, u) + a CTL-bit mask; phase 2 then
+  // rebuilds the bounds of a row item from 40 bytes per lane instead of streaming 2 x 2 x CTL x 8 -- bit for bit the
+  // same numbers.  An item with a lane that does not fit (per-period max_rates) streams its bounds as before.
+  constexpr bool kFlat = !LDSR && CTL <= kLongPairRows && ACNQP_LONG_FLAT_BOUNDS;
+  const bool flat_on = kFlat && 4 * NE <= kLongFlatRows;
+  const unsigned cblu = (unsigned)(SA.ws_per_problem - long_flat_doubles(NP)) * 8u;   // [item][row of the pair][lane] (l, u)
+  const unsigned cbm = cblu + (unsigned)NE * 4096u;                                   // [item][lane] two masks
   real* AaH = AaHS + wave * (AMX * AMX + AMX);   // this wave's copy of (H, b): every wave runs the small solve itself
   const real* FG = static_cast<const real*>(A.fragG2);   // pair order: a 16-byte load per lane fetches two k-slices
   const real* FQ = static_cast<const real*>(A.fragQ2);
@@ -216,25 +241,28 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   };
   // two adjacent registers (2 rp, 2 rp + 1; uo = fidx / sidx2 of the even one) in one 16-byte access (float arrays:
   // 8-byte, widened to / rounded from double exactly as the single-element accessor does)
-  auto ld2 = [&](auto base, unsigned uo, real& a, real& b) __attribute__((always_inline)) {
+  // kill (wave-uniform, 0 or kWsKill): a workspace access whose lane offset carries kWsKill is out of the descriptor's
+  // range -- the load returns zeros and the store is dropped, neither touches memory.  The tile phases pass it for a
+  // register pair whose eight EVSEs are all padding (their state is zero and stays zero); LDS-resident arrays ignore it.
+  auto ld2 = [&](auto base, unsigned uo, real& a, real& b, unsigned kill = 0u) __attribute__((always_inline)) {
     typedef decltype(base) B;
     if constexpr (std::is_same<B, WsArr64>::value) {
-      const ws_d2 d = __builtin_bit_cast(ws_d2, __builtin_amdgcn_raw_buffer_load_b128(wsr, (unsigned)lane * 16u, base.off + uo * 8u, 0));
+      const ws_d2 d = __builtin_bit_cast(ws_d2, __builtin_amdgcn_raw_buffer_load_b128(wsr, ((unsigned)lane * 16u) | kill, base.off + uo * 8u, 0));
       a = d.x; b = d.y;
     } else if constexpr (std::is_same<B, WsArr32>::value) {
-      const ws_f2 d = __builtin_bit_cast(ws_f2, __builtin_amdgcn_raw_buffer_load_b64(wsr, (unsigned)lane * 8u, base.off + uo * 4u, 0));
+      const ws_f2 d = __builtin_bit_cast(ws_f2, __builtin_amdgcn_raw_buffer_load_b64(wsr, ((unsigned)lane * 8u) | kill, base.off + uo * 4u, 0));
       a = d.x; b = d.y;
     } else {   // LDS-resident state (doubles)
       const ws_d2 d = *reinterpret_cast<const ws_d2*>(reinterpret_cast<const char*>(base + uo) + (unsigned)lane * 16u);
       a = d.x; b = d.y;
     }
   };
-  auto st2 = [&](auto base, unsigned uo, real a, real b) __attribute__((always_inline)) {
+  auto st2 = [&](auto base, unsigned uo, real a, real b, unsigned kill = 0u) __attribute__((always_inline)) {
     typedef decltype(base) B;
     if constexpr (std::is_same<B, WsArr64>::value) {
       const ws_d2 d = {a, b};
       const ws_v4u q4 = __builtin_bit_cast(ws_v4u, d);
-      __builtin_amdgcn_raw_buffer_store_b128(q4, wsr, (unsigned)lane * 16u, base.off + uo * 8u, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(q4, wsr, ((unsigned)lane * 16u) | kill, base.off + uo * 8u, 0);
       // gfx950 store-data hazard: a buffer store of more than 64 bits per lane reads its data registers over several
       // cycles, and a VALU write to them in the next two issue slots changes what the last lanes (12..15 of each DPP
       // row) store.  LLVM inserts the wait states for such stores EXCEPT when soffset is a register
@@ -247,21 +275,24 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
 #endif
     } else if constexpr (std::is_same<B, WsArr32>::value) {
       const ws_f2 d = {(float)a, (float)b};
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ws_v2u, d), wsr, (unsigned)lane * 8u, base.off + uo * 4u, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ws_v2u, d), wsr, ((unsigned)lane * 8u) | kill, base.off + uo * 4u, 0);
     } else {
       const ws_d2 d = {a, b};
       *reinterpret_cast<ws_d2*>(reinterpret_cast<char*>(base + uo) + (unsigned)lane * 16u) = d;
     }
   };
   // the four registers of a tile (uo = fidx / sidx2 of register 0)
-  auto ld4 = [&](auto base, unsigned uo, real (&v)[4]) __attribute__((always_inline)) {
+  // (kill2: the kill flag of the SECOND pair, registers 2 and 3 = rows 8 .. 15 of the tile)
+  auto ld4 = [&](auto base, unsigned uo, real (&v)[4], unsigned kill2 = 0u) __attribute__((always_inline)) {
     ld2(base, uo, v[0], v[1]);
-    ld2(base, uo + 128u, v[2], v[3]);
+    ld2(base, uo + 128u, v[2], v[3], kill2);
   };
-  auto st4 = [&](auto base, unsigned uo, const real (&v)[4]) __attribute__((always_inline)) {
+  auto st4 = [&](auto base, unsigned uo, const real (&v)[4], unsigned kill2 = 0u) __attribute__((always_inline)) {
     st2(base, uo, v[0], v[1]);
-    st2(base, uo + 128u, v[2], v[3]);
+    st2(base, uo + 128u, v[2], v[3], kill2);
   };
+  // rows 8 .. 15 of EVSE tile e are all padding (54 EVSEs: rows 56 .. 63 of tile 3): their pair is not streamed
+  auto pad2 = [&](int e) -> unsigned { return 16 * e + 8 >= N ? kWsKill : 0u; };
   // the four k-slices of one 4 x 64 fragment block of the site matrices (pair order: two 16-byte loads)
   auto ldf4 = [&](const real* blk, real (&v)[4]) __attribute__((always_inline)) {
 #pragma unroll
@@ -293,6 +324,32 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       const unsigned i = fidx(e, c, r);
       at(LBs, i) = l; at(UBs, i) = u; at(Qs, i) = q;
       qn = fmax(qn, fabs(q)); um = fmax(um, u);
+    }
+    if constexpr (kFlat) {
+      if (flat_on) {   // (block-uniform)
+        real L = lbv[0], U = ubv[0];
+#pragma unroll
+        for (int c = 1; c < CTL; ++c) {   // the pair with the largest u (then l): the candidate "on" value of this lane
+          const bool up = ubv[c] > U || (ubv[c] == U && lbv[c] > L);
+          L = up ? lbv[c] : L; U = up ? ubv[c] : U;
+        }
+        auto bits = [](real v) -> long long { return __builtin_bit_cast(long long, v); };
+        unsigned mk = 0; bool okl = true;
+#pragma unroll
+        for (int c = 0; c < CTL; ++c) {
+          // (bit patterns, not values: the rebuilt bounds are the stored ones to the last bit, signed zeros included)
+          const bool on = bits(lbv[c]) == bits(L) && bits(ubv[c]) == bits(U), off = bits(lbv[c]) == 0 && bits(ubv[c]) == 0;
+          okl = okl && (on || off);
+          mk |= on && !off ? 1u << c : 0u;
+        }
+        const int pi = ri >> 1, hr = ri & 1;
+        const unsigned o = cblu + (unsigned)(pi * 2 + hr) * 1024u;
+        WsRef64{wsr, (unsigned)lane * 16u, o} = L;
+        WsRef64{wsr, (unsigned)lane * 16u, o + 8u} = U;
+        __builtin_amdgcn_raw_buffer_store_b32(mk, wsr, (unsigned)lane * 8u, cbm + (unsigned)pi * 512u + (unsigned)hr * 4u, 0);
+        const bool okrow = __builtin_amdgcn_ballot_w64(!okl) == 0;
+        if (lane == 0) RowFlat[ri] = okrow ? 1 : 0;   // read after the barriers of the block maximum below
+      }
     }
 #pragma unroll 1
     for (int k = 0; k < K; ++k) {
@@ -727,8 +784,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         const int qe = q - n_site;
         const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
         const real* fg = FGi + (size_t)e * MT * 2 * 4 * 64;
+        const unsigned kl = pad2(e);
         real rv[4], xv[4], zv[4], yv[4], fx[MT][4], ev4[MT][4];
-        ld4(RZ, fidx(e, c, 0), rv); ld4(Xs, fidx(e, c, 0), xv); ld4(Z1s, fidx(e, c, 0), zv); ld4(Y1s, fidx(e, c, 0), yv);
+        ld4(RZ, fidx(e, c, 0), rv, kl); ld4(Xs, fidx(e, c, 0), xv, kl); ld4(Z1s, fidx(e, c, 0), zv, kl); ld4(Y1s, fidx(e, c, 0), yv, kl);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           ld4(EH, sidx2(m, c, 0), ev4[m]);
@@ -747,8 +805,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
           zo4[r] = alpha * xn + (1.0 - alpha) * zv[r] + yv[r] * inv_rho;
           xo4[r] = alpha * xn + (1.0 - alpha) * xv[r];
         }
-        st4(RZ, fidx(e, c, 0), zo4);
-        st4(Xs, fidx(e, c, 0), xo4);
+        st4(RZ, fidx(e, c, 0), zo4, kl);
+        st4(Xs, fidx(e, c, 0), xo4, kl);
       }
     }
     STAMP(2);   // 1b
@@ -761,13 +819,13 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
 #pragma unroll
       for (int j = 0; j < AMX + 2; ++j) d[j] = 0;
       // four registers of one tile: g = zsrc[zo + 64 r], state index uo + 64 r
-      auto aa_tile = [&](auto zsrc, unsigned zo, unsigned uo) __attribute__((always_inline)) {
+      auto aa_tile = [&](auto zsrc, unsigned zo, unsigned uo, unsigned kl) __attribute__((always_inline)) {
         real gv[4], uv[4], fpv[4], gpv[4], hv[AMX][4], cqv[4], cgv[4], fv[4];
-        ld4(zsrc, zo, gv); ld4(UP, uo, uv); ld4(FP, uo, fpv); ld4(GP, uo, gpv);
+        ld4(zsrc, zo, gv, kl); ld4(UP, uo, uv, kl); ld4(FP, uo, fpv, kl); ld4(GP, uo, gpv, kl);
         // every ring column is requested, live or not (a branch per column puts each load in a basic block of its own:
         // five dependent memory round trips per tile instead of one); a dead column's data is replaced by zeros
 #pragma unroll
-        for (int j = 0; j < AMX; ++j) ld4(HF + (size_t)(j < aa_m ? j : aa_m - 1) * DU, uo, hv[j]);
+        for (int j = 0; j < AMX; ++j) ld4(HF + (size_t)(j < aa_m ? j : aa_m - 1) * DU, uo, hv[j], kl);
 #pragma unroll
         for (int j = 0; j < AMX; ++j) {
           const bool live = ((aa_valid >> j) & 1u) && j != slot;   // uniform
@@ -784,19 +842,19 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
           for (int j = 0; j < AMX; ++j) d[j] += (real)cq * (j == slot ? (real)cq : hv[j][r]);
           d[AMX] += (real)cq * f;
         }
-        if (col) { st4(HF + (size_t)slot * DU, uo, cqv); st4(HG + (size_t)slot * DU, uo, cgv); }
-        st4(FP, uo, fv); st4(GP, uo, gv);
+        if (col) { st4(HF + (size_t)slot * DU, uo, cqv, kl); st4(HG + (size_t)slot * DU, uo, cgv, kl); }
+        st4(FP, uo, fv, kl); st4(GP, uo, gv, kl);
       };
 #pragma unroll 1
       for (int q = wave; q < n_tile; q += NWV) {
         RELANE();
         if (q < n_site) {
           const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
-          aa_tile(ZHR, sidx2(mo, c, 0), (unsigned)NT + sidx2(mo, c, 0));
+          aa_tile(ZHR, sidx2(mo, c, 0), (unsigned)NT + sidx2(mo, c, 0), 0u);
         } else {
           const int qe = q - n_site;
           const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
-          aa_tile(RZ, fidx(e, c, 0), fidx(e, c, 0));
+          aa_tile(RZ, fidx(e, c, 0), fidx(e, c, 0), pad2(e));
         }
       }
 #pragma unroll
@@ -874,12 +932,12 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         aa_was = true;
       }
       // ---- apply: u = g - sum_j gamma_j dG_j; the site rows are projected from their (extrapolated) point -------
-      auto aa_apply = [&](auto zdst, unsigned zo, unsigned uo, real (&out)[4]) __attribute__((always_inline)) {
+      auto aa_apply = [&](auto zdst, unsigned zo, unsigned uo, real (&out)[4], unsigned kl) __attribute__((always_inline)) {
         real hv[AMX][4];
-        ld4(zdst, zo, out);
+        ld4(zdst, zo, out, kl);
         if (ext) {
 #pragma unroll
-          for (int j = 0; j < AMX; ++j) ld4(HG + (size_t)(j < aa_m ? j : aa_m - 1) * DU, uo, hv[j]);   // one batch, as in aa_tile
+          for (int j = 0; j < AMX; ++j) ld4(HG + (size_t)(j < aa_m ? j : aa_m - 1) * DU, uo, hv[j], kl);   // one batch, as in aa_tile
 #pragma unroll
           for (int j = 0; j < AMX; ++j) {
             const bool live = (aa_valid >> j) & 1u;   // uniform
@@ -887,7 +945,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
             for (int r = 0; r < 4; ++r) out[r] -= gam[j] * (live ? hv[j][r] : 0.0);
           }
         }
-        st4(UP, uo, out);
+        st4(UP, uo, out, kl);
       };
 #pragma unroll 1
       for (int q = wave; q < n_tile; q += NWV) {
@@ -895,15 +953,15 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         if (q < n_site) {
           const int mo = __builtin_amdgcn_readfirstlane(q / nct), c = q - mo * nct;
           real zhr[4], gxn[4];
-          aa_apply(ZHR, sidx2(mo, c, 0), (unsigned)NT + sidx2(mo, c, 0), zhr);
+          aa_apply(ZHR, sidx2(mo, c, 0), (unsigned)NT + sidx2(mo, c, 0), zhr, 0u);
           ld4(GX, sidx2(mo, c, 0), gxn);
           site_project(mo, c, zhr, gxn, quad);
         } else {
           const int qe = q - n_site;
           const int e = __builtin_amdgcn_readfirstlane(qe / nct), c = qe - e * nct;
           real o4[4];
-          aa_apply(RZ, fidx(e, c, 0), fidx(e, c, 0), o4);
-          if (ext) st4(RZ, fidx(e, c, 0), o4);
+          aa_apply(RZ, fidx(e, c, 0), fidx(e, c, 0), o4, pad2(e));
+          if (ext) st4(RZ, fidx(e, c, 0), o4, pad2(e));
         }
       }
     }
@@ -923,10 +981,25 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
         // on the Caltech-shaped site, where the kernel is bandwidth-bound at 2,048 problems (block-uniform per wave)
         if (16 * e + 4 * r0_ >= N) continue;
         real zh2[2][CTL], lb2[2][CTL], ub2[2][CTL], z1p[2][CTL];
+        bool flat = false;
+        if constexpr (kFlat) flat = flat_on && __builtin_amdgcn_readfirstlane((int)RowFlat[2 * pi] & (int)RowFlat[2 * pi + 1]) != 0;
+        if (flat) {
+          const ws_d2 lu0 = __builtin_bit_cast(ws_d2, __builtin_amdgcn_raw_buffer_load_b128(wsr, (unsigned)lane * 16u, cblu + (unsigned)pi * 2048u, 0));
+          const ws_d2 lu1 = __builtin_bit_cast(ws_d2, __builtin_amdgcn_raw_buffer_load_b128(wsr, (unsigned)lane * 16u, cblu + (unsigned)pi * 2048u + 1024u, 0));
+          const ws_v2u mk = __builtin_amdgcn_raw_buffer_load_b64(wsr, (unsigned)lane * 8u, cbm + (unsigned)pi * 512u, 0);
 #pragma unroll
-        for (int c = 0; c < CTL; ++c) {   // padding columns hold zeros and stay zero
-          const unsigned i = fidx(e, c, r0_);
-          ld2(RZ, i, zh2[0][c], zh2[1][c]); ld2(LBs, i, lb2[0][c], lb2[1][c]); ld2(UBs, i, ub2[0][c], ub2[1][c]);
+          for (int c = 0; c < CTL; ++c) {
+            ld2(RZ, fidx(e, c, r0_), zh2[0][c], zh2[1][c]);
+            const bool on0 = (mk.x >> c) & 1u, on1 = (mk.y >> c) & 1u;
+            lb2[0][c] = on0 ? lu0.x : 0.0; ub2[0][c] = on0 ? lu0.y : 0.0;
+            lb2[1][c] = on1 ? lu1.x : 0.0; ub2[1][c] = on1 ? lu1.y : 0.0;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < CTL; ++c) {   // padding columns hold zeros and stay zero
+            const unsigned i = fidx(e, c, r0_);
+            ld2(RZ, i, zh2[0][c], zh2[1][c]); ld2(LBs, i, lb2[0][c], lb2[1][c]); ld2(UBs, i, ub2[0][c], ub2[1][c]);
+          }
         }
         project_row(e, r0_, zh2[0], lb2[0], ub2[0], z1p[0], false);
         project_row(e, r0_ + 1, zh2[1], lb2[1], ub2[1], z1p[1], false);

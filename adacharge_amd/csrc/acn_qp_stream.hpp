@@ -53,10 +53,19 @@ struct StreamArgs {
 constexpr int kStreamAccelMax = 5;   // Anderson columns (the ring lives in the workspace)
 
 // doubles of workspace one problem needs (accel = Anderson columns in use)
+// Compressed bounds of an EVSE tile (`flat tiles` in the kernel; the long-horizon kernel's flat items, acn_qp_long.hpp):
+// per register row and lane one (l, u) pair of doubles, and per lane the 4 x CT period bits of its four rows
+#ifndef ACNQP_STREAM_FLAT_BOUNDS
+#define ACNQP_STREAM_FLAT_BOUNDS 1
+#endif
+constexpr int kStreamFlatTiles = 64;   // tiles whose flags fit the LDS table: sites of up to 1,024 EVSEs
+__host__ __device__ inline long long stream_flat_doubles(int NP) { return (long long)(NP / 16) * 544; }
+
 __host__ __device__ inline long long stream_workspace(int NP, int CT, int K, int MT, int accel) {
   const long long NT = (long long)(NP / 16) * CT * 256, MS = (long long)MT * CT * 256, DU = NT + MS;
   long long w = 6 * NT + (long long)K * NP + 3 * MS + (DU + 1) / 2 + 64;   // + the certificate's dual snapshot (floats)
   if (accel > 0) w += DU + 3 * DU + (2LL * accel * DU * 4 + 7) / 8;         // zh / zhr of the event; u, f, g; the float rings
+  w += stream_flat_doubles(NP);   // at the END of the workspace
   return w;
 }
 
@@ -110,6 +119,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
   constexpr int AMX = kStreamAccelMax;
   __shared__ real AaRedS[NWV * (AMX + 2)];               // per-wave partial dot products of an Anderson event
   __shared__ real AaHS[NWV * (AMX * AMX + AMX)];         // every wave's own copy of the Gram matrix and rhs
+  // Clearing a wave's copy: EVERY lane stores (the lanes beyond the 30 entries repeat the last one) -- no divergent
+  // region.  Behind the `if (lane < 30)` form the compiler (ROCm 7.2) placed the spill of two values that live across
+  // the solver loop BEFORE the exec restore of the region's end: stored with no lane enabled, reloaded as garbage (the
+  // reported objective lost its pdiag term; adacharge_amd/store_hazard.py scan_exec_spills now refuses such code).
+  static_assert(AMX * AMX + AMX <= 64, "one store per lane clears the Gram matrix and its right-hand side");
+  auto aa_clear_idx = []() -> int { const int l = (int)(threadIdx.x & 63); return l < AMX * AMX + AMX ? l : AMX * AMX + AMX - 1; };
   real* RED0 = sm + L.red;
   real* G0H = sm + L.g0h;
   real* WE = sm + L.we;
@@ -120,6 +135,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
   // through a per-pass opaque pointer to the kernarg segment: nothing of a pass is invariant across passes, so no
   // pass-invariant address, predicate or argument is kept alive across the solver loop.
   __shared__ int q_slot;
+  __shared__ unsigned char TileFlat[kStreamFlatTiles];   // per EVSE tile: its bounds compress (flat tiles, tile_back)
   for (int q_round = 0;; ++q_round) {   // work queue: this workgroup's next problem (queue_next, acn_qp_tiled.hpp)
   const int q_pos = queue_next(SA_kernarg.t.queue, queue_length(SA_kernarg.t), q_round, &q_slot);
   if (q_pos < 0) break;
@@ -212,6 +228,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
   // and spilled around them (416 bytes of scratch traffic per lane and tile against 864 useful, round 3).  The cold
   // paths (start, restart, residual check, certificate, output) keep the pointers; both name the same memory.
   const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(W0, 0, (int)(SA.ws_per_problem * 8), 0x00020000);
+  const bool flat_on = ACNQP_STREAM_FLAT_BOUNDS && NE <= kStreamFlatTiles;
+  const unsigned cblu = (unsigned)(SA.ws_per_problem - stream_flat_doubles(NP)) * 8u;   // [tile][row][lane] (l, u)
+  const unsigned cbm = cblu + (unsigned)NE * 4096u;                                     // [tile][lane] period bits
   constexpr int kNt = 2;   // gfx940+ cache policy bit 1 = nt: what __builtin_nontemporal_load / _store emit
   const unsigned oX = 0, oZ1 = (unsigned)NT, oY1 = 2 * (unsigned)NT, oQ = 3 * (unsigned)NT, oLB = 4 * (unsigned)NT, oUB = 5 * (unsigned)NT;
   auto fidp = [&](int e, int c, int rp) -> unsigned { return (unsigned)((e * CT + c) * 256 + rp * 128); };   // registers 2 rp, 2 rp + 1
@@ -274,6 +293,31 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
         LBs[fidx(e, c, r)] = l; UBs[fidx(e, c, r)] = u; Qs[fidx(e, c, r)] = q;
         qn = fmax(qn, fabs(q)); um = fmax(um, u);
       }
+    if (flat_on) {   // (block-uniform) flat tiles: see tile_back
+      auto bits = [](real v) -> long long { return __builtin_bit_cast(long long, v); };
+      unsigned mk = 0; bool okl = true;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        real L = lbv[0][r], U = ubv[0][r];
+#pragma unroll
+        for (int c = 1; c < CT; ++c) {   // the pair with the largest u (then l): the candidate "on" value of this lane's row
+          const bool up = ubv[c][r] > U || (ubv[c][r] == U && lbv[c][r] > L);
+          L = up ? lbv[c][r] : L; U = up ? ubv[c][r] : U;
+        }
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {   // bit patterns: the rebuilt bounds are the stored ones to the last bit
+          const bool on = bits(lbv[c][r]) == bits(L) && bits(ubv[c][r]) == bits(U), off = bits(lbv[c][r]) == 0 && bits(ubv[c][r]) == 0;
+          okl = okl && (on || off);
+          mk |= on && !off ? 1u << (r * CT + c) : 0u;
+        }
+        const unsigned o = cblu + (unsigned)(e * 4 + r) * 1024u;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ws_v2u_s, L), wsr, (unsigned)lane * 16u, o, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ws_v2u_s, U), wsr, (unsigned)lane * 16u, o + 8u, 0);
+      }
+      __builtin_amdgcn_raw_buffer_store_b32(mk, wsr, (unsigned)lane * 4u, cbm + (unsigned)e * 256u, 0);
+      const bool oktile = __builtin_amdgcn_ballot_w64(!okl) == 0;
+      if (lane == 0) TileFlat[e] = oktile ? 1 : 0;   // read after the barriers of the block maximum below
+    }
 #pragma unroll 1
     for (int k = 0; k < K; ++k)
 #pragma unroll
@@ -607,7 +651,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
   real fn_prev = 0;
   real* AaH = AaHS + (size_t)wave * (AMX * AMX + AMX);
   if (aa_m > 0)
-    for (int k = lane; k < AMX * AMX + AMX; k += 64) AaH[k] = 0;
+    AaH[aa_clear_idx()] = 0;
   real sv0 = 0, sv2 = 0;   // |G x - z2|_inf, max(|G x|, |z2|): the site-row share of the residuals, per iteration
 
   // ---- projection of one site-row tile onto C from its pre-projection point: z2, y2, the tile's residual terms ------
@@ -736,7 +780,26 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
     // the bounds and session slots of all four register rows are requested at once: one memory round trip per tile
     // instead of four + four.  (Requesting them BEFORE tile_front, under its loads and MFMA chain, was measured too:
     // 468 -> 507 ms on the configs[4] leg -- the 64 registers they pin spill the front.)
+    // Flat tiles.  The rate bounds of a session are two constants inside its window and zero outside (aco.py:45-73), so
+    // per lane the CT (l, u) pairs of a row nearly always take ONE non-zero value: the init phase checks exactly that and
+    // keeps (l, u) per row + one word of period bits per lane; such a tile's bounds are rebuilt from 68 bytes per lane
+    // instead of streamed (2 x 4 x CT x 8) -- bit for bit the same numbers.  Any other tile streams them as before.
     real lb4[4][CT], ub4[4][CT];
+    const bool flat = flat_on && __builtin_amdgcn_readfirstlane((int)TileFlat[e]) != 0;
+    if (flat) {
+      ws_d2_s lu[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        lu[r] = __builtin_bit_cast(ws_d2_s, __builtin_amdgcn_raw_buffer_load_b128(wsr, (unsigned)lane * 16u, cblu + (unsigned)(e * 4 + r) * 1024u, 0));
+      const unsigned mk = __builtin_amdgcn_raw_buffer_load_b32(wsr, (unsigned)lane * 4u, cbm + (unsigned)e * 256u, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const bool on = (mk >> (r * CT + c)) & 1u;
+          lb4[r][c] = on ? lu[r].x : 0.0; ub4[r][c] = on ? lu[r].y : 0.0;
+        }
+    } else {
 #pragma unroll
     for (int rp = 0; rp < 2; ++rp)
 #pragma unroll
@@ -744,6 +807,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
         const unsigned i = fidp(e, c, rp);
         ld2_nt(oLB, i, lb4[2 * rp][c], lb4[2 * rp + 1][c]); ld2_nt(oUB, i, ub4[2 * rp][c], ub4[2 * rp + 1][c]);
       }
+    }
     Slot0 s4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) s4[r] = slot0_of(e, r);
@@ -1012,7 +1076,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
         // the accelerated step made the residual worse: clear the ring, back off exponentially
         aa_cnt = 0; aa_head = 0; aa_valid = 0; keep = false;
         __builtin_amdgcn_wave_barrier();
-        for (int k = lane; k < AMX * AMX + AMX; k += 64) AaH[k] = 0;
+        AaH[aa_clear_idx()] = 0;
         aa_cool = aa_pen;
         aa_pen = aa_pen < 64 ? 2 * aa_pen : 64;
       } else if (aa_cool > 0) --aa_cool;
@@ -1313,7 +1377,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
             reset_u();
             aa_cnt = 0; aa_head = 0; aa_valid = 0; aa_have_prev = false; aa_was = false;
             __builtin_amdgcn_wave_barrier();
-            for (int k = lane; k < AMX * AMX + AMX; k += 64) AaH[k] = 0;
+            AaH[aa_clear_idx()] = 0;
           }
         }
       }

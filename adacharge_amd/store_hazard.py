@@ -128,13 +128,75 @@ def scan_isa(text):
     return stores, found
 
 
+_EXEC_WRITE = re.compile(r"^s_\w+_saveexec_b64\b|^s_\w+\s+exec\b|^s_\w+\s+exec_(lo|hi)\b")
+_EXEC_BLIND = re.compile(r"^(v_writelane_b32\b|v_readlane_b32\b|s_nop\b|s_waitcnt\b|scratch_store_|scratch_load_)")
+
+
+def scan_exec_spills(text):
+    """[(kernel symbol, instruction)]: register spills / reloads (``scratch_store`` / ``scratch_load``) that sit at the
+    top of a join block BEFORE the ``s_or_b64 exec, exec, s[..]`` that restores the lanes of the divergent region which
+    ends there.  Round 4 found the compiler (ROCm 7.2 LLVM) doing this to values that live across the region: behind
+    ``if (lane < 30) for (...) AaH[k] = 0`` the large-site kernel spilled two block-uniform doubles with exec = 0 --
+    nothing was stored -- and the objective reported at the end was built from the slot's garbage.  The scan walks each
+    scratch access forward over instructions that do not depend on exec (SGPR spills by v_writelane, scalar ALU, waits);
+    reaching the exec restore before anything else, in a block that has not itself narrowed exec, is the pattern."""
+    ins = _parse(text)
+    leaders = set()
+    where = {}
+    for idx, (kind, l, addr, _) in enumerate(ins):
+        if kind == "ins" and addr is not None:
+            where[addr] = idx
+        elif kind == "local":
+            where[l] = idx
+    for idx, (kind, l, _, target) in enumerate(ins):
+        if kind != "ins":
+            leaders.add(idx + 1)
+            continue
+        if _BRANCH.match(l):
+            leaders.add(idx + 1)
+            if target in where:
+                leaders.add(where[target])
+    kern, found = "?", []
+    for idx, (kind, l, _, _) in enumerate(ins):
+        if kind == "label":
+            kern = l
+            continue
+        if kind != "ins" or not re.match(r"scratch_(store|load)", l):
+            continue
+        # back to the block leader: the block must not have narrowed exec itself before this access
+        j, own = idx - 1, False
+        while j >= 0 and ins[j][0] == "ins":
+            if _EXEC_WRITE.match(ins[j][1]):
+                own = True
+                break
+            if j in leaders:
+                break
+            j -= 1
+        if own:
+            continue
+        j = idx + 1
+        while j < len(ins) and ins[j][0] == "ins" and j not in leaders:
+            t = ins[j][1]
+            if re.match(r"^s_or_b64 exec, exec,", t):
+                found.append((kern, l))
+                break
+            if _BRANCH.match(t) or t.startswith("s_endpgm"):
+                break
+            if _EXEC_BLIND.match(t) or (t.startswith("s_") and not _EXEC_WRITE.match(t)):
+                j += 1
+                continue
+            break
+    return found
+
+
 class ScannerUnavailable(RuntimeError):
     """llvm-objdump is not where the ROCm image keeps it: the scan cannot run.  The build FAILS on this unless
     ACNQP_SKIP_HAZARD_SCAN=1 is set (the scan is the only protection against the hazard)."""
 
 
-def scan_library(path):
-    """Disassemble every gfx950 code object bundled in the shared library at ``path``; returns (stores, hazards)."""
+def scan_library(path, spills=None):
+    """Disassemble every gfx950 code object bundled in the shared library at ``path``; returns (stores, hazards).
+    ``spills``: a list that receives scan_exec_spills' findings for the same disassembly."""
     objdump = os.path.join(_LLVM_BIN, "llvm-objdump")
     if not os.path.exists(objdump):
         raise ScannerUnavailable(f"{objdump} not found")
@@ -155,6 +217,8 @@ def scan_library(path):
             s, f = scan_isa(d.stdout)
             stores += s
             found += f
+            if spills is not None:
+                spills += scan_exec_spills(d.stdout)
     return stores, found
 
 

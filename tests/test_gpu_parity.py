@@ -805,6 +805,39 @@ def test_long_horizon_kernel_matches_c_twin(site_name, T, ct, accel):
     h.close()
 
 
+@pytest.mark.parametrize("T", [96, 144])
+def test_long_horizon_kernel_bounds_that_do_not_compress(T):
+    """Round 4: a row item whose bounds are one (l, u) pair inside the windows and zero outside is rebuilt from 40 bytes
+    per lane instead of streamed (acn_qp_long.hpp, `flat items`).  Per-period maximum rates (aco.py:45-73 takes
+    session.max_rates as an array) do not fit that form: here every third period of half the EVSEs is derated and some
+    periods carry a minimum rate, so items of both kinds sit in one problem.  Plain ADMM must still follow the C twin
+    iteration for iteration -- a rebuilt bound that differed in one bit, or an item wrongly taken for flat, parts them."""
+    from adacharge_amd.acn import Interface
+    from oracle import admm_port
+
+    infra = sites.caltech54()
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-12)]
+    snaps = sites.snapshot_batch(infra, T, 4, seed=300 + T, demand_range=(5.0, 40.0))
+    batch = build_batch(snaps, infra, iface, obj, "SOC")
+    tt = np.arange(batch.ub.shape[2])
+    derate = np.where(tt % 3 == 0, 0.75, 1.0)
+    batch.ub[:, 0:54:2, :] *= derate                         # EVSEs 0, 2, 4 ...: not one value per lane any more
+    batch.lb[:, 1:20:4, :] = np.where(batch.ub[:, 1:20:4, :] > 0, 0.5 * (tt % 5 == 1), 0.0)   # a few minimum rates
+    batch.ub[:, 48:54, :] = np.where(batch.ub[:, 48:54, :] > 0, 16.0 + (tt % 7), 0.0)       # the partly padded tile
+    h = SiteHandle(batch.site, 0)
+    res = h.solve(batch, default_options(accel_mem=0))
+    ref = admm_port.solve_batch(batch, threads=4, accel_mem=0)
+    assert (res.status == ref["status"]).all() and (res.status == 1).all()
+    assert (res.iters == ref["iters"]).all()
+    assert np.abs(res.x - ref["x"]).max() <= 1e-6
+    assert (res.x <= batch.ub + 1e-9).all() and (res.x >= batch.lb - 1e-9).all()
+    # the same problems with the acceleration on: same optimum
+    acc = h.solve(batch, default_options())
+    assert (acc.status == 1).all() and np.abs(acc.obj - ref["obj"]).max() <= 2e-5 * np.abs(ref["obj"]).max()
+    h.close()
+
+
 def test_long_horizon_kernel_many_sessions_per_evse_and_warm_start():
     """K = 3 session slots per EVSE over 96 periods (multipliers of every slot live in the workspace), then the same
     batch warm-started from its own solution: fewer iterations, same optimum."""

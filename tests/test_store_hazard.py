@@ -56,6 +56,52 @@ _ZN5acnqp1kE:
     assert store_hazard.scan_isa(listing.replace("v_mov_b32 v45", "v_mov_b32 v55")) == (1, [])
 
 
+JOIN_SPILL = """
+_ZN5acnqp1kE:
+	s_and_saveexec_b64 s[10:11], s[12:13]
+	s_cbranch_execz .LBB0_3
+.LBB0_2:
+	ds_write_b64 v1, v[156:157]
+	s_andn2_b64 exec, exec, s[12:13]
+	s_cbranch_execnz .LBB0_2
+.LBB0_3:
+	v_writelane_b32 v253, s38, 34
+	scratch_store_dwordx2 off, v[154:155], off offset:148 ; 8-byte Folded Spill
+	scratch_store_dwordx2 off, v[152:153], off offset:140 ; 8-byte Folded Spill
+	v_writelane_b32 v253, s39, 35
+	s_or_b64 exec, exec, s[10:11]
+	s_mov_b32 s26, s87
+	s_endpgm
+"""
+
+
+def test_scanner_finds_a_spill_ahead_of_the_exec_restore():
+    """Round 4 (acn_qp_stream.hpp, aa_clear_idx): the compiler put the spill of two values that live across a divergent
+    region at the top of the region's join block, BEFORE `s_or_b64 exec, exec, ...` -- stored with no lane enabled.  The
+    listing is that block; the same spills behind the restore, or inside a region the block narrowed itself (a value of
+    the active lanes only), are fine."""
+    found = store_hazard.scan_exec_spills(JOIN_SPILL)
+    assert len(found) == 2 and all("scratch_store" in l for _, l in found) and found[0][0] == "_ZN5acnqp1kE"
+    after = JOIN_SPILL.replace("\ts_or_b64 exec, exec, s[10:11]\n", "").replace("\tv_writelane_b32 v253, s38, 34\n", "\tv_writelane_b32 v253, s38, 34\n\ts_or_b64 exec, exec, s[10:11]\n")
+    assert store_hazard.scan_exec_spills(after) == []
+    own = JOIN_SPILL.replace(".LBB0_3:\n", ".LBB0_3:\n\ts_and_saveexec_b64 s[10:11], vcc\n")
+    assert store_hazard.scan_exec_spills(own) == []
+    reload_ = JOIN_SPILL.replace("scratch_store_dwordx2 off, v[154:155], off offset:148", "scratch_load_dwordx2 v[154:155], off, off offset:148")
+    assert len(store_hazard.scan_exec_spills(reload_)) == 2
+    valu_between = JOIN_SPILL.replace("\tv_writelane_b32 v253, s39, 35\n", "\tv_mov_b32 v1, 0\n")
+    assert store_hazard.scan_exec_spills(valu_between) == []   # not the prologue of a join block: something else's business
+
+
+def test_built_library_has_no_spill_ahead_of_an_exec_restore(hip_library):
+    spills = []
+    try:
+        store_hazard.scan_library(backend.library_path(), spills)
+    except store_hazard.ScannerUnavailable as e:
+        import pytest
+        pytest.skip(str(e))
+    assert not spills, spills[:8]
+
+
 def test_loaded_library_was_scanned_by_the_build(hip_library):
     """The build writes what its scan saw next to the library; a library built with the scan skipped (or by hand) does
     not pass."""
