@@ -14,9 +14,13 @@ sys.path.insert(0, ROOT)
 from adacharge_amd import store_hazard  # noqa: E402
 
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "adacharge_amd", "lib", "libacn_qp_hip.so")
-stores, found = store_hazard.scan_library(path)
+spills = []
+stores, found = store_hazard.scan_library(path, spills)
 print(f"{path}: {stores} buffer stores of more than 64 bits per lane, {len(found)} followed within "
       f"{store_hazard.WAIT_STATES} wait states by a VALU write of their data registers")
 if found:
     print(store_hazard.describe(found))
-raise SystemExit(1 if found else 0)
+print(f"{len(spills)} register spills / reloads ahead of an exec restore (store_hazard.scan_exec_spills)")
+for k, l in spills[:8]:
+    print(f"  {k[:100]}\n    {l}")
+raise SystemExit(1 if found or spills else 0)
