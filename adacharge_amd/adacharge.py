@@ -212,6 +212,9 @@ class AdaptiveSchedulingAlgorithm(BaseAlgorithm):
         else:
             pl = [peak_limits[k] for k in nonempty]
         res, batch = self._optimizer().solve_table(table, infrastructure, pl, self.interface.get_prev_peak())
+        from .adaptive_charging_optimization import warn_inaccurate
+
+        warn_inaccurate(res.status, res.pri_res, res.dua_res)   # cvxpy's "Solution may be inaccurate" (aco.py:315-321)
         if self.quantize:                                                           # ada.py:176-184
             if self.reallocate:
                 r = diff_based_reallocation_batch(res.x, table, infrastructure, self.interface)

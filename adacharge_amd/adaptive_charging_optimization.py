@@ -181,6 +181,25 @@ def _site_handle(infrastructure, constraint_type, with_peak, device, with_flat=F
     return ent
 
 
+def warn_inaccurate(status, pri_res, dua_res):
+    """A schedule accepted as OPTIMAL_INACCURATE (aco.py:319 accepts it, and so does this path) is announced the way the
+    reference's solver layer announces it -- cvxpy's ``Problem.solve`` emits a UserWarning "Solution may be inaccurate"
+    for that status -- with the residuals the device reached, so the caller can judge the distance to the tolerances
+    asked for (``last_result`` keeps them per problem).  Returns the number of such problems."""
+    import warnings
+
+    from . import backend
+
+    status = np.asarray(status)
+    bad = np.flatnonzero(status == backend.STATUS_SOLVED_INACCURATE)
+    if bad.size:
+        warnings.warn(
+            f"Solution may be inaccurate: {bad.size} of {status.size} problems ended OPTIMAL_INACCURATE "
+            f"(worst primal residual {float(np.max(np.asarray(pri_res)[bad])):.2e}, dual {float(np.max(np.asarray(dua_res)[bad])):.2e}); "
+            "raise max_iter / retry_passes or inspect last_result", UserWarning, stacklevel=3)
+    return int(bad.size)
+
+
 class AdaptiveChargingOptimization:
     """Base class for all MPC based charging algorithms (aco.py:18-43).
 
@@ -443,4 +462,5 @@ class AdaptiveChargingOptimization:
         for j, k in enumerate(nonempty):
             rates[k] = res.x[j, :, : int(batch.T[j])].copy()
             status[k] = res.status[j]
+        warn_inaccurate(res.status, res.pri_res, res.dua_res)
         return rates, status

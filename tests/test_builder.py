@@ -202,3 +202,21 @@ def test_scenario_batch_equals_the_session_by_session_builder():
     assert fast.B == 16 and fast.K == slow.K and fast.Tm == slow.Tm
     uniform = scenario_batch(base, np.array([0.5, 1.0, 2.0]))
     assert np.allclose(uniform.s_cap[2], 2.0 * base.s_cap[0]) and uniform.B == 3
+
+
+def test_optimal_inaccurate_is_announced_like_cvxpy_does():
+    """aco.py:319 accepts OPTIMAL_INACCURATE and so does the drop-in; cvxpy warns "Solution may be inaccurate" for that
+    status and the drop-in's solve paths do the same, with the residuals reached."""
+    import warnings
+
+    import numpy as np
+    import pytest
+
+    from adacharge_amd.adaptive_charging_optimization import warn_inaccurate
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert warn_inaccurate(np.array([1, 1, 3]), np.zeros(3), np.zeros(3)) == 0
+    with pytest.warns(UserWarning, match="may be inaccurate: 2 of 4") as rec:
+        assert warn_inaccurate(np.array([1, 5, 1, 5]), np.array([0, 2e-6, 0, 7e-6]), np.array([0, 1e-7, 0, 3e-6])) == 2
+    assert "7.00e-06" in str(rec[0].message) and "3.00e-06" in str(rec[0].message)
