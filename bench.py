@@ -315,6 +315,19 @@ def host_inclusive_leg(infra, iface, objective, site, handle, opts, n_snapshots=
     out["sessions"] = {"snapshots": n2, "qps": n2 / dt, "ms": 1e3 * dt, "solved": int(sum(o is not None for o in outs)),
                        "note": "lists of SessionInfo objects -> schedule_batch (pre-processing, table entry, post-processing) -> one "
                                "{station: rates} dict per snapshot; one host thread"}
+    # configs[0]'s call pattern: ONE MPC step, AdaptiveSchedulingAlgorithm.schedule(active_sessions) -> {station: rates}
+    # (ada.py:141-194; the reference solves it with cvxpy / ECOS on the CPU) -- the latency a simulator loop sees
+    lat = []
+    for k in range(200):
+        t0 = time.perf_counter()
+        o = alg.schedule(snaps[k])
+        lat.append(time.perf_counter() - t0)
+        assert o is not None
+    lat = np.sort(np.asarray(lat[8:]))
+    out["single_step"] = {"calls": int(lat.size), "ms_median": 1e3 * float(np.median(lat)), "ms_p95": 1e3 * float(lat[int(0.95 * lat.size)]),
+                          "ms_min": 1e3 * float(lat[0]),
+                          "note": "configs[0]: one schedule() call per MPC step on one snapshot (pre-processing, builder, H2D, "
+                                  "kernel, D2H, post-processing; one host thread, nothing batched or overlapped)"}
     return out
 
 

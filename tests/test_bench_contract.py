@@ -67,6 +67,10 @@ def test_committed_bench_line_has_the_contract_fields():
     assert hi["table"]["solved"] == hi["table"]["snapshots"] == 16384 and hi["table"]["qps"] >= 200e3, hi["table"]
     assert hi["table"]["h2d_bytes_per_problem"] < 0.3 * r["hbm"]["bytes_per_qp"]
     assert hi["sessions"]["solved"] == hi["sessions"]["snapshots"]
+    # configs[0]'s call pattern: one schedule() per MPC step; a step of the drop-in stays well under the 5-minute period
+    # and under what one ECOS solve of this size takes on a CPU (tens of milliseconds)
+    ss = hi["single_step"]
+    assert ss["calls"] >= 100 and 0 < ss["ms_min"] <= ss["ms_median"] <= ss["ms_p95"] and ss["ms_median"] < 50.0, ss
     # ... the polish's counters, and a CPU baseline that is not tail-bound (item 7: >= 32 problems per thread)
     pol = d["polish"]
     assert pol["attempted"] > 0 and pol["solved"] >= 0.98 * pol["attempted"], pol
