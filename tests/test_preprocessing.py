@@ -100,3 +100,37 @@ def test_adapter_wires_estimator_and_uninterrupted_charging():
     by_id = {x.session_id: x for x in pre}
     assert np.all(by_id["s0"].max_rates == 12) and np.all(by_id["s1"].max_rates == 32)
     assert by_id["s0"].min_rates[0] == 6 and by_id["s1"].min_rates[0] == 6
+
+
+def test_copy_sessions_is_deepcopy_written_out():
+    """The pre-processing steps copy the sessions before they cap rates (acnportal's preprocessing deep-copies); the
+    written-out copy must give the same independent objects -- for SessionInfo itself and for a subclass with a mutable
+    member of its own."""
+    from copy import deepcopy
+
+    import numpy as np
+
+    from adacharge_amd import sites
+    from adacharge_amd.acn import SessionInfo, copy_sessions, enforce_pilot_limit
+
+    infra = sites.caltech54()
+    sl = sites.snapshot_batch(infra, 12, 1, seed=7)[0]
+
+    class Tagged(SessionInfo):
+        pass
+
+    t = deepcopy(sl[0]); t.__class__ = Tagged; t.tags = ["a", ["b"]]
+    mixed = list(sl) + [t]
+    got, want = copy_sessions(mixed), deepcopy(mixed)
+    for g, w, src in zip(got, want, mixed):
+        assert type(g) is type(src) and vars(g).keys() == vars(w).keys()
+        for k, vw in vars(w).items():
+            vg = getattr(g, k)
+            assert np.array_equal(vg, vw) if isinstance(vw, np.ndarray) else vg == vw, k
+            if isinstance(vw, (np.ndarray, list)):
+                assert vg is not getattr(src, k), k
+    assert got[-1].tags[1] is not t.tags[1]
+    before = [s.max_rates.copy() for s in sl]
+    capped = enforce_pilot_limit(sl, infra)
+    capped[0].max_rates[:] = -1.0
+    assert all(np.array_equal(s.max_rates, b) for s, b in zip(sl, before))   # the caller's sessions are untouched
