@@ -120,6 +120,7 @@ class Options(C.Structure):
         ("polish_iters", C.c_int32),
         ("retry_rho", C.c_double),
         ("inaccurate_floor", C.c_double),
+        ("polish_stall", C.c_int32),
     ]
 
 

@@ -461,6 +461,7 @@ void acnqp_default_options(acnqp_options* o) {
   o->polish_iters = 800;
   o->retry_rho = 0.5;
   o->inaccurate_floor = 1e-5;
+  o->polish_stall = 0;
 }
 
 int acnqp_create(const acnqp_site* site, int32_t device_id, acnqp_handle** out) {
@@ -564,7 +565,7 @@ static int check_problem_shapes(const acnqp_handle* h, const acnqp_problems* p, 
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: null result array");
   if (!(o->eps_abs >= 0) || !(o->eps_rel >= 0) || o->max_iter < 1 || o->check_every < 1 || !(o->rho > 0) ||
       !(o->sigma >= 0) || !(o->alpha > 0 && o->alpha < 2) || !(o->adapt_tol > 1) || !(o->reg_rel >= 0) ||
-      o->adapt_every < 0 || o->polish_iters < 0 || o->stall_iters < 0 || o->retry_passes < 0 || o->retry_passes > 8 || o->retry_max_iter < 1 ||
+      o->adapt_every < 0 || o->polish_iters < 0 || o->polish_stall < 0 || o->stall_iters < 0 || o->retry_passes < 0 || o->retry_passes > 8 || o->retry_max_iter < 1 ||
       !(o->retry_rho > 0) || !(o->inaccurate_floor >= 0))
     return fail(ACNQP_ERR_INVALID, "acnqp_solve_batch: invalid option value");
   if (o->precision != 64)
@@ -752,9 +753,10 @@ int acnqp_solve_batch_device(acnqp_handle* h, const acnqp_problems* p, const acn
     if (a1.polish_iters < o->check_every) a1.polish_iters = o->check_every;
     a1.pol_list = list; a1.pol_count = ctr + 2; a1.y_out = ybuf; a1.pol_rows = pol_max;
     // (measured, wave kernel: the early hand-over takes 5 % off the headline launch and 23 % off configs[3] site 0, and hands
-    //  ten times as many problems to the polish -- one 256-batch per call 81 -> 62 k QP/s, the table path 654 -> 580 k: off)
+    //  ten times as many problems to the polish -- one 256-batch per call 81 -> 62 k QP/s, the table path 654 -> 580 k: off
+    //  by default; options.polish_stall, ABI v9, is the caller's switch, the environment variable the diagnostic one)
     static const int early = std::getenv("ACNQP_EARLY_HANDOVER") ? std::atoi(std::getenv("ACNQP_EARLY_HANDOVER")) : 0;   // diagnostic: the window (1: polish_iters / 4)
-    a1.polish_stall = early > 1 ? early : (early == 1 ? std::max(o->check_every, a1.polish_iters / 4) : 0);
+    a1.polish_stall = early > 1 ? early : (early == 1 ? std::max(o->check_every, a1.polish_iters / 4) : o->polish_stall);
     a1.y_for_polish_only = r->y ? 0 : 1;
     e = launch_solver(a1);
     if (e == hipSuccess) {

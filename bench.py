@@ -244,6 +244,19 @@ def other_configs_leg(dev, only=None):
             "flops_per_iteration_sparse": fl, "fp64_TFs": tf, "fp64_frac": tf / FP64_VALU_PEAK_TF,
             "build_s": t_build,
         }
+        if name.startswith("cfg3_"):
+            # configs[3] is the scenario MPC: 1,024 problems per GPU, each with a wavefront of its own -- the launch lasts
+            # as long as its slowest problem.  options.polish_stall (ABI v9, off by default) hands a stalled problem to the
+            # polish early; reported beside the default, never instead of it
+            from adacharge_amd.backend import default_options
+
+            o2 = default_options(polish_stall=100)
+            for f, _ in opts._fields_:
+                if f != "polish_stall":
+                    setattr(o2, f, getattr(opts, f))
+            ms2, it2, st2, _ = time_device_launch(batch, o2, dev)
+            out[name]["polish_stall_100"] = {"kernel_ms": ms2, "qps": batch.B / (ms2 * 1e-3), "iters_mean": float(it2.mean()),
+                                             "iters_max": int(it2.max()), "solved": int((st2 == 1).sum())}
     return out
 
 

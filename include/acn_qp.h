@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define ACNQP_ABI_VERSION 8
+#define ACNQP_ABI_VERSION 9
 
 /* cone of the infrastructure rows (constraint_type at aco.py:35, 151, 165) */
 #define ACNQP_CONE_LINEAR 0
@@ -188,6 +188,16 @@ typedef struct {
                             iterations still counts as SOLVED_INACCURATE even when 100x the requested tolerance
                             is tighter.  Default 1e-5 (what cvxpy hands OSQP as eps_abs = eps_rel).  0 = the
                             100x rule alone                                                               */
+  /* -- ABI v9 ------------------------------------------------------------------------------------------ */
+  int32_t polish_stall;  /* early hand-over to the polish (one-wave-per-problem kernel: N <= 64, horizon <= 12 with up to 16
+                            site rows): from polish_iters / 2 on, a problem whose residual score has not improved by 10 % for
+                            this many iterations goes to the polish at once instead of at polish_iters.  For a launch in
+                            which every problem has a wavefront of its own -- up to 1,024 per GPU: the scenario MPC of
+                            BASELINE configs[3] -- the launch lasts as long as its slowest problem, and 100 takes a
+                            quarter off it (1,024 scenarios of one site: 3.4 -> 2.5 ms, 9.8 -> 7.3 ms).  On a
+                            throughput-bound launch it sends ten times as many problems to the polish, most of which
+                            the ADMM would have finished by itself: slower (one 256-batch per call 81 -> 62 k QP/s).
+                            Same optimum either way (the polish verifies the KKT conditions).  0 = off.  Default 0 */
 } acnqp_options;
 
 /* acnqp_create -- uploads the site once.  Replaces the per-call rebuilding of

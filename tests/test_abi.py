@@ -26,13 +26,13 @@ def test_header_symbols_all_exported(hip_library):
 
 
 def test_abi_version_and_defaults(hip_library):
-    assert hip_library.acnqp_abi_version() == 8
+    assert hip_library.acnqp_abi_version() == 9
     o = backend.default_options()
     assert o.precision == 64 and 0 < o.alpha < 2 and o.max_iter > 0 and o.eps_abs > 0
     # ABI v7: stall rule and retry passes are options of the library (every entry point), not of the binding
     assert o.stall_iters == 3000 and o.retry_passes == 2 and o.retry_max_iter == 8000 and o.retry_rho == 0.5
-    assert o.inaccurate_floor == 1e-5 and o.polish_iters == 800
-    assert C.sizeof(backend.Options) == 112   # sizeof(acnqp_options) as gcc lays the header out
+    assert o.inaccurate_floor == 1e-5 and o.polish_iters == 800 and o.polish_stall == 0
+    assert C.sizeof(backend.Options) == 120   # sizeof(acnqp_options) as gcc lays the header out
     o2 = backend.default_options(eps_abs=1e-9, max_iter=5)
     assert o2.eps_abs == 1e-9 and o2.max_iter == 5
     with pytest.raises(TypeError):

@@ -62,6 +62,9 @@ def test_committed_bench_line_has_the_contract_fields():
     # round 4: the straggler tail is gone from the congested configs[3] site (<= 2,500 iterations, <= 15 ms)
     s3 = legs["cfg3_site3_T12_b1024"]
     assert s3["iters_max"] <= 2500 and s3["kernel_ms"] <= 15.0, s3
+    # ... and the early hand-over (options.polish_stall, ABI v9) is reported beside the default for the scenario legs
+    e3 = s3["polish_stall_100"]
+    assert e3["solved"] == s3["batch"] and e3["iters_max"] <= s3["iters_max"] and e3["kernel_ms"] <= 1.05 * s3["kernel_ms"], (s3, e3)
     # ... the host side is in the driver's line (item 4: >= 200 k QP/s from a SessionTable, the builder inside the clock)
     hi = d["host_inclusive"]
     assert hi["table"]["solved"] == hi["table"]["snapshots"] == 16384 and hi["table"]["qps"] >= 200e3, hi["table"]

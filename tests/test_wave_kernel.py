@@ -126,3 +126,43 @@ def test_default_routing_is_by_shape_and_matches_the_twin():
     # 1,024 problems, one per wave, four per CU: the slowest problem's ~800 iterations at ~4.3 us (the tiled kernel, two
     # problems per CU, needed two rounds of them: 7.7 ms at 4,096)
     assert ms_big < 5.0, ms_big
+
+
+@pytest.mark.gpu
+def test_polish_stall_option_shortens_a_scenario_launch_and_keeps_the_optimum():
+    """options.polish_stall (ABI v9): from polish_iters / 2 on, a problem whose residual score has stood still for that
+    many iterations goes to the polish at once.  On the scenario MPC of BASELINE configs[3] -- 1,024 demand scenarios of
+    one site, a wavefront each, so the launch lasts as long as its slowest problem -- the option cuts the longest ADMM run
+    and the launch; every problem is still SOLVED, at the same (unique: equal_share 1e-3) optimum, and the polish is
+    the one that did the extra work.  Off by default: the same launch at default options does not change."""
+    import torch
+
+    from adacharge_amd.acn import Interface
+    from adacharge_amd.backend import DeviceBatch, SiteHandle, default_options
+    from adacharge_amd.builder import scenario_batch
+
+    infra = sites.eight_sites()[0]
+    iface = Interface({"infrastructure_info": infra, "period": 5})
+    rng = np.random.default_rng(500)
+    obj = [ObjectiveComponent(quick_charge), ObjectiveComponent(equal_share, 1e-3)]
+    base = build_batch([sites.random_sessions(infra, 12, rng)], infra, iface, obj, "SOC")
+    batch = scenario_batch(base, rng.lognormal(0.0, 0.25, size=(1024, base.K, base.N)))
+    h = SiteHandle(batch.site, 0)
+    assert default_options().polish_stall == 0
+    with pytest.raises(ValueError):
+        h.solve(batch.subset(slice(0, 4)), default_options(polish_stall=-1))
+    dev = DeviceBatch(batch, "cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for tag, opts in (("default", default_options()), ("early", default_options(polish_stall=100))):
+        before = h.polish_stats()
+        h.solve_device(dev, opts, stream=st); torch.cuda.synchronize()
+        tried = h.polish_stats()["attempted"] - before["attempted"]
+        h.solve_device(dev, opts, stream=st); torch.cuda.synchronize()
+        out[tag] = (dev.x.cpu().numpy().copy(), dev.iters.cpu().numpy().copy(), dev.status.cpu().numpy().copy(), h.last_kernel_ms(), tried)
+    h.close()
+    (xd, itd, std_, msd, trd), (xe, ite, ste, mse, tre) = out["default"], out["early"]
+    assert (std_ == 1).all() and (ste == 1).all()
+    assert np.abs(xd - xe).max() <= RATE_TOL
+    assert tre > trd and ite.max() < itd.max(), (trd, tre, itd.max(), ite.max())
+    assert mse < 0.95 * msd, (msd, mse)
