@@ -129,7 +129,10 @@ def scan_isa(text):
 
 
 _EXEC_WRITE = re.compile(r"^s_\w+_saveexec_b64\b|^s_\w+\s+exec\b|^s_\w+\s+exec_(lo|hi)\b")
-_EXEC_BLIND = re.compile(r"^(v_writelane_b32\b|v_readlane_b32\b|s_nop\b|s_waitcnt\b|scratch_store_|scratch_load_)")
+_EXEC_BLIND = re.compile(r"^(v_writelane_b32\b|v_readlane_b32\b|s_nop\b|s_waitcnt\b|scratch_store_|scratch_load_|v_accvgpr_(write|read)_b32\b)")
+# (scratch accesses only: the allocator also spills to AGPRs, but a v_accvgpr copy cannot be told from the masked update of
+#  a variable that lives there -- the tiled kernel has fourteen legitimate ones in this position)
+_SPILL_LIKE = re.compile(r"^scratch_(store|load)_")
 
 
 def scan_exec_spills(text):
@@ -141,7 +144,7 @@ def scan_exec_spills(text):
     scratch access forward over instructions that do not depend on exec (SGPR spills by v_writelane, scalar ALU, waits);
     reaching the exec restore before anything else, in a block that has not itself narrowed exec, is the pattern."""
     ins = _parse(text)
-    leaders = set()
+    leaders, targets = set(), set()
     where = {}
     for idx, (kind, l, addr, _) in enumerate(ins):
         if kind == "ins" and addr is not None:
@@ -155,24 +158,31 @@ def scan_exec_spills(text):
         if _BRANCH.match(l):
             leaders.add(idx + 1)
             if target in where:
-                leaders.add(where[target])
+                t = where[target]
+                while t < len(ins) and ins[t][0] != "ins":   # a .L label of a -S listing: its first instruction
+                    t += 1
+                leaders.add(t)
+                targets.add(t)
     kern, found = "?", []
     for idx, (kind, l, _, _) in enumerate(ins):
         if kind == "label":
             kern = l
             continue
-        if kind != "ins" or not re.match(r"scratch_(store|load)", l):
+        if kind != "ins" or not _SPILL_LIKE.match(l):
             continue
-        # back to the block leader: the block must not have narrowed exec itself before this access
-        j, own = idx - 1, False
+        # back to the block leader: the block must be a JOIN (some branch lands on it -- the fall-through block behind
+        # an s_cbranch_execz is the region's own body, whose masked accesses are its business) and must not have
+        # narrowed exec itself before this access
+        j, own, lead = idx, False, None
         while j >= 0 and ins[j][0] == "ins":
-            if _EXEC_WRITE.match(ins[j][1]):
+            if j != idx and _EXEC_WRITE.match(ins[j][1]):
                 own = True
                 break
             if j in leaders:
+                lead = j
                 break
             j -= 1
-        if own:
+        if own or lead not in targets:
             continue
         j = idx + 1
         while j < len(ins) and ins[j][0] == "ins" and j not in leaders:
