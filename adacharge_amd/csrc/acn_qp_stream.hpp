@@ -777,51 +777,54 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
   };
   // back: box + energy-row projection of zh one register row at a time, z1 and y1 stored, the tile's NEW r0 left in zh
   auto tile_back = [&](int e, real (&zh)[4][CT], const real (&sq)[4][CT]) __attribute__((always_inline)) {
-    // the bounds and session slots of all four register rows are requested at once: one memory round trip per tile
-    // instead of four + four.  (Requesting them BEFORE tile_front, under its loads and MFMA chain, was measured too:
-    // 468 -> 507 ms on the configs[4] leg -- the 64 registers they pin spill the front.)
+    // the session slots of all four register rows are requested at once; the bounds one register PAIR at a time, right
+    // before that pair's rows are projected: 24 registers held instead of 48, which takes 7 of the 11 spill stores and 6
+    // of the 20 reloads out of the tile loop (272 -> 208 B of scratch per lane; configs[4] leg 421.8 -> 417.4 ms, A/B in
+    // one session) at the price of a second dependent round trip per tile.  (Requesting all of them BEFORE tile_front,
+    // under its loads and MFMA chain, was measured too: 468 -> 507 ms -- the 64 registers they pin spill the front.)
     // Flat tiles.  The rate bounds of a session are two constants inside its window and zero outside (aco.py:45-73), so
     // per lane the CT (l, u) pairs of a row nearly always take ONE non-zero value: the init phase checks exactly that and
     // keeps (l, u) per row + one word of period bits per lane; such a tile's bounds are rebuilt from 68 bytes per lane
     // instead of streamed (2 x 4 x CT x 8) -- bit for bit the same numbers.  Any other tile streams them as before.
-    real lb4[4][CT], ub4[4][CT];
     const bool flat = flat_on && __builtin_amdgcn_readfirstlane((int)TileFlat[e]) != 0;
+    ws_d2_s lu[4];
+    unsigned mk = 0;
     if (flat) {
-      ws_d2_s lu[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         lu[r] = __builtin_bit_cast(ws_d2_s, __builtin_amdgcn_raw_buffer_load_b128(wsr, (unsigned)lane * 16u, cblu + (unsigned)(e * 4 + r) * 1024u, 0));
-      const unsigned mk = __builtin_amdgcn_raw_buffer_load_b32(wsr, (unsigned)lane * 4u, cbm + (unsigned)e * 256u, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          const bool on = (mk >> (r * CT + c)) & 1u;
-          lb4[r][c] = on ? lu[r].x : 0.0; ub4[r][c] = on ? lu[r].y : 0.0;
-        }
-    } else {
-#pragma unroll
-    for (int rp = 0; rp < 2; ++rp)
-#pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        const unsigned i = fidp(e, c, rp);
-        ld2_nt(oLB, i, lb4[2 * rp][c], lb4[2 * rp + 1][c]); ld2_nt(oUB, i, ub4[2 * rp][c], ub4[2 * rp + 1][c]);
-      }
+      mk = __builtin_amdgcn_raw_buffer_load_b32(wsr, (unsigned)lane * 4u, cbm + (unsigned)e * 256u, 0);
     }
     Slot0 s4[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) s4[r] = slot0_of(e, r);
 #pragma unroll
-    for (int rp = 0; rp < 2; ++rp) {   // the two rows of a register pair, then their 16-byte stores
+    for (int rp = 0; rp < 2; ++rp) {
+      real lbp[2][CT], ubp[2][CT];
+      if (flat) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int c = 0; c < CT; ++c) {
+            const bool on = (mk >> ((2 * rp + h) * CT + c)) & 1u;
+            lbp[h][c] = on ? lu[2 * rp + h].x : 0.0; ubp[h][c] = on ? lu[2 * rp + h].y : 0.0;
+          }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const unsigned i = fidp(e, c, rp);
+          ld2_nt(oLB, i, lbp[0][c], lbp[1][c]); ld2_nt(oUB, i, ubp[0][c], ubp[1][c]);
+        }
+      }
       real z1a[CT], z1b[CT];
-      project_row(e, 2 * rp, zh[2 * rp], lb4[2 * rp], ub4[2 * rp], z1a, false, s4[2 * rp]);
-      project_row(e, 2 * rp + 1, zh[2 * rp + 1], lb4[2 * rp + 1], ub4[2 * rp + 1], z1b, false, s4[2 * rp + 1]);
+      project_row(e, 2 * rp, zh[2 * rp], lbp[0], ubp[0], z1a, false, s4[2 * rp]);
+      project_row(e, 2 * rp + 1, zh[2 * rp + 1], lbp[1], ubp[1], z1b, false, s4[2 * rp + 1]);
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const unsigned i = fidp(e, c, rp);
         const real ya = rho * (zh[2 * rp][c] - z1a[c]), yb = rho * (zh[2 * rp + 1][c] - z1b[c]);
         st2_nt(oZ1, i, z1a[c], z1b[c]); st2_nt(oY1, i, ya, yb);
-        zh[2 * rp][c] = sq[2 * rp][c] + rho * z1a[c] - ya;   // the new r0, in zh's registers
+        zh[2 * rp][c] = sq[2 * rp][c] + rho * z1a[c] - ya;
         zh[2 * rp + 1][c] = sq[2 * rp + 1][c] + rho * z1b[c] - yb;
       }
     }
