@@ -119,6 +119,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
   constexpr int AMX = kStreamAccelMax;
   __shared__ real AaRedS[NWV * (AMX + 2)];               // per-wave partial dot products of an Anderson event
   __shared__ real AaHS[NWV * (AMX * AMX + AMX)];         // every wave's own copy of the Gram matrix and rhs
+  __shared__ real ResS[NWV * 8];                          // per wave: the residual terms of a check iteration
   // Clearing a wave's copy: EVERY lane stores (the lanes beyond the 30 entries repeat the last one) -- no divergent
   // region.  Behind the `if (lane < 30)` form the compiler (ROCm 7.2) placed the spill of two values that live across
   // the solver loop BEFORE the exec restore of the region's end: stored with no lane enabled, reloaded as garbage (the
@@ -829,9 +830,19 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
       }
     }
   };
-  real v0, v1, v2, v4, v5;   // residual terms of the iteration's check
+  // Residual terms of the iteration's check: per wave in LDS (ResS), not in registers -- as five loop-carried maxima
+  // (plus the site rows' two) they lived across the tile loop of EVERY iteration for the sake of one iteration in twenty,
+  // and the allocator spilled and reloaded them around every tile (4 of the tile loop's spill stores and 8 of its
+  // reloads).  A maximum does not care in which order or grouping it is taken: same bits.
+  auto fold_site_residuals = [&](bool chk) __attribute__((always_inline)) {   // before a tile loop: sv0 / sv2 end here
+    if (chk) {
+      const real m0 = wave_max<real>(sv0), m2 = wave_max<real>(sv2);
+      if (lane == 0) { ResS[wave * 8 + 0] = m0; ResS[wave * 8 + 1] = 0; ResS[wave * 8 + 2] = m2; ResS[wave * 8 + 3] = 0; ResS[wave * 8 + 4] = 0; }
+    }
+  };
   auto tile_residuals = [&](int e) __attribute__((always_inline)) {
     // residual terms of this tile (state re-read: L2-hot); (G' y2) tile by MFMA with the un-rotated site matrix
+    real v0 = 0, v1 = 0, v2 = 0, v4 = 0, v5 = 0;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       vec4 gty = {0, 0, 0, 0};
@@ -850,6 +861,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
         v4 = fmax(v4, fabs(pd * xk));
         v5 = fmax(v5, fabs(yk + gty[r]));
       }
+    }
+    v0 = wave_max<real>(v0); v1 = wave_max<real>(v1); v2 = wave_max<real>(v2); v4 = wave_max<real>(v4); v5 = wave_max<real>(v5);
+    if (lane == 0) {
+      real* R = ResS + wave * 8;
+      R[0] = fmax(R[0], v0); R[1] = fmax(R[1], v1); R[2] = fmax(R[2], v2); R[3] = fmax(R[3], v4); R[4] = fmax(R[4], v5);
     }
   };
 #ifdef ACNQP_STAMPS
@@ -954,9 +970,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
     }
     __syncthreads();
     STAMP(0);   // eigen step + site rows + their two barriers
-    v0 = 0; v1 = 0; v2 = 0; v4 = 0; v5 = 0;
     if (!ev_it) {
       if (dc_on && wave == kStreamWaves - 1) { RELANE(); dc_row(); }
+      fold_site_residuals(check);
       // ---- the fused pass over this wave's EVSE tiles -----------------------------------------------------------
       zero_pown();
 #pragma unroll 1
@@ -1167,6 +1183,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
       }
       __syncthreads();
       if (dc_on && wave == kStreamWaves - 1) { RELANE(); dc_row(); }
+      fold_site_residuals(check);
       // ---- pass B: the extrapolated zh of every tile -> projection, y1, the new r0 -> P ----------------------------
       zero_pown();
 #pragma unroll 1
@@ -1204,7 +1221,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? ACNQP_STREAM_OCC : 1) void adm
       asm volatile("" : "+s"(soff_));
       float* Y1P = reinterpret_cast<float*>(W0 + off_snap + soff_);
       float* Y2P = Y1P + NT;
-      real v[5] = {fmax(v0, sv0), v1, fmax(v2, sv2), v4, v5};
+      real v[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) v[k] = ResS[wave * 8 + k];   // (site rows folded in before the tile loop)
       stream_block_max<5, NWV>(v, SC, lane, wave);
       pri = v[0]; dua = v[1];
       const real npri = v[2], ndua = fmax(fmax(v[3], v[4]), qnorm);
