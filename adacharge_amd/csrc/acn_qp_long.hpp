@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
   // non-zero value: the init phase checks exactly that, lane by lane, and keeps (l, u) + a CTL-bit mask; phase 2 then
   // rebuilds the bounds of a row item from 40 bytes per lane instead of streaming 2 x 2 x CTL x 8 -- bit for bit the
   // same numbers.  An item with a lane that does not fit (per-period max_rates) streams its bounds as before.
-  constexpr bool kFlat = !LDSR && CTL <= kLongPairRows && ACNQP_LONG_FLAT_BOUNDS;
+  constexpr bool kFlat = !LDSR && CTL <= 31 && ACNQP_LONG_FLAT_BOUNDS;   // (the period bits of a row fit one word)
   const bool flat_on = kFlat && 4 * NE <= kLongFlatRows;
   const unsigned cblu = (unsigned)(SA.ws_per_problem - long_flat_doubles(NP)) * 8u;   // [item][row of the pair][lane] (l, u)
   const unsigned cbm = cblu + (unsigned)NE * 4096u;                                   // [item][lane] two masks
@@ -1026,10 +1026,23 @@ __global__ __launch_bounds__(NWV * 64, 1) void admm_long_kernel(const StreamArgs
       const int e = ri >> 2, r = ri & 3;
       if (16 * e + 4 * r >= N) continue;   // four padding EVSEs: zeros that stay zeros (see the pair-row loop)
       real zh[CTL], lbv[CTL], ubv[CTL], z1[CTL];
+      bool flat = false;
+      if constexpr (kFlat) flat = flat_on && __builtin_amdgcn_readfirstlane((int)RowFlat[ri]) != 0;   // this row alone
+      if (flat) {   // flat items: (l, u) + the row's period bits instead of 2 x CTL x 8 bytes (same slots as the pair items)
+        const ws_d2 lu = __builtin_bit_cast(ws_d2, __builtin_amdgcn_raw_buffer_load_b128(wsr, (unsigned)lane * 16u, cblu + (unsigned)ri * 1024u, 0));
+        const unsigned mk = __builtin_amdgcn_raw_buffer_load_b32(wsr, (unsigned)lane * 8u, cbm + (unsigned)(ri >> 1) * 512u + (unsigned)(ri & 1) * 4u, 0);
 #pragma unroll
-      for (int c = 0; c < CTL; ++c) {   // padding columns hold zeros and stay zero
-        const unsigned i = fidx(e, c, r);
-        zh[c] = at(RZ, i); lbv[c] = at(LBs, i); ubv[c] = at(UBs, i);
+        for (int c = 0; c < CTL; ++c) {
+          zh[c] = at(RZ, fidx(e, c, r));
+          const bool on = (mk >> c) & 1u;
+          lbv[c] = on ? lu.x : 0.0; ubv[c] = on ? lu.y : 0.0;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < CTL; ++c) {   // padding columns hold zeros and stay zero
+          const unsigned i = fidx(e, c, r);
+          zh[c] = at(RZ, i); lbv[c] = at(LBs, i); ubv[c] = at(UBs, i);
+        }
       }
       project_row(e, r, zh, lbv, ubv, z1, false);
       STAMP(5);   // row loads, water-filling

@@ -805,10 +805,11 @@ def test_long_horizon_kernel_matches_c_twin(site_name, T, ct, accel):
     h.close()
 
 
-@pytest.mark.parametrize("T", [96, 144])
+@pytest.mark.parametrize("T", [96, 144, 200])
 def test_long_horizon_kernel_bounds_that_do_not_compress(T):
     """Round 4: a row item whose bounds are one (l, u) pair inside the windows and zero outside is rebuilt from 40 bytes
-    per lane instead of streamed (acn_qp_long.hpp, `flat items`).  Per-period maximum rates (aco.py:45-73 takes
+    per lane instead of streamed (acn_qp_long.hpp, `flat items`; horizon 200 takes the one-row items of horizons beyond
+    144, which rebuild a single row the same way).  Per-period maximum rates (aco.py:45-73 takes
     session.max_rates as an array) do not fit that form: here every third period of half the EVSEs is derated and some
     periods carry a minimum rate, so items of both kinds sit in one problem.  Plain ADMM must still follow the C twin
     iteration for iteration -- a rebuilt bound that differed in one bit, or an item wrongly taken for flat, parts them."""
