@@ -35,6 +35,18 @@ def test_abi_version_and_defaults(hip_library):
     assert C.sizeof(backend.Options) == 120   # sizeof(acnqp_options) as gcc lays the header out
     o2 = backend.default_options(eps_abs=1e-9, max_iter=5)
     assert o2.eps_abs == 1e-9 and o2.max_iter == 5
+    assert backend.default_options(polish_stall=100).polish_stall == 100      # ABI v9: the last field of the structure
+    # the header's own layout (compiled here with gcc): the new field sits behind inaccurate_floor, where the binding has it
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "o.c")
+        with open(src, "w") as f:
+            f.write('#include <stdio.h>\n#include <stddef.h>\n#include "acn_qp.h"\nint main(){printf("%zu %zu %zu", sizeof(acnqp_options), '
+                    'offsetof(acnqp_options, polish_stall), offsetof(acnqp_options, inaccurate_floor));return 0;}')
+        exe = os.path.join(tmp, "o")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe], check=True)
+        size, off_stall, off_floor = map(int, subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split())
+    assert size == C.sizeof(backend.Options) and off_stall == backend.Options.polish_stall.offset and off_floor == backend.Options.inaccurate_floor.offset
     with pytest.raises(TypeError):
         backend.default_options(nonsense=1)
 
